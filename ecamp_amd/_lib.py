@@ -1,0 +1,70 @@
+"""ctypes binding of libecamp_hip.so.  The prototypes are parsed from include/ecamp_hip.h so the binding can
+never drift from the declared C ABI.  There is NO fallback: if the library is missing or a call fails, we raise."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libecamp_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "ecamp_hip.h")
+
+F32, BF16 = 0, 1
+
+_CT = {
+    "int": ctypes.c_int32, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+    "float": ctypes.c_float, "ecampStream_t": ctypes.c_void_p,
+}
+
+
+class EcampHipError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(ctype, argname), ...])} for every `int ecamp_*(...)` / `const char* ecamp_*` prototype."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(ecamp_\w+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argl = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("", "void"):
+                continue
+            if "*" in a:
+                ct, an = ctypes.c_void_p, a.split("*")[-1].strip()
+            else:
+                parts = a.split()
+                ct, an = _CT[parts[-2]], parts[-1]
+            argl.append((ct, an))
+        protos[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int32, argl)
+    return protos
+
+
+_lib = None
+_protos = None
+
+
+def load():
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EcampHipError("libecamp_hip.so not found at %s -- run `python -m ecamp_amd.build` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (ret, args) in _protos.items():
+        fn = getattr(lib, name)  # raises AttributeError if the symbol is not exported
+        fn.restype = ret
+        fn.argtypes = [a[0] for a in args]
+    if lib.ecamp_abi_version() != 1:
+        raise EcampHipError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise EcampHipError("%s failed (rc=%d): %s" % (name, rc, lib.ecamp_last_error().decode()))

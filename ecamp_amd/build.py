@@ -1,0 +1,65 @@
+"""Build libecamp_hip.so (gfx950 only) from ecamp_amd/csrc/*.hip with hipcc.
+
+    python -m ecamp_amd.build            # incremental
+    python -m ecamp_amd.build --force
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container; the resulting in-tree
+`ecamp_amd/libecamp_hip.so` travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(os.path.dirname(HERE), "build")
+LIB = os.path.join(HERE, "libecamp_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    jobs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s[:-4] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        r = subprocess.run([hipcc] + FLAGS + ["-c", src, "-o", obj], capture_output=True, text=True)
+        return src, r.returncode, r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for src, rc, err in ex.map(cc, jobs):
+                if verbose:
+                    print("[ecamp_amd.build] hipcc %s -> rc %d" % (os.path.basename(src), rc), flush=True)
+                if rc != 0:
+                    raise RuntimeError("hipcc failed on %s:\n%s" % (src, err))
+    objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
+    if force or jobs or _stale(LIB, objs):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr)
+        if verbose:
+            print("[ecamp_amd.build] linked %s" % LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

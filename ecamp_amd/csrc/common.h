@@ -1,0 +1,133 @@
+// Shared device/host helpers for libecamp_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define ECAMP_F32 0
+#define ECAMP_BF16 1
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // MFMA bf16 operand (8 x bf16 = 4 VGPRs)
+
+extern thread_local char g_ecamp_err[512];
+int ecamp_set_error(int code, const char* fmt, ...);
+
+#define ECAMP_CHECK_ARG(cond, ...)                         \
+    do {                                                   \
+        if (!(cond)) return ecamp_set_error(-1, __VA_ARGS__); \
+    } while (0)
+
+#define ECAMP_LAUNCH_CHECK()                                                        \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) return ecamp_set_error((int)e_, "%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+// value after a round trip through storage type T (used so fwd statistics match what bwd re-reads)
+template <typename T> __device__ __forceinline__ float rnd(float v) { return to_f<T>(from_f<T>(v)); }
+
+// 4-element vector load/store (16 B for f32, 8 B for bf16); pointers must be suitably aligned
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&o)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&o)[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+    v.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions (all 64 lanes end with the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block reduction for blockDim.x == 256 (4 waves); `sh` must hold >= 4 floats. All threads get the sum.
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (Salmon et al. 2011).  One call yields 4 x 32 random bits for counter
+// (idx_lo, idx_hi, offset_lo, offset_hi) under key `seed`.  Forward and backward regenerate identical
+// masks from (seed, offset, element index): no mask tensor ever touches HBM.
+__device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// keep-mask scale for element `e` of a tensor: returns 0 or 1/(1-p).  4 consecutive elements share one
+// Philox call (counter = e >> 2, word = e & 3).
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t offset, uint64_t e, float p, float inv_keep) {
+    uint4 r = philox4x32(seed, offset, e >> 2);
+    uint32_t w = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+    // uniform in [0,1): keep iff u >= p
+    float u = (float)(w >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.0f;
+}
+__device__ __forceinline__ void dropout_scale4(uint64_t seed, uint64_t offset, uint64_t e4, float p, float inv_keep,
+                                               float (&s)[4]) {
+    uint4 r = philox4x32(seed, offset, e4);
+    s[0] = ((float)(r.x >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
+    s[1] = ((float)(r.y >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
+    s[2] = ((float)(r.z >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
+    s[3] = ((float)(r.w >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
+}
+
+// exact (erf) GELU and its derivative -- nn.GELU() default in timm Mlp / HF "gelu"
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,233 @@
+// LayerNorm forward / backward.  HBM-bound: one wave64 per row, 4-element vector
+// accesses, wave-shuffle reductions, fp32 statistics.  The BERT post-LN form
+//     y = LN( dropout(x) + residual )
+// is fused: the Philox keep-mask is regenerated from (seed, offset, element index) in the backward pass,
+// so no mask tensor is stored; `z = dropout(x) + residual` is written once because backward needs it.
+#include "common.h"
+
+template <typename T, int IT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ zout,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                     long rows, int cols, float eps, float drop_p, uint64_t seed,
+                                                     uint64_t offset) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = cols >> 2;
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    float v[IT][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        int c = lane + 64 * i;
+        if (c < nv) {
+            ld4<T>(x + row * cols + c * 4, v[i]);
+            if (drop_p > 0.f) {
+                float m[4];
+                dropout_scale4(seed, offset, (uint64_t)(row * nv + c), drop_p, inv_keep, m);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] *= m[r];
+            }
+            if (res) {
+                float q[4];
+                ld4<T>(res + row * cols + c * 4, q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] += q[r];
+            }
+            if (zout) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] = rnd<T>(v[i][r]);
+                st4<T>(zout + row * cols + c * 4, v[i]);
+            }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i][r] = 0.f;
+        }
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        int c = lane + 64 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float d = v[i][r] - mu;
+                q += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        int c = lane + 64 * i;
+        if (c < nv) {
+            float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+            float4 b = *reinterpret_cast<const float4*>(beta + c * 4);
+            float o[4];
+            o[0] = (v[i][0] - mu) * rs * g.x + b.x;
+            o[1] = (v[i][1] - mu) * rs * g.y + b.y;
+            o[2] = (v[i][2] - mu) * rs * g.z + b.z;
+            o[3] = (v[i][3] - mu) * rs * g.w + b.w;
+            st4<T>(y + row * cols + c * 4, o);
+        }
+    }
+}
+
+// dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ;  dz += dres_in
+// dx_drop = dz * keepmask/(1-p)   (gradient reaching the dense output through the dropout)
+// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy     (f32 atomics, one set per block)
+template <typename T, int IT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                     T* __restrict__ dz, T* __restrict__ dxdrop, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, long rows, int cols, float drop_p,
+                                                     uint64_t seed, uint64_t offset) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // [4][cols]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = cols >> 2;
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    float ag[IT][4], ab[IT][4], gm[IT][4];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        int c = lane + 64 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ag[i][r] = ab[i][r] = 0.f;
+        if (c < nv) {
+            float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+            gm[i][0] = g.x; gm[i][1] = g.y; gm[i][2] = g.z; gm[i][3] = g.w;
+        } else {
+            gm[i][0] = gm[i][1] = gm[i][2] = gm[i][3] = 0.f;
+        }
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[IT][4], g[IT][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            int c = lane + 64 * i;
+            if (c < nv) {
+                float d[4], zz[4];
+                ld4<T>(dy + row * cols + c * 4, d);
+                ld4<T>(z + row * cols + c * 4, zz);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xh[i][r] = (zz[r] - mu) * rs;
+                    g[i][r] = d[r] * gm[i][r];
+                    s1 += g[i][r];
+                    s2 += g[i][r] * xh[i][r];
+                    ag[i][r] += d[r] * xh[i][r];
+                    ab[i][r] += d[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xh[i][r] = g[i][r] = 0.f;
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            int c = lane + 64 * i;
+            if (c < nv) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = rs * (g[i][r] - s1 - xh[i][r] * s2);
+                if (dres) {
+                    float q[4];
+                    ld4<T>(dres + row * cols + c * 4, q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += q[r];
+                }
+                st4<T>(dz + row * cols + c * 4, o);
+                if (dxdrop) {
+                    if (drop_p > 0.f) {
+                        float m[4];
+                        dropout_scale4(seed, offset, (uint64_t)(row * nv + c), drop_p, inv_keep, m);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = rnd<T>(o[r]) * m[r];
+                    }
+                    st4<T>(dxdrop + row * cols + c * 4, o);
+                }
+            }
+        }
+    }
+    // block reduction of the per-lane column partials, then one atomic set per block
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            int c = lane + 64 * i;
+            if (c < nv) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sh[wave * cols + c * 4 + r] = pass == 0 ? ag[i][r] : ab[i][r];
+            }
+        }
+        __syncthreads();
+        float* dst = pass == 0 ? dgamma : dbeta;
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            float t = sh[c] + sh[cols + c] + sh[2 * cols + c] + sh[3 * cols + c];
+            atomicAdd(dst + c, t);
+        }
+    }
+}
+
+template <typename T>
+static int ln_fwd_launch(const void* x, const void* res, void* z, const float* gamma, const float* beta, void* y, float* mean,
+                         float* rstd, long rows, int cols, float eps, float p, uint64_t seed, uint64_t off, hipStream_t st) {
+    dim3 grid(ceil_div(rows, 4)), block(256);
+    const int it = ceil_div(cols / 4, 64);
+#define L(IT_) hipLaunchKernelGGL((ln_fwd_kernel<T, IT_>), grid, block, 0, st, (const T*)x, (const T*)res, (T*)z, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, p, seed, off)
+    if (it <= 1) L(1); else if (it <= 2) L(2); else if (it <= 3) L(3); else if (it <= 4) L(4); else L(8);
+#undef L
+    return 0;
+}
+
+extern "C" int ecamp_layernorm_fwd(const void* x, const void* residual, void* z_out, const float* gamma, const float* beta,
+                                   void* y, float* mean, float* rstd, int64_t rows, int32_t cols, float eps, float drop_p,
+                                   uint64_t seed, uint64_t offset, int32_t dtype, hipStream_t stream) {
+    ECAMP_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    ECAMP_CHECK_ARG(cols % 4 == 0 && cols <= 2048 && rows > 0, "layernorm_fwd: cols=%d must be a multiple of 4 and <= 2048", cols);
+    ECAMP_CHECK_ARG(!(residual || drop_p > 0.f) || z_out, "layernorm_fwd: fused residual/dropout needs z_out");
+    if (dtype == ECAMP_F32) ln_fwd_launch<float>(x, residual, z_out, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p, seed, offset, stream);
+    else if (dtype == ECAMP_BF16) ln_fwd_launch<bf16_t>(x, residual, z_out, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p, seed, offset, stream);
+    else return ecamp_set_error(-1, "layernorm_fwd: bad dtype %d", dtype);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int ln_bwd_launch(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                         const void* dres, void* dz, void* dxdrop, float* dgamma, float* dbeta, long rows, int cols, float p,
+                         uint64_t seed, uint64_t off, hipStream_t st) {
+    int nb = ceil_div(rows, 4);
+    if (nb > 1024) nb = 1024;
+    dim3 grid(nb), block(256);
+    size_t shm = (size_t)4 * cols * sizeof(float);
+    const int it = ceil_div(cols / 4, 64);
+#define L(IT_) hipLaunchKernelGGL((ln_bwd_kernel<T, IT_>), grid, block, shm, st, (const T*)dy, (const T*)z, mean, rstd, gamma, (const T*)dres, (T*)dz, (T*)dxdrop, dgamma, dbeta, rows, cols, p, seed, off)
+    if (it <= 1) L(1); else if (it <= 2) L(2); else if (it <= 3) L(3); else if (it <= 4) L(4); else L(8);
+#undef L
+    return 0;
+}
+
+extern "C" int ecamp_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                   const void* dres_in, void* dz, void* dx_drop, float* dgamma, float* dbeta, int64_t rows,
+                                   int32_t cols, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
+                                   hipStream_t stream) {
+    ECAMP_CHECK_ARG(dy && z && mean && rstd && gamma && dz && dgamma && dbeta, "layernorm_bwd: null pointer");
+    ECAMP_CHECK_ARG(cols % 4 == 0 && cols <= 2048 && rows > 0, "layernorm_bwd: cols=%d must be a multiple of 4 and <= 2048", cols);
+    if (dtype == ECAMP_F32) ln_bwd_launch<float>(dy, z, mean, rstd, gamma, dres_in, dz, dx_drop, dgamma, dbeta, rows, cols, drop_p, seed, offset, stream);
+    else if (dtype == ECAMP_BF16) ln_bwd_launch<bf16_t>(dy, z, mean, rstd, gamma, dres_in, dz, dx_drop, dgamma, dbeta, rows, cols, drop_p, seed, offset, stream);
+    else return ecamp_set_error(-1, "layernorm_bwd: bad dtype %d", dtype);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,64 @@
+// Optimizer-side HBM-bound kernels over the FLAT parameter / gradient arenas:
+// global gradient sum-of-squares (misc.py:280-292) and fused decoupled-weight-decay Adam (torch AdamW
+// semantics, main_pretrain.py:254) that also refreshes the bf16 shadow copy the MFMA GEMMs read.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n4, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+extern "C" int ecamp_sumsq(const float* x, int64_t n, float* out, hipStream_t stream) {
+    ECAMP_CHECK_ARG(x && out && n % 4 == 0, "ecamp_sumsq: n=%ld must be a multiple of 4", (long)n);
+    long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, stream, x, n4, out);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ p16, long n4, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float rsqrt_bc2, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float pp[4], gg[4], mm[4], vv[4];
+        ld4<float>(p + i * 4, pp);
+        ld4<float>(g + i * 4, gg);
+        ld4<float>(m + i * 4, mm);
+        ld4<float>(v + i * 4, vv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float gr = gg[r] * gscale;
+            pp[r] *= 1.0f - lr * wd;
+            mm[r] = b1 * mm[r] + (1.0f - b1) * gr;
+            vv[r] = b2 * vv[r] + (1.0f - b2) * gr * gr;
+            float denom = sqrtf(vv[r]) * rsqrt_bc2 + eps;
+            pp[r] -= (lr / bc1) * (mm[r] / denom);
+        }
+        st4<float>(p + i * 4, pp);
+        st4<float>(m + i * 4, mm);
+        st4<float>(v + i * 4, vv);
+        if (p16) st4<bf16_t>(p16 + i * 4, pp);
+    }
+}
+extern "C" int ecamp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int64_t step, float grad_scale, hipStream_t stream) {
+    ECAMP_CHECK_ARG(p && g && m && v && n % 4 == 0 && step >= 1, "ecamp_adamw: bad args (n=%ld)", (long)n);
+    long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n4, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,315 @@
+"""Thin tensor-level wrappers over the C ABI (include/ecamp_hip.h).  torch is used ONLY for device memory
+(`torch.empty`) and the current HIP stream handle; every FLOP / byte moved below happens in libecamp_hip.so.
+No CPU fallback exists: CPU tensors raise."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, call
+
+_I64x3 = ctypes.c_int64 * 3
+
+
+def code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("ecamp_amd supports float32 and bfloat16 activations, got %s" % dtype)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.EcampHipError("ecamp_amd ops need tensors on an MI355X (HIP) device; got a CPU tensor. "
+                                     "There is no CPU fallback in the product path.")
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+# --------------------------------------------------------------------------------------------- gemm
+def gemm(A, B, C, M, N, K, a_kc, lda, b_kc, ldb, ldc, bias=None, residual=None, ldr=0, pre_out=None, ldp=0, gmul=None,
+         ldg=0, act=0, alpha=1.0, alpha_dev=None, out_f32=False, accumulate=False, split_k=1):
+    _chk(A, B, C)
+    call("ecamp_gemm", ptr(A), ptr(B), ptr(C), M, N, K, int(a_kc), lda, int(b_kc), ldb, ldc, ptr(bias), ptr(residual), ldr,
+         ptr(pre_out), ldp, ptr(gmul), ldg, int(act), float(alpha), ptr(alpha_dev), code(A.dtype), int(out_f32), int(accumulate), int(split_k),
+         stream())
+    return C
+
+
+def linear_fwd(x, w, bias=None, act=0, residual=None, save_pre=False, out_dtype=None):
+    """y = act(x @ w.T + bias) (+ residual);  x [M,K] (K-contiguous rows), w [N,K] in x.dtype."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1 and w.dtype == x.dtype
+    out_f32 = out_dtype == torch.float32 and x.dtype != torch.float32
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    pre = torch.empty((M, N), device=x.device, dtype=x.dtype) if save_pre else None
+    gemm(x, w, y, M, N, K, True, x.stride(0), True, w.stride(0), N, bias=bias, residual=residual,
+         ldr=residual.stride(0) if residual is not None else 0, pre_out=pre, ldp=N, act=act, out_f32=out_f32)
+    return (y, pre) if save_pre else y
+
+
+def linear_dgrad(dy, w, gmul=None, alpha=1.0, alpha_dev=None, residual=None):
+    """dx = alpha * (dy @ w) [* gelu'(gmul)] [+ residual];  dy [M,N], w [N,K]."""
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
+    gemm(dy, w, dx, M, K, N, True, dy.stride(0), False, w.stride(0), K, gmul=gmul, ldg=gmul.stride(0) if gmul is not None else 0,
+         residual=residual, ldr=residual.stride(0) if residual is not None else 0, alpha=alpha, alpha_dev=alpha_dev)
+    return dx
+
+
+def _split_k(n_out, k_in, m):
+    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+    s = max(1, 1024 // tiles)
+    return max(1, min(s, (m + 255) // 256))
+
+
+def linear_wgrad(dy, x, gw, alpha=1.0, alpha_dev=None):
+    """gw[N,K] (f32, accumulated) += alpha * dy[M,N]^T @ x[M,K]."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert gw.dtype == torch.float32 and gw.is_contiguous() and gw.numel() == N * K
+    gemm(dy, x, gw, N, K, M, False, dy.stride(0), False, x.stride(0), K, alpha=alpha, alpha_dev=alpha_dev, out_f32=True, accumulate=True,
+         split_k=_split_k(N, K, M))
+
+
+def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):
+    """out[N] (f32) += alpha * sum_m x[m, :]  (optionally only rows with lo <= m % period < hi)."""
+    _chk(x, out)
+    M, N = x.shape
+    call("ecamp_colsum", ptr(x), x.stride(0), M, N, float(alpha), ptr(alpha_dev), period, lo, hi, ptr(out), code(x.dtype), stream())
+
+
+# --------------------------------------------------------------------------------------------- layernorm
+def layernorm_fwd(x, gamma, beta, eps, residual=None, drop_p=0.0, seed=0, offset=0):
+    """-> (y, z, mean, rstd);  z is x itself unless residual/dropout are fused (then the materialised LN input)."""
+    _chk(x, gamma, beta)
+    rows, cols = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    fused = residual is not None or drop_p > 0.0
+    z = torch.empty_like(x) if fused else None
+    call("ecamp_layernorm_fwd", ptr(x), ptr(residual), ptr(z), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, cols,
+         float(eps), float(drop_p), seed, offset, code(x.dtype), stream())
+    return y, (z if fused else x), mean, rstd
+
+
+def layernorm_bwd(dy, z, mean, rstd, gamma, ggamma, gbeta, dres=None, drop_p=0.0, seed=0, offset=0, want_drop=False):
+    """-> dz (+dres) [, dz through the dropout mask];  ggamma/gbeta (f32) are accumulated."""
+    rows, cols = dy.shape
+    assert dy.is_contiguous() and z.is_contiguous()
+    dz = torch.empty_like(dy)
+    dxd = torch.empty_like(dy) if want_drop else None
+    call("ecamp_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dz), ptr(dxd), ptr(ggamma),
+         ptr(gbeta), rows, cols, float(drop_p), seed, offset, code(dy.dtype), stream())
+    return (dz, dxd) if want_drop else dz
+
+
+# --------------------------------------------------------------------------------------------- attention
+def _st(t3):
+    return _I64x3(*t3)
+
+
+def attn_fwd(q, k, v, B, H, Tq, Tk, hd, qs, ks, vs, scale, key_mask=None, drop_p=0.0, seed=0, offset=0):
+    """q/k/v: tensors whose storage is addressed with element strides (batch, token, head); returns (o [B,Tq,H*hd], lse)."""
+    _chk(q, k, v)
+    o = torch.empty((B, Tq, H * hd), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    call("ecamp_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_mask), B, H, Tq, Tk, hd, _st(qs), _st(ks), _st(vs),
+         _st((Tq * H * hd, H * hd, hd)), float(scale), float(drop_p), seed, offset, code(q.dtype), stream())
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, H, Tq, Tk, hd, qs, ks, vs, dqs, dks, dvs, scale, key_mask=None, drop_p=0.0,
+             seed=0, offset=0):
+    delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    os_ = (Tq * H * hd, H * hd, hd)
+    assert do.is_contiguous() and o.is_contiguous()
+    call("ecamp_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(key_mask),
+         B, H, Tq, Tk, hd, _st(qs), _st(ks), _st(vs), _st(os_), _st(os_), _st(dqs), _st(dks), _st(dvs), float(scale), float(drop_p),
+         seed, offset, code(q.dtype), stream())
+
+
+# --------------------------------------------------------------------------------------------- misc
+def add(a, b):
+    _chk(a, b)
+    y = torch.empty_like(a)
+    call("ecamp_add", ptr(a), ptr(b), ptr(y), a.numel(), code(a.dtype), stream())
+    return y
+
+
+def cast(src, dst):
+    _chk(src, dst)
+    call("ecamp_cast", ptr(src), ptr(dst), src.numel(), code(src.dtype), code(dst.dtype), stream())
+    return dst
+
+
+def zero_(t):
+    _chk(t)
+    call("ecamp_zero", ptr(t), t.numel() * t.element_size(), stream())
+    return t
+
+
+def zeros(shape, device, dtype=torch.float32):
+    return zero_(torch.empty(shape, device=device, dtype=dtype))
+
+
+def bcast_add(x, g):
+    B, S, H = x.shape
+    y = torch.empty_like(x)
+    call("ecamp_bcast_add", ptr(x), ptr(g), ptr(y), B, S, H, code(x.dtype), stream())
+    return y
+
+
+def seq_sum(x, s0, s1, scale):
+    B, S, H = x.shape
+    out = torch.empty((B, H), device=x.device, dtype=x.dtype)
+    call("ecamp_seq_sum", ptr(x), ptr(out), B, S, H, s0, s1, float(scale), code(x.dtype), stream())
+    return out
+
+
+def seq_bcast(g, y, s0, s1, scale, mode):
+    B, S, H = y.shape
+    call("ecamp_seq_bcast", ptr(g), ptr(y), B, S, H, s0, s1, float(scale), mode, code(y.dtype), stream())
+    return y
+
+
+def uniform(shape, device, seed, offset):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    call("ecamp_uniform", ptr(out), out.numel(), seed, offset, stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------------- image side
+def bicubic_resize(src, Hd, Wd):
+    _chk(src)
+    B, C, Hs, Ws = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    dst = torch.empty((B, C, Hd, Wd), device=src.device, dtype=torch.float32)
+    call("ecamp_bicubic_resize", ptr(src), ptr(dst), B * C, Hs, Ws, Hd, Wd, stream())
+    return dst
+
+
+def mask_indices(noise, len_keep):
+    _chk(noise)
+    B, L = noise.shape
+    ids_restore = torch.empty((B, L), device=noise.device, dtype=torch.int32)
+    ids_keep = torch.empty((B, len_keep), device=noise.device, dtype=torch.int32)
+    mask = torch.empty((B, L), device=noise.device, dtype=torch.float32)
+    call("ecamp_mask_indices", ptr(noise), B, L, len_keep, ptr(ids_restore), ptr(ids_keep), ptr(mask), stream())
+    return ids_restore, ids_keep, mask
+
+
+def im2col_gather(imgs, ids_keep, p, dtype):
+    B, C, R, _ = imgs.shape
+    Lk = ids_keep.shape[1]
+    out = torch.empty((B * (Lk + 1), C * p * p), device=imgs.device, dtype=dtype)
+    call("ecamp_im2col_gather", ptr(imgs), ptr(ids_keep), ptr(out), B, Lk, C, R, p, code(dtype), stream())
+    return out
+
+
+def assemble_tokens_(x, cls, pos, ids_keep, B, Lk, D):
+    call("ecamp_assemble_tokens", ptr(x), ptr(cls), ptr(pos), ptr(ids_keep), B, Lk, D, code(x.dtype), stream())
+    return x
+
+
+def unshuffle_fwd(y, ids_restore, mask_token, dpos, B, L, Lk, D):
+    xd = torch.empty((B, L + 1, D), device=y.device, dtype=y.dtype)
+    call("ecamp_unshuffle_fwd", ptr(y), ptr(ids_restore), ptr(mask_token), ptr(dpos), ptr(xd), B, L, Lk, D, code(y.dtype), stream())
+    return xd
+
+
+def unshuffle_bwd(dxd, ids_restore, ids_keep, gmask_token, B, L, Lk, D):
+    dy = torch.empty((B, Lk + 1, D), device=dxd.device, dtype=dxd.dtype)
+    call("ecamp_unshuffle_bwd", ptr(dxd), ptr(ids_restore), ptr(ids_keep), ptr(dy), ptr(gmask_token), B, L, Lk, D, code(dxd.dtype),
+         stream())
+    return dy
+
+
+def unpatchify_mim(pred, imgs, mask, loss_sum, B, R, p):
+    pred_img = torch.empty((B, 3, R, R), device=pred.device, dtype=torch.float32)
+    call("ecamp_unpatchify_mim", ptr(pred), ptr(imgs), ptr(mask), ptr(pred_img), ptr(loss_sum), B, R, p, code(pred.dtype), stream())
+    return pred_img
+
+
+def img_loss_bwd(pred_img, imgs, mask, dsr, gm_gs, B, R, p, dtype):
+    L = (R // p) ** 2
+    dpred = torch.empty((B * (L + 1), p * p * 3), device=pred_img.device, dtype=dtype)
+    call("ecamp_img_loss_bwd", ptr(pred_img), ptr(imgs), ptr(mask), ptr(dsr), ptr(gm_gs), ptr(dpred), B, R, p, code(dtype), stream())
+    return dpred
+
+
+def sr_fwd(pred_img, big, column, row, w1, b1, w2, b2, loss_sum, super_patch, window, dtype):
+    B, _, R, _ = pred_img.shape
+    shp = (B, 3, 2 * R, 2 * R)
+    u = torch.empty(shp, device=big.device, dtype=dtype)
+    c1 = torch.empty(shp, device=big.device, dtype=dtype)
+    ds = torch.empty(shp, device=big.device, dtype=dtype)
+    call("ecamp_sr_fwd", ptr(pred_img), ptr(big), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(u), ptr(c1), ptr(ds),
+         ptr(loss_sum), B, R, super_patch, window, code(dtype), stream())
+    return u, c1, ds
+
+
+def sr_bwd(u, c1, ds, w1, b1, w2, b2, gw_ws):
+    B, _, R2, _ = u.shape
+    R = R2 // 2
+    dc1 = torch.empty_like(u)
+    du = torch.empty_like(u)
+    dsr = torch.empty((B, 3, R, R), device=u.device, dtype=torch.float32)
+    call("ecamp_sr_bwd", ptr(u), ptr(c1), ptr(ds), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dc1), ptr(du), ptr(dsr), ptr(gw_ws), B, R,
+         code(u.dtype), stream())
+    return dsr
+
+
+def scaled_accum(ws, grad, scale_dev, idx):
+    call("ecamp_scaled_accum", ptr(ws), ptr(grad), ptr(scale_dev), idx, ws.numel(), stream())
+
+
+# --------------------------------------------------------------------------------------------- report side
+def bert_embed_fwd(ids, type_ids, word, pos, typ, gamma, beta, eps, dtype, drop_p=0.0, seed=0, offset=0):
+    _chk(ids, word)
+    B, S = ids.shape
+    H = word.shape[1]
+    z = torch.empty((B * S, H), device=ids.device, dtype=dtype)
+    e = torch.empty((B * S, H), device=ids.device, dtype=dtype)
+    mean = torch.empty(B * S, device=ids.device, dtype=torch.float32)
+    rstd = torch.empty(B * S, device=ids.device, dtype=torch.float32)
+    call("ecamp_bert_embed_fwd", ptr(ids), ptr(type_ids), ptr(word), ptr(pos), ptr(typ), ptr(gamma), ptr(beta), ptr(z), ptr(e),
+         ptr(mean), ptr(rstd), B, S, H, float(eps), float(drop_p), seed, offset, code(dtype), stream())
+    return e, z, mean, rstd
+
+
+def bert_embed_bwd(de, z, mean, rstd, gamma, ids, type_ids, gword, gpos, gtype, ggamma, gbeta, B, S, H, drop_p=0.0, seed=0,
+                   offset=0, pad_id=0, hot=(2, 3)):
+    call("ecamp_bert_embed_bwd", ptr(de), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(ids), ptr(type_ids), ptr(gword), ptr(gpos),
+         ptr(gtype), ptr(ggamma), ptr(gbeta), B, S, H, pad_id, hot[0], hot[1], float(drop_p), seed, offset, code(de.dtype), stream())
+
+
+def ce_fwd_bwd_(logits, labels, weights, loss_sum):
+    """In place: logits -> d(mean weighted CE)/d logits (unit upstream gradient); loss_sum += sum_i w_i CE_i."""
+    _chk(logits, labels, weights)
+    M, V = logits.shape
+    call("ecamp_ce_fwd_bwd", ptr(logits), ptr(labels), ptr(weights), ptr(loss_sum), M, V, logits.stride(0), 1.0 / M,
+         code(logits.dtype), stream())
+    return logits
+
+
+# --------------------------------------------------------------------------------------------- optimizer side
+def sumsq(x, out):
+    call("ecamp_sumsq", ptr(x), x.numel(), ptr(out), stream())
+
+
+def adamw(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    call("ecamp_adamw", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+         float(wd), int(step), float(grad_scale), stream())

@@ -1,0 +1,127 @@
+/* libecamp_hip.so -- C ABI of the MI355X-native ECAMP pre-training hot path.
+ *
+ * The reference (ToniChopp/ECAMP) is 100 % Python: it has NO native interface to mirror.
+ * Each entry point below therefore cites the reference *Python call site* whose ATen/cuDNN/cuBLAS kernels it
+ * replaces (paths relative to ECAMP/Pre-training/).  Conventions:
+ *   - raw device pointers + explicit sizes / element strides; dtype enum 0 = f32, 1 = bf16 (storage of activations);
+ *     parameters, LayerNorm statistics, losses and all parameter gradients are always f32
+ *   - every call only ENQUEUES work on `stream` (never synchronises, never allocates, never frees)
+ *   - returns 0 on success, <0 on argument errors, >0 = hipError_t; message via ecamp_last_error() (thread-local)
+ *   - parameter-gradient outputs ACCUMULATE (+=) into the caller's f32 buffers (gradient accumulation,
+ *     main_pretrain.py:147-153); activation-gradient outputs are overwritten
+ *   - dropout is a Philox4x32-10 stream keyed by (seed, offset, element index): backward regenerates the mask
+ */
+#ifndef ECAMP_HIP_H
+#define ECAMP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ecampStream_t; /* == hipStream_t */
+
+#define ECAMP_F32 0
+#define ECAMP_BF16 1
+
+int ecamp_abi_version(void);
+const char* ecamp_last_error(void);
+
+/* ---- dense contractions -------------------------------------------------------------------------------------
+ * C[M,N] (+)= epi( alpha * (alpha_dev ? *alpha_dev : 1) * sum_k opA[m,k] opB[k,n] ); a_kc/b_kc = operand is contiguous along the contraction.
+ * Replaces every nn.Linear / Conv2d-as-GEMM on the path: timm PatchEmbed.proj (model_ecamp.py:60,220), Block
+ * qkv/proj/fc1/fc2 (:66-68,80-82,233-234,254-255), decoder_embed/pred (:74,85,242,259), bert_mlp (:99,268), HF
+ * Bert* dense layers (bert_modeling.py:113-131, context_fusion.py:32-72), MLM decoder (bert_modeling.py:209), and
+ * their autograd dgrad/wgrad.  Epilogue: +bias[n]; save pre-activation; exact-erf GELU; *gelu'(gmul[m,n]);
+ * +residual[m,n].  out_f32/accumulate/split_k: f32 atomically-accumulated output for weight gradients. */
+int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda, int b_kc,
+               int64_t ldb, int64_t ldc, const float* bias, const void* residual, int64_t ldr, void* pre_out, int64_t ldp,
+               const void* gmul, int64_t ldg, int act, float alpha, const float* alpha_dev, int dtype, int out_f32, int accumulate,
+               int split_k,
+               ecampStream_t stream);
+
+/* ---- LayerNorm (nn.LayerNorm eps 1e-6: model_ecamp.py:69,84,235,256 + timm Block norms; HF LN eps 1e-12:
+ * BertSelfOutput/BertOutput/BertEmbeddings/transform).  y = LN(z), z = dropout(x) + residual (both optional). */
+int ecamp_layernorm_fwd(const void* x, const void* residual, void* z_out, const float* gamma, const float* beta, void* y,
+                        float* mean, float* rstd, int64_t rows, int32_t cols, float eps, float drop_p, uint64_t seed,
+                        uint64_t offset, int32_t dtype, ecampStream_t stream);
+int ecamp_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                        const void* dres_in, void* dz, void* dx_drop, float* dgamma, float* dbeta, int64_t rows, int32_t cols,
+                        float drop_p, uint64_t seed, uint64_t offset, int32_t dtype, ecampStream_t stream);
+
+/* ---- attention (timm Attention.forward: softmax(q k^T * hd^-1/2) v; HF BertSelfAttention 4.42.4 incl. the
+ * cross-attention mode of context_fusion.py:45-53).  strides = {batch, token, head} in elements, head_dim contiguous.
+ * key_mask: int32 [B,Tk], nonzero = attend (the additive finfo.min mask of bert_modeling.py:92), or NULL. */
+int ecamp_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* key_mask, int32_t B,
+                   int32_t H, int32_t Tq, int32_t Tk, int32_t hd, const int64_t* q_strides, const int64_t* k_strides,
+                   const int64_t* v_strides, const int64_t* o_strides, float scale, float drop_p, uint64_t seed, uint64_t offset,
+                   int32_t dtype, ecampStream_t stream);
+int ecamp_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   float* delta_ws, void* dq, void* dk, void* dv, const int32_t* key_mask, int32_t B, int32_t H, int32_t Tq,
+                   int32_t Tk, int32_t hd, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                   const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                   const int64_t* dv_strides, float scale, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
+                   ecampStream_t stream);
+
+/* ---- elementwise / reductions ---- */
+int ecamp_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, ecampStream_t stream);
+int ecamp_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, ecampStream_t stream);
+int ecamp_zero(void* p, int64_t bytes, ecampStream_t stream);
+/* out[n] += alpha * sum over rows m (optionally only rows with lo <= m % period < hi) of X[m*ld+n]: bias grads,
+ * cls-token grad (model_ecamp.py:228-230). */
+int ecamp_colsum(const void* X, int64_t ld, int64_t M, int64_t N, float alpha, const float* alpha_dev, int32_t period, int32_t lo, int32_t hi,
+                 float* out, int32_t dtype, ecampStream_t stream);
+int ecamp_bcast_add(const void* x, const void* g, void* y, int64_t B, int32_t S, int32_t H, int32_t dtype,
+                    ecampStream_t stream); /* context_fusion.py:55 */
+int ecamp_seq_sum(const void* x, void* out, int64_t B, int32_t S, int32_t H, int32_t s0, int32_t s1, float scale, int32_t dtype,
+                  ecampStream_t stream); /* model_ecamp.py:269 gap token; grad of the broadcast */
+int ecamp_seq_bcast(const void* g, void* y, int64_t B, int32_t S, int32_t H, int32_t s0, int32_t s1, float scale, int32_t mode,
+                    int32_t dtype, ecampStream_t stream);
+int ecamp_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, ecampStream_t stream); /* model_ecamp.py:177 */
+
+/* ---- image side ---- */
+int ecamp_bicubic_resize(const float* src, float* dst, int64_t planes, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd,
+                         ecampStream_t stream); /* model_ecamp.py:318 */
+int ecamp_mask_indices(const float* noise, int64_t B, int32_t L, int32_t len_keep, int32_t* ids_restore, int32_t* ids_keep,
+                       float* mask, ecampStream_t stream); /* model_ecamp.py:168-193 */
+int ecamp_im2col_gather(const float* imgs, const int32_t* ids_keep, void* out, int64_t B, int32_t Lk, int32_t C, int32_t R,
+                        int32_t p, int32_t dtype, ecampStream_t stream); /* model_ecamp.py:220 + :185 */
+int ecamp_assemble_tokens(void* x, const float* cls, const float* pos, const int32_t* ids_keep, int64_t B, int32_t Lk, int32_t D,
+                          int32_t dtype, ecampStream_t stream); /* model_ecamp.py:222,228-230 */
+int ecamp_unshuffle_fwd(const void* y, const int32_t* ids_restore, const float* mask_token, const float* dpos, void* xd, int64_t B,
+                        int32_t L, int32_t Lk, int32_t D, int32_t dtype, ecampStream_t stream); /* model_ecamp.py:245-251 */
+int ecamp_unshuffle_bwd(const void* dxd, const int32_t* ids_restore, const int32_t* ids_keep, void* dy, float* dmask_token,
+                        int64_t B, int32_t L, int32_t Lk, int32_t D, int32_t dtype, ecampStream_t stream);
+int ecamp_unpatchify_mim(const void* pred, const float* imgs, const float* mask, float* pred_img, float* loss_sum, int64_t B,
+                         int32_t R, int32_t p, int32_t dtype, ecampStream_t stream); /* model_ecamp.py:153-165,288-298 */
+int ecamp_img_loss_bwd(const float* pred_img, const float* imgs, const float* mask, const float* dsr, const float* gm_gs,
+                       void* dpred, int64_t B, int32_t R, int32_t p, int32_t dtype, ecampStream_t stream);
+int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
+                 const float* b1, const float* w2, const float* b2, void* u, void* c1, void* ds, float* loss_sum, int64_t B,
+                 int32_t R, int32_t super_patch, int32_t window, int32_t dtype,
+                 ecampStream_t stream); /* model_ecamp.py:28-46,196-215,291-299 */
+int ecamp_sr_bwd(const void* u, const void* c1, const void* ds, const float* w1, const float* b1, const float* w2, const float* b2,
+                 void* dc1, void* du, float* dsr, float* gw_ws, int64_t B, int32_t R, int32_t dtype, ecampStream_t stream);
+int ecamp_scaled_accum(const float* ws, float* grad, const float* scale_dev, int32_t idx, int32_t n, ecampStream_t stream);
+
+/* ---- report side ---- */
+int ecamp_bert_embed_fwd(const int64_t* ids, const int64_t* type_ids, const float* word, const float* pos, const float* type,
+                         const float* gamma, const float* beta, void* z, void* e, float* mean, float* rstd, int64_t B, int32_t S,
+                         int32_t cols, float eps, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
+                         ecampStream_t stream); /* HF BertEmbeddings, bert_modeling.py:113 */
+int ecamp_bert_embed_bwd(const void* de, const void* z, const float* mean, const float* rstd, const float* gamma, const int64_t* ids,
+                         const int64_t* type_ids, float* gword, float* gpos, float* gtype, float* dgamma, float* dbeta, int64_t B,
+                         int32_t S, int32_t cols, int32_t pad_id, int32_t hot0, int32_t hot1, float drop_p, uint64_t seed,
+                         uint64_t offset, int32_t dtype, ecampStream_t stream);
+int ecamp_ce_fwd_bwd(void* logits, const int64_t* labels, const float* weights, float* loss_sum, int64_t M, int32_t V, int64_t ld,
+                     float inv_count, int32_t dtype, ecampStream_t stream); /* bert_modeling.py:213-217 */
+
+/* ---- optimizer side ---- */
+int ecamp_sumsq(const float* x, int64_t n, float* out, ecampStream_t stream); /* util/misc.py:280-292 */
+int ecamp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int64_t step, float grad_scale,
+                ecampStream_t stream); /* torch.optim.AdamW, main_pretrain.py:254 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

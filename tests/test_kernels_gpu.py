@@ -1,0 +1,475 @@
+"""-m gpu: every HIP kernel, called through the C ABI (ecamp_amd.hip_ops -> libecamp_hip.so), against a plain
+fp32 PyTorch CPU restatement of the same op on identical seeded inputs.
+
+Tolerances (relative to max|ref|): f32 mode 2e-5 (exact-f32 MFMA, different summation order only);
+bf16 mode 2e-2 on activations (8-bit mantissa storage; inputs are pre-rounded to bf16 so only the
+kernel's own rounding is measured) and 1e-2 on f32-accumulated parameter gradients.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def ops():
+    from ecamp_amd import hip_ops
+    return hip_ops
+
+
+def rnd(t, dtype):
+    return t.to(dtype).to(torch.float32)
+
+
+def check(name, got, ref, tol):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), name + ": non-finite output"
+    err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-20)
+    print("  %-40s rel-err %.3e (tol %.1e)" % (name, err, tol))
+    assert err <= tol, "%s: rel err %.3e > %.1e" % (name, err, tol)
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 2304, 768), (512, 128, 3072), (256, 30000, 768), (37 * 4, 512, 64)])
+def test_gemm_fwd_epilogues(dev, dtype, M, N, K):
+    o = ops()
+    x, w, b, r = rnd(gen(M, K, seed=1), dtype), rnd(gen(N, K, seed=2, scale=K ** -0.5), dtype), gen(N, seed=3), rnd(gen(M, N, seed=4), dtype)
+    xd, wd, bd, rd = x.to(dev, dtype), w.to(dev, dtype), b.to(dev), r.to(dev, dtype)
+    tol = TOL[dtype]
+    y = o.linear_fwd(xd, wd, bd)
+    check("linear", y, x @ w.T + b, tol)
+    y = o.linear_fwd(xd, wd, None, residual=rd)
+    check("linear+residual", y, x @ w.T + r, tol)
+    y, pre = o.linear_fwd(xd, wd, bd, act=1, save_pre=True)
+    ref_pre = x @ w.T + b
+    check("linear pre", pre, ref_pre, tol)
+    check("linear gelu", y, F.gelu(rnd(ref_pre, dtype) if dtype != torch.float32 else ref_pre), tol)
+    if dtype == torch.bfloat16:
+        y32 = o.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
+        assert y32.dtype == torch.float32
+        check("linear f32-out", y32, x @ w.T + b, 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 3072, 768), (256, 30000, 768)])
+def test_gemm_dgrad_wgrad(dev, dtype, M, N, K):
+    o = ops()
+    x = rnd(gen(M, K, seed=1), dtype)
+    w = rnd(gen(N, K, seed=2, scale=N ** -0.5), dtype)
+    dy = rnd(gen(M, N, seed=5), dtype)
+    pre = rnd(gen(M, K, seed=6), dtype)
+    xd, wd, dyd, pred = x.to(dev, dtype), w.to(dev, dtype), dy.to(dev, dtype), pre.to(dev, dtype)
+    tol = TOL[dtype]
+    check("dgrad", o.linear_dgrad(dyd, wd), dy @ w, tol)
+    pr = pre.clone().requires_grad_(True)
+    F.gelu(pr).backward(dy @ w)
+    check("dgrad*gelu'", o.linear_dgrad(dyd, wd, gmul=pred), pr.grad, tol)
+    check("dgrad alpha", o.linear_dgrad(dyd, wd, alpha=0.25), 0.25 * (dy @ w), tol)
+    g0 = gen(N, K, seed=7)
+    gw = g0.to(dev).contiguous()
+    o.linear_wgrad(dyd, xd, gw, alpha=0.5)
+    check("wgrad (accumulate, split-K)", gw, g0 + 0.5 * (dy.T @ x), 2e-5 if dtype == torch.float32 else 1e-2)
+    gb = torch.zeros(N, device=dev)
+    o.colsum(dyd, gb, alpha=2.0)
+    check("bias grad", gb, 2.0 * dy.sum(0), 2e-5 if dtype == torch.float32 else 1e-2)
+
+
+def test_gemm_rejects_bad_alignment(dev):
+    o = ops()
+    from ecamp_amd._lib import EcampHipError
+    x = torch.zeros(8, 30, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(16, 30, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(EcampHipError):
+        o.linear_fwd(x, w)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols,eps", [(100, 768, 1e-6), (394, 512, 1e-6), (7, 192, 1e-6), (256, 768, 1e-12), (33, 1024, 1e-6)])
+def test_layernorm(dev, dtype, rows, cols, eps):
+    o = ops()
+    x = rnd(gen(rows, cols, seed=1) * 2 + 0.3, dtype)
+    res = rnd(gen(rows, cols, seed=2), dtype)
+    g, b = 1 + 0.1 * gen(cols, seed=3), 0.1 * gen(cols, seed=4)
+    dy = rnd(gen(rows, cols, seed=5), dtype)
+    dres = rnd(gen(rows, cols, seed=6), dtype)
+    tol = TOL[dtype]
+    gtol = 2e-5 if dtype == torch.float32 else 1e-2
+    # plain
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (cols,), gr, br, eps)
+    yr.backward(dy)
+    y, z, mean, rstd = o.layernorm_fwd(x.to(dev, dtype), g.to(dev), b.to(dev), eps)
+    check("ln y", y, yr, tol)
+    check("ln mean", mean, x.mean(1), 1e-5)
+    gg, gb = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    dz = o.layernorm_bwd(dy.to(dev, dtype), z, mean, rstd, g.to(dev), gg, gb, dres=dres.to(dev, dtype))
+    check("ln dx(+dres)", dz, xr.grad + dres, tol)
+    check("ln dgamma", gg, gr.grad, gtol)
+    check("ln dbeta", gb, br.grad, gtol)
+    # fused residual
+    y2, z2, m2, r2 = o.layernorm_fwd(x.to(dev, dtype), g.to(dev), b.to(dev), eps, residual=res.to(dev, dtype))
+    zz = rnd(x + res, dtype)
+    check("ln(x+res) z", z2, zz, tol)
+    check("ln(x+res) y", y2, F.layer_norm(zz, (cols,), g, b, eps), tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layernorm_dropout_consistency(dev, dtype):
+    """fwd and bwd must regenerate the SAME Philox mask; keep-rate ~ 1-p; scale 1/(1-p)."""
+    o = ops()
+    rows, cols, p = 512, 768, 0.1
+    x = torch.ones(rows, cols, device=dev, dtype=dtype)
+    res = torch.zeros(rows, cols, device=dev, dtype=dtype)
+    g, b = torch.ones(cols, device=dev), torch.zeros(cols, device=dev)
+    y, z, mean, rstd = o.layernorm_fwd(x, g, b, 1e-6, residual=res, drop_p=p, seed=1234, offset=77)
+    zf = z.float().cpu()
+    keep = (zf != 0)
+    rate = keep.float().mean().item()
+    assert abs(rate - 0.9) < 0.01, rate
+    assert torch.allclose(zf[keep], torch.full_like(zf[keep], 1 / 0.9), rtol=1e-2)
+    dy = torch.randn(rows, cols, device=dev).to(dtype)
+    gg, gb = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    dz, dxd = o.layernorm_bwd(dy, z, mean, rstd, g, gg, gb, drop_p=p, seed=1234, offset=77, want_drop=True)
+    dzf, dxf = dz.float().cpu(), dxd.float().cpu()
+    assert ((dxf != 0) <= keep).all(), "bwd mask is not a subset of the fwd mask"
+    check("dropout bwd scale", dxf, dzf * keep.float() / 0.9, 2e-2 if dtype == torch.bfloat16 else 1e-6)
+    # a different offset must give a different mask
+    _, z3, _, _ = o.layernorm_fwd(x, g, b, 1e-6, residual=res, drop_p=p, seed=1234, offset=78)
+    assert (z3.float().cpu() != zf).float().mean().item() > 0.05
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def ref_attn(q, k, v, scale, key_mask=None):
+    # q [B,H,Tq,hd], k/v [B,H,Tk,hd]
+    s = (q @ k.transpose(-1, -2)) * scale
+    if key_mask is not None:
+        s = s + (1.0 - key_mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    return s.softmax(-1) @ v
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,T,hd", [(2, 3, 50, 64), (2, 16, 197, 32), (3, 12, 50, 64), (1, 2, 130, 128)])
+def test_attention_packed_qkv(dev, dtype, B, H, T, hd):
+    """timm layout: one [B,T,3,H,hd] buffer straight out of the qkv GEMM."""
+    o = ops()
+    D = H * hd
+    qkv = rnd(gen(B, T, 3, H, hd, seed=1), dtype)
+    do = rnd(gen(B, T, D, seed=2), dtype)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = (qr[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    out = ref_attn(q, k, v, hd ** -0.5).transpose(1, 2).reshape(B, T, D)
+    out.backward(do)
+    qd = qkv.to(dev, dtype)
+    st = (T * 3 * D, 3 * D, hd)
+    qp, kp, vp = qd.view(-1)[0:], qd.view(-1)[D:], qd.view(-1)[2 * D:]
+    og, lse = o.attn_fwd(qp, kp, vp, B, H, T, T, hd, st, st, st, hd ** -0.5)
+    tol = TOL[dtype]
+    check("attn out", og, out, tol)
+    dqkv = torch.empty_like(qd)
+    dv_ = dqkv.view(-1)
+    o.attn_bwd(qp, kp, vp, og, do.to(dev, dtype), lse, dv_[0:], dv_[D:], dv_[2 * D:], B, H, T, T, hd, st, st, st, st, st, st, hd ** -0.5)
+    check("attn dqkv", dqkv, qr.grad, tol * 2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("S,Tk,cross", [(128, 128, False), (256, 256, False), (128, 49, True), (40, 49, True)])
+def test_attention_bert_masked_and_cross(dev, dtype, S, Tk, cross):
+    """HF layout: separate [B,S,H*hd] projections; key-padding mask; cross-attention reads tokens 1..49 of a 50-token buffer."""
+    o = ops()
+    B, H, hd = 2, 6, 128
+    D = H * hd
+    q = rnd(gen(B, S, D, seed=1), dtype)
+    kvlen = Tk + 1 if cross else Tk
+    k = rnd(gen(B, kvlen, D, seed=2), dtype)
+    v = rnd(gen(B, kvlen, D, seed=3), dtype)
+    do = rnd(gen(B, S, D, seed=4), dtype)
+    lens = torch.tensor([Tk // 2 + 3, Tk])
+    km = None if cross else (torch.arange(Tk)[None, :] < lens[:, None]).int()
+    qr, kr, vr = q.clone().requires_grad_(True), k.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    off = 1 if cross else 0
+    sp = lambda t, n: t.view(B, n, H, hd).permute(0, 2, 1, 3)
+    out = ref_attn(sp(qr, S), sp(kr[:, off:], Tk), sp(vr[:, off:], Tk), 1 / math.sqrt(hd), km).permute(0, 2, 1, 3).reshape(B, S, D)
+    out.backward(do)
+    qd, kd, vd = q.to(dev, dtype), k.to(dev, dtype), v.to(dev, dtype)
+    kmd = km.to(dev) if km is not None else None
+    qs, ks = (S * D, D, hd), (kvlen * D, D, hd)
+    kp, vp = kd.view(-1)[off * D:], vd.view(-1)[off * D:]
+    og, lse = o.attn_fwd(qd, kp, vp, B, H, S, Tk, hd, qs, ks, ks, 1 / math.sqrt(hd), key_mask=kmd)
+    tol = TOL[dtype]
+    check("bert attn out", og, out, tol)
+    dq = torch.empty_like(qd)
+    dk = torch.zeros_like(kd)
+    dv = torch.zeros_like(vd)
+    o.attn_bwd(qd, kp, vp, og, do.to(dev, dtype), lse, dq, dk.view(-1)[off * D:], dv.view(-1)[off * D:], B, H, S, Tk, hd, qs, ks, ks,
+               qs, ks, ks, 1 / math.sqrt(hd), key_mask=kmd)
+    check("bert attn dq", dq, qr.grad, tol * 2)
+    check("bert attn dk", dk, kr.grad, tol * 2)
+    check("bert attn dv", dv, vr.grad, tol * 2)
+
+
+def test_attention_dropout_statistics(dev):
+    """P-dropout: E[out] is preserved and fwd/bwd use the same mask (finite-difference-free check via linearity in v)."""
+    o = ops()
+    B, H, T, hd = 4, 6, 128, 128
+    D = H * hd
+    q = gen(B, T, D, seed=1).to(dev)
+    k = gen(B, T, D, seed=2).to(dev)
+    v = torch.ones(B, T, D, device=dev)
+    st = (T * D, D, hd)
+    o0, _ = o.attn_fwd(q, k, v, B, H, T, T, hd, st, st, st, hd ** -0.5)
+    o1, lse = o.attn_fwd(q, k, v, B, H, T, T, hd, st, st, st, hd ** -0.5, drop_p=0.1, seed=5, offset=9)
+    assert torch.allclose(o0, torch.ones_like(o0), atol=1e-4)  # softmax rows sum to 1
+    m = o1.mean().item()
+    assert abs(m - 1.0) < 0.02, m
+    assert o1.std().item() > 1e-3
+    # out is linear in v for a fixed mask: dv from bwd with do=1 equals column sums of the dropped P, whose total is B*H*T*mean(o1)*hd
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    o.attn_bwd(q, k, v, o1, torch.ones_like(o1), lse, dq, dk, dv, B, H, T, T, hd, st, st, st, st, st, st, hd ** -0.5, drop_p=0.1, seed=5, offset=9)
+    assert abs(dv.sum().item() / o1.sum().item() - 1.0) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ image side
+def test_bicubic(dev):
+    o = ops()
+    x = gen(3, 3, 64, 64, seed=1)
+    check("bicubic 2x down", o.bicubic_resize(x.to(dev), 32, 32), F.interpolate(x, size=[32, 32], mode="bicubic", align_corners=False), 2e-6)
+    x = gen(2, 3, 448, 448, seed=2)
+    check("bicubic 448->224", o.bicubic_resize(x.to(dev), 224, 224), F.interpolate(x, size=[224, 224], mode="bicubic", align_corners=False), 2e-6)
+    x = gen(1, 2, 40, 52, seed=3)
+    check("bicubic generic", o.bicubic_resize(x.to(dev), 17, 33), F.interpolate(x, size=[17, 33], mode="bicubic", align_corners=False), 1e-5)
+
+
+@pytest.mark.parametrize("L,ratio", [(196, 0.75), (784, 0.75), (196, 0.0), (16, 0.5)])
+def test_mask_indices(dev, L, ratio):
+    o = ops()
+    B = 5
+    noise = torch.rand(B, L, generator=torch.Generator().manual_seed(3))
+    noise[0, 3] = noise[0, 7]  # a tie: stable order must hold
+    len_keep = int(L * (1 - ratio))
+    ids_shuffle = torch.argsort(noise, dim=1, stable=True)
+    ids_restore = torch.argsort(ids_shuffle, dim=1, stable=True)
+    mask = torch.ones(B, L)
+    mask[:, :len_keep] = 0
+    mask = torch.gather(mask, 1, ids_restore)
+    r, kk, m = o.mask_indices(noise.to(dev), len_keep)
+    assert (r.cpu().long() == ids_restore).all()
+    assert (kk.cpu().long() == ids_shuffle[:, :len_keep]).all()
+    assert (m.cpu() == mask).all()
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_patch_embed_path(dev, dtype):
+    """im2col(visible) + GEMM + assemble == conv2d patch-embed + pos + gather + cls concat (model_ecamp.py:218-230)."""
+    o = ops()
+    B, R, p, D = 3, 64, 16, 192
+    G = R // p
+    L, Lk = G * G, 4
+    imgs = rnd(gen(B, 3, R, R, seed=1), dtype)
+    w = rnd(gen(D, 3, p, p, seed=2, scale=0.05), dtype)
+    b, cls, pos = gen(D, seed=3), gen(1, 1, D, seed=4), gen(1, L + 1, D, seed=5)
+    ids_keep = torch.stack([torch.randperm(L, generator=torch.Generator().manual_seed(i))[:Lk] for i in range(B)])
+    x = F.conv2d(imgs, w, b, stride=p).flatten(2).transpose(1, 2) + pos[:, 1:]
+    x = torch.gather(x, 1, ids_keep[:, :, None].expand(-1, -1, D))
+    ref = torch.cat([(cls + pos[:, :1]).expand(B, -1, -1), x], 1)
+    ik = ids_keep.int().to(dev)
+    cols = o.im2col_gather(imgs.to(dev), ik, p, dtype)
+    assert (cols.view(B, Lk + 1, -1)[:, 0] == 0).all()
+    y = o.linear_fwd(cols, w.view(D, -1).to(dev, dtype), b.to(dev))
+    o.assemble_tokens_(y, cls.to(dev), pos.to(dev), ik, B, Lk, D)
+    check("patch-embed path", y.view(B, Lk + 1, D), ref, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_unshuffle(dev, dtype):
+    o = ops()
+    B, L, Lk, D = 3, 16, 4, 64
+    y = rnd(gen(B, Lk + 1, D, seed=1), dtype)
+    mtok, dpos = gen(1, 1, D, seed=2), gen(1, L + 1, D, seed=3)
+    noise = torch.rand(B, L, generator=torch.Generator().manual_seed(4))
+    ids_shuffle = torch.argsort(noise, 1)
+    ids_restore = torch.argsort(ids_shuffle, 1)
+    ids_keep = ids_shuffle[:, :Lk]
+    yr, mr = y.clone().requires_grad_(True), mtok.clone().requires_grad_(True)
+    x_ = torch.cat([yr[:, 1:], mr.expand(B, L - Lk, D)], 1)
+    x_ = torch.gather(x_, 1, ids_restore[:, :, None].expand(-1, -1, D))
+    ref = torch.cat([yr[:, :1], x_], 1) + dpos
+    dxd = rnd(gen(B, L + 1, D, seed=5), dtype)
+    ref.backward(dxd)
+    xd = o.unshuffle_fwd(y.to(dev, dtype), ids_restore.int().to(dev), mtok.to(dev), dpos.to(dev), B, L, Lk, D)
+    check("unshuffle fwd", xd, ref, TOL[dtype])
+    gm = torch.zeros(D, device=dev)
+    dy = o.unshuffle_bwd(dxd.to(dev, dtype), ids_restore.int().to(dev), ids_keep.int().to(dev), gm, B, L, Lk, D)
+    check("unshuffle dy", dy, yr.grad, 1e-6)
+    check("unshuffle dmask_token", gm, mr.grad.view(-1), 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("R,win", [(64, 3), (32, 2)])
+def test_image_losses_and_sr_head(dev, dtype, R, win):
+    """unpatchify + masked MSE + SR head + windowed MSE, forward and backward, vs the reference formulas
+    (model_ecamp.py:28-46,153-165,196-215,276-300) differentiated by torch autograd."""
+    o = ops()
+    B, p = 3, 16
+    G = R // p
+    L = G * G
+    pred = rnd(gen(B, L + 1, p * p * 3, seed=1), dtype)
+    imgs, big = gen(B, 3, R, R, seed=2), gen(B, 3, 2 * R, 2 * R, seed=3)
+    mask = (torch.rand(B, L, generator=torch.Generator().manual_seed(4)) < 0.75).float()
+    column, row = torch.tensor([0, 1, 1][:B]), torch.tensor([1, 0, 1][:B])
+    w1, b1, w2, b2 = gen(3, 3, 3, 3, seed=5, scale=0.3), gen(3, seed=6, scale=0.1), gen(3, 3, 3, 3, seed=7, scale=0.3), gen(3, seed=8, scale=0.1)
+    pr = pred.clone().requires_grad_(True)
+    ws = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    x = pr[:, 1:].reshape(B, G, G, p, p, 3)
+    pimg = torch.einsum("nhwpqc->nchpwq", x).reshape(B, 3, R, R)
+    u = F.interpolate(pimg, scale_factor=2, mode="bilinear", align_corners=False)
+    sr = F.relu(F.conv2d(F.relu(F.conv2d(u, ws[0], ws[1], padding=1)), ws[2], ws[3], padding=1) + u)
+    pm = torch.kron(mask.view(B, G, G), torch.ones(p, p))[:, None].expand(-1, 3, -1, -1)
+    sm = torch.zeros(B, G, G)
+    for i in range(B):
+        sm[i, column[i]:column[i] + win, row[i]:row[i] + win] = 1
+    spm = torch.kron(sm, torch.ones(2 * p, 2 * p))[:, None].expand(-1, 3, -1, -1)
+    mim = F.mse_loss(pimg * pm, imgs * pm)
+    res = F.mse_loss(sr * spm, big * spm)
+    g_mim, g_res = 0.7, 1.3
+    (g_mim * mim + g_res * res).backward()
+
+    sums = torch.zeros(2, device=dev)
+    pd = pred.to(dev, dtype)
+    pimg_d = o.unpatchify_mim(pd, imgs.to(dev), mask.to(dev), sums[0:], B, R, p)
+    check("unpatchify", pimg_d, pimg, 1e-6)
+    wd = [t.to(dev).contiguous() for t in (w1, b1, w2, b2)]
+    ud, c1d, dsd = o.sr_fwd(pimg_d, big.to(dev), column.to(dev), row.to(dev), *wd, sums[1:], 2 * p, win, dtype)
+    n1, n2 = B * 3 * R * R, B * 3 * 4 * R * R
+    tol = TOL[dtype]
+    check("mim loss", sums[0:1] / n1, mim.view(1), 1e-5)
+    check("res loss", sums[1:2] / n2, res.view(1), 1e-5 if dtype == torch.float32 else 1e-2)
+    gw = torch.zeros(168, device=dev)
+    dsr = o.sr_bwd(ud, c1d, dsd, *wd, gw)
+    gmgs = torch.tensor([g_mim * 2 / n1, g_res * 2 / n2], device=dev)
+    dpred = o.img_loss_bwd(pimg_d, imgs.to(dev), mask.to(dev), dsr, gmgs, B, R, p, dtype)
+    # bf16 mode keeps the five SR intermediates (u, c1, ds, dc1, du) in bf16: errors compound through two 3x3 convs
+    check("d pred (mim + SR branch)", dpred.view(B, L + 1, -1), pr.grad, 5e-2 if dtype == torch.bfloat16 else 1e-4)
+    s = g_res * 2 / n2
+    gtol = 1e-4 if dtype == torch.float32 else 3e-2
+    check("d conv1.weight", gw[0:81] * s, ws[0].grad.view(-1), gtol)
+    check("d conv1.bias", gw[81:84] * s, ws[1].grad, gtol)
+    check("d conv2.weight", gw[84:165] * s, ws[2].grad.view(-1), gtol)
+    check("d conv2.bias", gw[165:168] * s, ws[3].grad, gtol)
+
+
+# ------------------------------------------------------------------------------------------------ report side
+@pytest.mark.parametrize("dtype", DT)
+def test_bert_embeddings(dev, dtype):
+    o = ops()
+    B, S, H, V = 6, 40, 768, 500
+    g0 = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, V, (B, S), generator=g0)
+    ids[:, 0] = 2
+    ids[torch.rand(B, S, generator=g0) < 0.3] = 3
+    ids[:, -5:] = 0  # PAD tail
+    ty = (torch.rand(B, S, generator=g0) < 0.2).long()
+    word, pos, typ = gen(V, H, seed=2, scale=0.5), gen(64, H, seed=3, scale=0.5), gen(2, H, seed=4, scale=0.5)
+    g, b = 1 + 0.1 * gen(H, seed=5), 0.1 * gen(H, seed=6)
+    de = rnd(gen(B * S, H, seed=7), dtype)
+    wr, pr, tr, gr, br = (t.clone().requires_grad_(True) for t in (word, pos, typ, g, b))
+    e = F.embedding(ids, wr, padding_idx=0) + F.embedding(ty, tr) + pr[:S][None]
+    ref = F.layer_norm(e, (H,), gr, br, 1e-12)
+    ref.backward(de.view(B, S, H))
+    ed, z, mean, rstd = o.bert_embed_fwd(ids.to(dev), ty.to(dev), word.to(dev), pos.to(dev), typ.to(dev), g.to(dev), b.to(dev), 1e-12, dtype)
+    check("bert embed", ed.view(B, S, H), ref, TOL[dtype])
+    gw, gp, gt = torch.zeros(V, H, device=dev), torch.zeros(64, H, device=dev), torch.zeros(2, H, device=dev)
+    gg, gb = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    o.bert_embed_bwd(de.to(dev, dtype), z, mean, rstd, g.to(dev), ids.to(dev), ty.to(dev), gw, gp, gt, gg, gb, B, S, H)
+    gtol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert (gw[0] == 0).all(), "PAD row must get no gradient (padding_idx=0)"
+    check("d word_embeddings", gw, wr.grad, gtol)
+    check("d position_embeddings", gp, pr.grad, gtol)
+    check("d token_type_embeddings", gt, tr.grad, gtol)
+    check("d LN gamma", gg, gr.grad, gtol)
+    check("d LN beta", gb, br.grad, gtol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,V", [(64, 30000), (33, 1000)])
+def test_weighted_cross_entropy(dev, dtype, M, V):
+    o = ops()
+    logits = rnd(gen(M, V, seed=1) * 3, dtype)
+    labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(2))
+    w = torch.rand(M, generator=torch.Generator().manual_seed(3)) * 2
+    lr = logits.clone().requires_grad_(True)
+    loss = (F.cross_entropy(lr, labels, reduction="none") * w).mean()
+    loss.backward()
+    ld = logits.to(dev, dtype)
+    s = torch.zeros(1, device=dev)
+    o.ce_fwd_bwd_(ld, labels.to(dev), w.to(dev), s)
+    check("mlm loss", s / M, loss.view(1), 1e-5)
+    check("d logits", ld, lr.grad, TOL[dtype] if dtype == torch.bfloat16 else 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ small ops / optimizer
+@pytest.mark.parametrize("dtype", DT)
+def test_small_ops(dev, dtype):
+    o = ops()
+    B, S, H = 3, 50, 768
+    x, g = rnd(gen(B, S, H, seed=1), dtype), rnd(gen(B, H, seed=2), dtype)
+    xd, gd = x.to(dev, dtype), g.to(dev, dtype)
+    tol = TOL[dtype]
+    check("add", o.add(xd, xd), 2 * x, tol)
+    check("bcast_add", o.bcast_add(xd, gd), x + g[:, None], tol)
+    check("seq_sum (gap mean)", o.seq_sum(xd, 1, S, 1.0 / (S - 1)), x[:, 1:].mean(1), tol)
+    y = torch.full((B, S, H), 7.0, device=dev, dtype=dtype)
+    o.seq_bcast(gd, y, 1, S, 0.5, 0)
+    ref = torch.zeros(B, S, H)
+    ref[:, 1:] = 0.5 * g[:, None]
+    check("seq_bcast set", y, ref, tol)
+    o.seq_bcast(gd, y, 0, S, 1.0, 1)
+    check("seq_bcast add", y, ref + g[:, None], tol)
+    out = torch.zeros(H, device=dev)
+    o.colsum(xd.view(B * S, H), out, 1.0, S, 0, 1)
+    check("colsum cls rows", out, x[:, 0].sum(0), 1e-2 if dtype == torch.bfloat16 else 1e-5)
+    out = torch.zeros(H, device=dev)
+    o.colsum(xd.view(B * S, H), out, 1.0, S, 1, S)
+    check("colsum non-cls rows", out, x[:, 1:].sum((0, 1)), 1e-2 if dtype == torch.bfloat16 else 1e-5)
+    u = o.uniform((4, 196), dev, 42, 0)
+    assert 0.0 <= u.min().item() and u.max().item() < 1.0 and abs(u.mean().item() - 0.5) < 0.05
+    assert (u != o.uniform((4, 196), dev, 42, 1)).any() and (u == o.uniform((4, 196), dev, 42, 0)).all()
+    f = gen(1000, seed=3).to(dev)
+    h = torch.empty(1000, device=dev, dtype=torch.bfloat16)
+    o.cast(f, h)
+    assert (h.cpu() == f.cpu().to(torch.bfloat16)).all(), "f32->bf16 must be round-to-nearest-even"
+
+
+def test_adamw_and_gradnorm(dev):
+    o = ops()
+    n = 4096 * 3
+    p0, g0 = gen(n, seed=1), gen(n, seed=2) * 0.01
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    p16 = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        g = g0 * step
+        pr.grad = g.clone()
+        opt.step()
+        o.adamw(p, g.to(dev), m, v, p16, 1.5e-4, 0.9, 0.95, 1e-8, 0.05, step)
+    check("adamw 3 steps (params)", p, pr.detach(), 1e-6)
+    check("adamw 3 steps (update; f32 cancellation-limited)", p - p0.to(dev), pr.detach() - p0, 3e-3)
+    assert (p16.cpu() == p.cpu().to(torch.bfloat16)).all()
+    s = torch.zeros(1, device=dev)
+    o.sumsq(g0.to(dev), s)
+    check("grad norm", s.sqrt(), g0.norm().view(1), 1e-5)
