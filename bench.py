@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- ECAMP pre-training throughput on MI355X (the metric of BASELINE.json).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one full optimizer-inclusive pre-training micro-step of configs[1]: ViT-B/16 MAE encoder/decoder + SR
+head + reference BERT (6L/6H/1536, vocab 30000) with context fusion, B=256 pairs per GPU, 224^2 encoder input (448^2
+images resized on device), reports of S=128 tokens, bf16 activations / f32 master weights, train mode (dropout
+active), forward + backward + grad all-reduce (N>1) + grad-norm + fused AdamW + zero_grad (accum_iter=1).
+Inputs are synthetic and already resident in HBM when the timed region starts.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the bf16 MFMA GEMM family, timed live with HIP
+events on the launch stream over the timed region) and `cpu_baseline` (the oracle -- a CPU restatement of the
+reference validated against it -- timed on this box's host cores on a bounded sample; kind="port").
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak of MI355X (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
+METRIC = "pretrain image-report pairs/sec (ViT-B/16, 224^2, seq=128)"
+
+
+def cpu_baseline(seq, budget_s=25.0):
+    """Oracle fwd+bwd+AdamW on the host cores, B=8 pairs/step, fp32."""
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = orc.cfg_base()
+    B = 8
+    P = orc.set_requires_grad(orc.load_state(orc.new_params(cfg), recipe.recipe_state(cfg, seed=0)), cfg)
+    names = [k for k in orc.trainable_names(cfg)]
+    no_decay = set(orc.weight_decay_groups(cfg)[0])
+    m = {k: torch.zeros_like(P[k]) for k in names}
+    v = {k: torch.zeros_like(P[k]) for k in names}
+    batch = recipe.recipe_batch(cfg, B, seq, seed=0)
+
+    def step(i):
+        mim, res, mlm = orc.forward(P, cfg, batch, 0.75, recipe.recipe_noise(B, cfg.num_patches, seed=i), train=True)
+        (mim + res + mlm).backward()
+        with torch.no_grad():
+            for k in names:
+                if P[k].grad is not None:
+                    orc.adamw_step(P[k], P[k].grad, m[k], v[k], i + 1, 1.5e-4, 0.0 if k in no_decay else 0.05)
+                    P[k].grad = None
+
+    step(0)  # warm-up
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < budget_s and n < 8):
+        step(n + 1)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ecamp_oracle.py (CPU restatement of the reference, fp32): %d optimizer-inclusive steps of B=%d, S=%d, "
+                      "448^2 images, dropout on, after 1 warm-up; torch %s, %d threads" % (n, B, seq, torch.__version__, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU (configs[1] = 256)")
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    from ecamp_amd import _lib, optim
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp
+    from ecamp_amd.parallel import DistributedDataParallel
+    from ecamp_amd.util.misc import NativeScalerWithGradNormCount
+
+    torch.manual_seed(42 + rank)  # main_pretrain.py:189
+    cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = model_ecamp.ecamp(compute_dtype=cd).to(dev)
+    model.prepare()
+    net = DistributedDataParallel(model) if world > 1 else model
+    opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
+    scaler = NativeScalerWithGradNormCount()
+    batch = synthetic_batch(args.batch, args.seq, 448, seed=rank, device=dev)  # resident in HBM before timing
+    net.train()
+    opt.zero_grad()
+
+    def step():
+        mim, res, mlm = net(batch)
+        norm = scaler(mim + res + mlm, opt, parameters=model.parameters(), update_grad=True)
+        opt.zero_grad()
+        return mim, res, mlm, norm
+
+    for _ in range(args.warmup):
+        out = step()
+    lib = _lib.load()
+    if not args.no_prof:
+        lib.ecamp_prof_collect(-1, None, None, None)
+        lib.ecamp_prof_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    lib.ecamp_prof_enable(0)
+    losses = [float(t) for t in out[:3]]
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        res = {"metric": METRIC, "value": round(pairs / dt, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[1]: ViT-B/16 MAE enc/dec + SR head + reference BERT (6L/6H/1536, vocab 30000) "
+                                      "+ context fusion; full train step (fwd+bwd+grad-norm+AdamW, dropout on)",
+                          "pairs_per_gpu": args.batch, "global_batch": args.batch * world, "image": "448^2 -> 224^2 encoder input",
+                          "seq_len": args.seq, "mask_ratio": 0.75, "accum_iter": 1, "parallelism": "dp%d" % world,
+                          "last_losses_mim_res_mlm": [round(x, 5) for x in losses]}}
+        if not args.no_prof:
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            cat = 0 if args.dtype == "bf16" else 1
+            lib.ecamp_prof_collect(cat, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+            ams, afl, an = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            lib.ecamp_prof_collect(2, ctypes.byref(ams), ctypes.byref(afl), ctypes.byref(an))
+            ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               "traffic": None, "kernel": "gemm_%s_kernel" % ("bf16" if args.dtype == "bf16" else "f32"),
+                               "launches_per_step": n.value // max(args.steps, 1),
+                               "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2),
+                               "algorithmic_gflop_per_launch": round(fl.value / max(n.value, 1) / 1e9, 3),
+                               "gemm_ms_per_step": round(ms.value / args.steps, 3),
+                               "attention_ms_per_step": round(ams.value / args.steps, 3),
+                               "note": "achieved = sum(2MNK) of every GEMM launch in the timed region / sum of their HIP-event durations"}
+            # whole-step view with SURVEY.md 8(d)'s algorithmic FLOPs per pair
+            gflop_pair = 88.99 if args.seq == 128 else 136.64
+            res["roofline"]["whole_step_tflops"] = round(gflop_pair * 1e9 * args.batch / (dt / args.steps) / 1e12, 2)
+        if not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.seq)
+            except Exception as e:  # the baseline is reporting only; never lose the GPU number over it
+                res["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

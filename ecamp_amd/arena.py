@@ -1,0 +1,122 @@
+"""Flat parameter / gradient arenas in HBM (MI355X-first memory layout).
+
+All trainable parameters of the model live in ONE contiguous f32 buffer, their gradients in a second one of
+identical layout, and (bf16 mode) a bf16 shadow copy in a third.  `p.data` / `p.grad` of every nn.Parameter
+are views into these arenas, so
+  * the fused AdamW, the global grad-norm and `zero_grad` are one kernel launch each over the whole model,
+  * data-parallel gradient buckets are zero-copy slices of the gradient arena (no flatten/unflatten),
+  * weight-gradient GEMMs accumulate straight into their final location (no autograd AccumulateGrad pass).
+Parameters are laid out in registration order -- the reverse of the order in which backward finishes them --
+each padded to 64 elements (256 B) so every weight matrix is 16-B aligned for the GEMM loads.
+"""
+import torch
+
+from . import hip_ops as ops
+
+ALIGN = 64
+
+
+class ParamArena:
+    def __init__(self, model, compute_dtype):
+        # registration order, except that members of a fuse group (e.g. BERT query/key/value weights, which run as one
+        # [3H,H] GEMM) are placed back to back at the position of the group's first member
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        name_of = {id(p): n for n, p in named}
+        group_of = {}
+        for grp in (model.arena_fuse_groups() if hasattr(model, "arena_fuse_groups") else []):
+            for p in grp:
+                group_of[id(p)] = grp
+        params, seen = [], set()
+        for name, p in named:
+            for q in group_of.get(id(p), [p]):
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    params.append((name_of[id(q)], q))
+        if not params:
+            raise ValueError("model has no trainable parameters")
+        dev = params[0][1].device
+        if dev.type != "cuda":
+            raise ops._lib.EcampHipError("ParamArena needs the model on an MI355X device (model.to('cuda')); no CPU fallback exists")
+        self.device = dev
+        self.compute_dtype = compute_dtype
+        self.names, self.params, self.offsets, self.sizes = [], [], [], []
+        off = 0
+        for name, p in params:
+            n = p.numel()
+            self.names.append(name)
+            self.params.append(p)
+            self.offsets.append(off)
+            self.sizes.append(n)
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.flat_p = ops.zeros((off,), dev)
+        self.flat_g = ops.zeros((off,), dev)
+        self.flat_p16 = torch.empty((off,), device=dev, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
+        self.index = {}
+        for i, (p, o, n) in enumerate(zip(self.params, self.offsets, self.sizes)):
+            self.flat_p[o:o + n].view(p.shape).copy_(p.data)
+            p.data = self.flat_p[o:o + n].view(p.shape)
+            p.grad = self.flat_g[o:o + n].view(p.shape)
+            p._ecamp_slot = i
+            p._ecamp_arena = self
+            self.index[id(p)] = i
+        self.unused = [i for i, p in enumerate(self.params) if getattr(p, "_ecamp_unused", False)]
+        self.on_ready = None  # callback(list of slot ids) set by the data-parallel reducer
+        self.sync_shadow()
+
+    # -- views ---------------------------------------------------------------------------------
+    def grad(self, p):
+        i = self.index[id(p)]
+        o, n = self.offsets[i], self.sizes[i]
+        return self.flat_g[o:o + n].view(p.shape)
+
+    def w(self, p):
+        """The tensor the kernels read for parameter p: the bf16 shadow in bf16 mode, the f32 master otherwise."""
+        if self.flat_p16 is None:
+            return p.data
+        i = self.index[id(p)]
+        o, n = self.offsets[i], self.sizes[i]
+        return self.flat_p16[o:o + n].view(p.shape)
+
+    def _span(self, ps):
+        idx = [self.index[id(p)] for p in ps]
+        for a, b, p in zip(idx[:-1], idx[1:], ps[:-1]):
+            if b != a + 1 or self.sizes[a] % ALIGN != 0:
+                raise RuntimeError("parameters are not adjacent in the arena; cannot fuse")
+        return self.offsets[idx[0]], sum(self.sizes[i] for i in idx)
+
+    def fused_w(self, ps, shape):
+        o, n = self._span(ps)
+        src = self.flat_p16 if self.flat_p16 is not None else self.flat_p
+        return src[o:o + n].view(shape)
+
+    def fused_f32(self, ps, shape):
+        o, n = self._span(ps)
+        return self.flat_p[o:o + n].view(shape)
+
+    def fused_grad(self, ps, shape):
+        o, n = self._span(ps)
+        return self.flat_g[o:o + n].view(shape)
+
+    # -- maintenance ---------------------------------------------------------------------------
+    def sync_shadow(self):
+        """Refresh the bf16 shadow from the f32 masters (after load_state_dict / manual edits; AdamW does it itself)."""
+        if self.flat_p16 is not None:
+            ops.cast(self.flat_p, self.flat_p16)
+
+    def zero_grad(self):
+        ops.zero_(self.flat_g)
+
+    def attach_grads(self):
+        """Re-point p.grad at the arena if someone set it to None (stock optimizers' zero_grad(set_to_none=True))."""
+        lost = False
+        for p, o, n in zip(self.params, self.offsets, self.sizes):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + n].view(p.shape)
+                lost = True
+        if lost:
+            self.zero_grad()
+
+    def ready(self, *ps):
+        if self.on_ready is not None:
+            self.on_ready([self.index[id(p)] for p in ps])

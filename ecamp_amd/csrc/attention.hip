@@ -427,6 +427,8 @@ extern "C" int ecamp_attn_fwd(const void* q, const void* k, const void* v, void*
     a.o_sb = o_strides[0]; a.o_st = o_strides[1]; a.o_sh = o_strides[2];
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
     if (int rc = attn_check(a, hd, dtype, false)) return rc;
+    const bool prof = ecamp_prof_active();
+    if (prof) ecamp_prof_begin(ECAMP_PROF_ATTN, 4.0 * B * H * (double)Tq * Tk * hd, stream);
 #define D(T_)                                                  \
     do {                                                       \
         if (hd == 32) fwd_dispatch<T_, 32>(a, stream);         \
@@ -435,6 +437,7 @@ extern "C" int ecamp_attn_fwd(const void* q, const void* k, const void* v, void*
     } while (0)
     if (dtype == ECAMP_F32) D(float); else D(bf16_t);
 #undef D
+    if (prof) ecamp_prof_end(stream);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
@@ -460,6 +463,8 @@ extern "C" int ecamp_attn_bwd(const void* q, const void* k, const void* v, const
     a.dv_sb = dv_strides[0]; a.dv_st = dv_strides[1]; a.dv_sh = dv_strides[2];
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
     if (int rc = attn_check(a, hd, dtype, true)) return rc;
+    const bool prof = ecamp_prof_active();
+    if (prof) ecamp_prof_begin(ECAMP_PROF_ATTN, 8.0 * B * H * (double)Tq * Tk * hd, stream);
 #define D(T_)                                                  \
     do {                                                       \
         if (hd == 32) bwd_dispatch<T_, 32>(a, stream);         \
@@ -468,6 +473,7 @@ extern "C" int ecamp_attn_bwd(const void* q, const void* k, const void* v, const
     } while (0)
     if (dtype == ECAMP_F32) D(float); else D(bf16_t);
 #undef D
+    if (prof) ecamp_prof_end(stream);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }

@@ -130,4 +130,12 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// profile.hip
+int ecamp_prof_active();
+void ecamp_prof_begin(int cat, double work, hipStream_t s);
+void ecamp_prof_end(hipStream_t s);
+#define ECAMP_PROF_GEMM_BF16 0
+#define ECAMP_PROF_GEMM_F32 1
+#define ECAMP_PROF_ATTN 2
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

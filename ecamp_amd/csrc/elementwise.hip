@@ -231,3 +231,27 @@ extern "C" int ecamp_uniform(float* out, int64_t n, uint64_t seed, uint64_t offs
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// dx = dy * gelu'(pre)   (BertPredictionHeadTransform: dense -> GELU -> LayerNorm, bert_modeling.py:209)
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ dx, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float p[4], q[4];
+        ld4<T>(dy + i * 4, p);
+        ld4<T>(pre + i * 4, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] *= gelu_grad_f(q[r]);
+        st4<T>(dx + i * 4, p);
+    }
+}
+extern "C" int ecamp_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, hipStream_t stream) {
+    ECAMP_CHECK_ARG(dy && pre && dx && n % 4 == 0, "ecamp_gelu_bwd: bad args");
+    long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    if (dtype == ECAMP_F32) hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)dy, (const float*)pre, (float*)dx, n4);
+    else hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)pre, (bf16_t*)dx, n4);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}

@@ -361,8 +361,11 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
         else if (!a_kc && b_kc) hipLaunchKernelGGL((KERN<false, true>), grid, block, 0, stream, g); \
         else hipLaunchKernelGGL((KERN<false, false>), grid, block, 0, stream, g);                   \
     } while (0)
+    const bool prof = ecamp_prof_active();
+    if (prof) ecamp_prof_begin(dtype == ECAMP_BF16 ? ECAMP_PROF_GEMM_BF16 : ECAMP_PROF_GEMM_F32, 2.0 * (double)M * (double)N * (double)K, stream);
     if (dtype == ECAMP_BF16) LAUNCH(gemm_bf16_kernel); else LAUNCH(gemm_f32_kernel);
 #undef LAUNCH
+    if (prof) ecamp_prof_end(stream);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }

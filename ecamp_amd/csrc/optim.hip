@@ -62,3 +62,61 @@ extern "C" int ecamp_adamw(float* p, const float* g, float* m, float* v, void* p
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Whole-arena AdamW: one launch for every parameter of the model.  Parameters are padded to 64-element blocks in
+// the arena; `block_group[i]` (uint8) names the param_group of block i (255 = frozen / unused -> skipped), and
+// each group carries its own (lr, weight_decay) so timm's decay / no-decay split (main_pretrain.py:253) and
+// `lr_scale` groups need no extra launches.
+struct GroupHyper {
+    float lr[8];
+    float wd[8];
+};
+__global__ __launch_bounds__(256) void adamw_grouped_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            bf16_t* __restrict__ p16, const unsigned char* __restrict__ grp,
+                                                            long n4, GroupHyper hp, float b1, float b2, float eps, float bc1,
+                                                            float rsqrt_bc2, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const unsigned gi = grp[i >> 4];  // 16 float4 per 64-element block
+        if (gi >= 8) continue;
+        const float lr = hp.lr[gi], wd = hp.wd[gi];
+        float pp[4], gg[4], mm[4], vv[4];
+        ld4<float>(p + i * 4, pp);
+        ld4<float>(g + i * 4, gg);
+        ld4<float>(m + i * 4, mm);
+        ld4<float>(v + i * 4, vv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float gr = gg[r] * gscale;
+            pp[r] *= 1.0f - lr * wd;
+            mm[r] = b1 * mm[r] + (1.0f - b1) * gr;
+            vv[r] = b2 * vv[r] + (1.0f - b2) * gr * gr;
+            float denom = sqrtf(vv[r]) * rsqrt_bc2 + eps;
+            pp[r] -= (lr / bc1) * (mm[r] / denom);
+        }
+        st4<float>(p + i * 4, pp);
+        st4<float>(m + i * 4, mm);
+        st4<float>(v + i * 4, vv);
+        if (p16) st4<bf16_t>(p16 + i * 4, pp);
+    }
+}
+extern "C" int ecamp_adamw_grouped(float* p, const float* g, float* m, float* v, void* p_bf16, const uint8_t* block_group,
+                                   int64_t n, int32_t ngroups, const float* lr_host, const float* wd_host, float beta1,
+                                   float beta2, float eps, int64_t step, float grad_scale, hipStream_t stream) {
+    ECAMP_CHECK_ARG(p && g && m && v && block_group && lr_host && wd_host, "ecamp_adamw_grouped: null pointer");
+    ECAMP_CHECK_ARG(n % 64 == 0 && ngroups >= 1 && ngroups <= 8 && step >= 1, "ecamp_adamw_grouped: bad args (n=%ld, groups=%d)", (long)n, ngroups);
+    GroupHyper hp;
+    for (int i = 0; i < 8; ++i) {
+        hp.lr[i] = i < ngroups ? lr_host[i] : 0.f;
+        hp.wd[i] = i < ngroups ? wd_host[i] : 0.f;
+    }
+    long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_grouped_kernel, dim3(nb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, block_group, n4, hp, beta1,
+                       beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}

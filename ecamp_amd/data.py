@@ -1,0 +1,49 @@
+"""Synthetic stand-in for ContextBertDataset (ECAMP/Pre-training/module/pretrain_datasets.py:34-239): the real
+dataset needs licensed MIMIC-CXR images + two CSVs that are not in the reference repo.  Emits the same batch dict
+schema (pretrain_datasets.py:228-237) with the statistics SURVEY.md 8d prescribes."""
+import torch
+from torch.utils.data import Dataset
+
+PAD, UNK, CLS, MASK, SEP = 0, 1, 2, 3, 4
+
+
+def synthetic_batch(B, S=256, img=448, vocab=30000, seed=0, device="cpu"):
+    g = torch.Generator().manual_seed(1234 + seed)
+    image = torch.randn(B, 3, img, img, generator=g)
+    labels = torch.randint(5, vocab, (B, S), generator=g)
+    lens = torch.randint(max(2, S // 4), S + 1, (B,), generator=g)
+    am = (torch.arange(S)[None, :] < lens[:, None]).long()
+    labels = labels * am
+    labels[:, 0] = CLS
+    mask_here = (torch.rand(B, S, generator=g) < 0.5) & (am == 1)
+    mask_here[:, 0] = False
+    ids = labels.clone()
+    ids[mask_here] = MASK
+    weights = torch.ones(B, S)
+    dim = torch.rand(B, S, generator=g) < 0.10
+    weights[dim] = 0.05
+    dcnt, mcnt, ldm = dim.sum(1).float(), mask_here.sum(1).float(), (dim & mask_here).sum(1).float()
+    expand = torch.where((mcnt > 0) & (dcnt > 0), (0.95 * (dcnt - ldm) + mcnt) / (mcnt - 0.95 * ldm).clamp_min(1e-6), torch.ones(B))
+    weights = torch.where(mask_here, weights * expand[:, None], weights)  # pretrain_datasets.py:177-181
+    batch = dict(image=image, ids=ids, labels=labels, attention_mask=am, type_ids=torch.zeros(B, S, dtype=torch.long),
+                 weights=weights, column=torch.randint(0, 3, (B,), generator=g), row=torch.randint(0, 3, (B,), generator=g))
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+class SyntheticContextBertDataset(Dataset):
+    """`len` samples of the schema above; `collate_fn` stacks WITHOUT the reference's .squeeze() (which drops the batch
+    dimension at B == 1, pretrain_datasets.py:218-225)."""
+
+    def __init__(self, length=1024, max_caption_length=256, img=448, vocab=30000, seed=0):
+        self.length, self.S, self.img, self.vocab, self.seed = length, max_caption_length, img, vocab, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        b = synthetic_batch(1, self.S, self.img, self.vocab, seed=self.seed * 1000003 + index)
+        return {k: v[0] for k, v in b.items()}
+
+    @staticmethod
+    def collate_fn(instances):
+        return {k: torch.stack([inst[k] for inst in instances]) for k in instances[0]}

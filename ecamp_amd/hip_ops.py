@@ -149,6 +149,13 @@ def add(a, b):
     return y
 
 
+def mul_gelu_grad(dy, pre):
+    _chk(dy, pre)
+    dx = torch.empty_like(dy)
+    call("ecamp_gelu_bwd", ptr(dy), ptr(pre), ptr(dx), dy.numel(), code(dy.dtype), stream())
+    return dx
+
+
 def cast(src, dst):
     _chk(src, dst)
     call("ecamp_cast", ptr(src), ptr(dst), src.numel(), code(src.dtype), code(dst.dtype), stream())
@@ -313,3 +320,10 @@ def sumsq(x, out):
 def adamw(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     call("ecamp_adamw", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
          float(wd), int(step), float(grad_scale), stream())
+
+
+def adamw_grouped(p, g, m, v, p16, block_group, lrs, wds, beta1, beta2, eps, step, grad_scale=1.0):
+    n = len(lrs)
+    arr = ctypes.c_float * n
+    call("ecamp_adamw_grouped", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), ptr(block_group), p.numel(), n, arr(*lrs), arr(*wds),
+         float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream())

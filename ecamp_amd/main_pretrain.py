@@ -1,0 +1,163 @@
+"""ECAMP pre-training driver -- same command line as ECAMP/Pre-training/main_pretrain.py (run.sh:3-16 works
+unchanged), on the MI355X-native model / optimizer / data-parallel reducer.
+
+    python -m torch.distributed.run --nproc_per_node=8 -m ecamp_amd.main_pretrain --batch_size 256 --accum_iter 8 ...
+
+Extra flags (all optional): --compute_dtype {bf16,fp32}, --max_caption_length, --synthetic_len, --print_freq.
+The MIMIC-CXR `ContextBertDataset` (pretrain_datasets.py) is outside this round's scope: when
+`--data_path` holds no dataset CSV the synthetic stand-in with the same batch schema is used.
+"""
+import argparse
+import datetime
+import json
+import os
+import shutil
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, DistributedSampler
+
+from . import optim as optim_factory
+from .data import SyntheticContextBertDataset
+from .engine_pretrain import train_one_epoch  # noqa: F401  (re-exported: the reference defines it in this module)
+from .module import model_ecamp
+from .parallel import DistributedDataParallel
+from .util import misc
+from .util.misc import NativeScalerWithGradNormCount as NativeScaler
+
+
+def dump(file_path, args):
+    import yaml
+    with open(file_path, "w") as f:
+        yaml.dump(data={k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in vars(args).items()}, stream=f)
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser("ECAMP pre-training", add_help=False)
+    p.add_argument("--description", type=str, default="ecamp_pretrain")
+    p.add_argument("--batch_size", default=256, type=int, help="Batch size per GPU (effective batch size is batch_size * accum_iter * # gpus")
+    p.add_argument("--epochs", default=115, type=int)
+    p.add_argument("--max_epoch", default=200, type=int)
+    p.add_argument("--accum_iter", default=2, type=int)
+    p.add_argument("--model", default="ecamp", type=str, metavar="MODEL")
+    p.add_argument("--input_size", default=448, type=int, help="images input size")
+    p.add_argument("--mask_ratio", default=0.75, type=float)
+    p.add_argument("--norm_pix_loss", action="store_true")
+    p.set_defaults(norm_pix_loss=False)
+    p.add_argument("--weight_decay", type=float, default=0.05)
+    p.add_argument("--lr", type=float, default=None, metavar="LR", help="learning rate (absolute lr)")
+    p.add_argument("--min_lr", type=float, default=0.0, metavar="LR")
+    p.add_argument("--warmup_epochs", type=int, default=40, metavar="N")
+    p.add_argument("--data_path", default="./dataset_dir", type=str)
+    p.add_argument("--output_dir", default="./output_dir")
+    p.add_argument("--job_dir", default="code_repo")
+    p.add_argument("--log_dir", default="./output_dir")
+    p.add_argument("--seed", default=42, type=int)
+    p.add_argument("--resume", default="")
+    p.add_argument("--start_epoch", default=0, type=int, metavar="N")
+    p.add_argument("--num_workers", default=16, type=int)
+    p.add_argument("--pin_mem", action="store_true")
+    p.add_argument("--no_pin_mem", action="store_false", dest="pin_mem")
+    p.set_defaults(pin_mem=True)
+    p.add_argument("--world_size", default=1, type=int)
+    p.add_argument("--local_rank", "--local-rank", default=-1, type=int)
+    p.add_argument("--dist_on_itp", action="store_true")
+    p.add_argument("--dist_url", default="env://")
+    # additions of this implementation
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--max_caption_length", default=256, type=int)
+    p.add_argument("--synthetic_len", default=4096, type=int, help="samples per epoch of the synthetic dataset")
+    p.add_argument("--print_freq", default=20, type=int)
+    p.add_argument("--snapshot_code", action="store_true", help="copy ./ into output_dir/job_dir like the reference does")
+    return p
+
+
+def main(args):
+    misc.init_distributed_mode(args)
+    if args.lr is None:
+        raise SystemExit("--lr is required (absolute learning rate), as in the reference")
+    device = torch.device("cuda")
+    seed = args.seed + misc.get_rank()
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+
+    if os.path.exists(os.path.join(args.data_path, "mimic-cxr-2.0.0-entity-llm.csv")):
+        raise SystemExit("the MIMIC-CXR ContextBertDataset pipeline is not part of this implementation yet (SURVEY.md 8f, f2)")
+    dataset_train = SyntheticContextBertDataset(args.synthetic_len, args.max_caption_length, args.input_size, seed=args.seed)
+    num_tasks, global_rank = misc.get_world_size(), misc.get_rank()
+    sampler_train = DistributedSampler(dataset_train, num_replicas=num_tasks, rank=global_rank, shuffle=True)
+    print("Sampler_train = %s" % str(sampler_train))
+
+    args.log_dir = os.path.join(args.output_dir, "tensorboard")
+    log_writer = None
+    if global_rank == 0 and args.log_dir is not None:
+        os.makedirs(args.log_dir, exist_ok=True)
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            log_writer = SummaryWriter(log_dir=args.log_dir)
+        except Exception:  # tensorboard is optional
+            print("tensorboard not available: scalars go to log.txt only")
+        if args.snapshot_code:
+            dst = os.path.join(args.output_dir, args.job_dir)
+            if os.path.exists(dst):
+                shutil.rmtree(dst)
+            shutil.copytree(os.path.dirname(os.path.abspath(__file__)), dst)
+
+    data_loader_train = DataLoader(dataset_train, sampler=sampler_train, batch_size=args.batch_size, num_workers=args.num_workers,
+                                   pin_memory=args.pin_mem, drop_last=True, collate_fn=dataset_train.collate_fn)
+
+    dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    model = model_ecamp.__dict__[args.model](norm_pix_loss=args.norm_pix_loss, compute_dtype=dtype)
+    model.to(device)
+    model_without_ddp = model
+    print("Model = %s" % str(model_without_ddp))
+    eff_batch_size = args.batch_size * args.accum_iter * misc.get_world_size()
+    print("actual lr: %.2e" % args.lr)
+    print("accumulate grad iterations: %d" % args.accum_iter)
+    print("effective batch size: %d" % eff_batch_size)
+
+    model_without_ddp.prepare()
+    if args.distributed:
+        model = DistributedDataParallel(model, device_ids=[args.gpu], find_unused_parameters=True)
+        model_without_ddp = model.module
+
+    # following timm: no weight decay for bias and norm layers
+    param_groups = optim_factory.add_weight_decay(model_without_ddp, args.weight_decay)
+    optimizer = optim_factory.FusedAdamW(param_groups, lr=args.lr, betas=(0.9, 0.95))
+    print(optimizer)
+    loss_scaler = NativeScaler()
+    if args.output_dir and misc.is_main_process():
+        dump(os.path.join(args.output_dir, "config.yaml"), args)
+    misc.load_model(args=args, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler)
+
+    print(f"Start training for {args.epochs} epochs")
+    start_time = time.time()
+    write_description = False
+    for epoch in range(args.start_epoch, args.epochs):
+        if args.distributed:
+            data_loader_train.sampler.set_epoch(epoch)
+        train_stats = train_one_epoch(model, data_loader_train, optimizer, device, epoch, loss_scaler, log_writer=log_writer, args=args)
+        if args.output_dir:
+            # checkpoint cadence of main_pretrain.py:274-292
+            if (epoch == 0) or (60 <= epoch < 100 and epoch % 10 == 0) or (epoch >= 100 and (epoch % 5 == 0 or epoch + 1 == args.epochs)):
+                misc.save_model(args=args, model=model, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler, epoch=epoch)
+        log_stats = {**{f"train_{k}": v for k, v in train_stats.items()}, "epoch": epoch}
+        if args.output_dir and misc.is_main_process():
+            if log_writer is not None:
+                log_writer.flush()
+            with open(os.path.join(args.output_dir, "log.txt"), mode="a", encoding="utf-8") as f:
+                if not write_description:
+                    f.write(args.description + "\n")
+                    write_description = True
+                f.write(json.dumps(log_stats) + "\n")
+    total_time = time.time() - start_time
+    print("Training time {}".format(str(datetime.timedelta(seconds=int(total_time)))))
+
+
+if __name__ == "__main__":
+    args = get_args_parser().parse_args()
+    if args.output_dir:
+        Path(args.output_dir).mkdir(parents=True, exist_ok=True)
+    main(args)

@@ -1,0 +1,257 @@
+"""ECAMP model -- drop-in for ECAMP/Pre-training/module/model_ecamp.py (ToniChopp/ECAMP), MI355X-native.
+
+Same public surface: `ecamp(**kwargs)` factory (model_ecamp.py:328-333), `ECAMP.forward(batch, mask_ratio=0.75)
+-> (mim_loss, res_loss, mlm_loss)` (:303-325), identical `state_dict()` keys, nn.Module semantics
+(`parameters()`, `train()/eval()`, `load_state_dict`).  Everything between is different: the forward and the
+backward are ~35 hand-written stages of HIP kernels (ecamp_amd/functions.py) over flat HBM arenas
+(ecamp_amd/arena.py).  There is no CPU execution path: calling the model without an MI355X raises.
+
+Lifted hard-coded constants of the reference (defaults unchanged): `.cuda()` -> the model's device; Resize([224,224])
+-> `img_size`; SR window 12 -> `sr_window` (scaled with the patch grid); `BertConfig()` -> `bert_config`;
+`bert_mlp` out features 768 -> `bert_config.hidden_size`.
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from ..util.pos_embed import get_2d_sincos_pos_embed
+from .bert_config import BertConfig
+from .bert_encoder import MultiModalBertEncoder
+
+
+class PatchEmbed(nn.Module):
+    """timm 0.4.12 PatchEmbed parameter container (`proj` = Conv2d k=stride=patch)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class Block(nn.Module):
+    """timm 0.4.12 Block parameter container (norm1, attn.qkv/proj, norm2, mlp.fc1/fc2)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm):
+        super().__init__()
+        assert qkv_bias, "the reference always builds Blocks with qkv_bias=True"
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+class InterpolateConvSuperResolution(nn.Module):
+    """Parameter container of model_ecamp.py:28-46 (bilinear x2 -> conv -> ReLU -> conv -> +skip -> ReLU)."""
+
+    def __init__(self, scale_factor, in_channels, out_channels, kernel_size=3, stride=1, padding=1):
+        super().__init__()
+        if (scale_factor, in_channels, out_channels, kernel_size, stride, padding) != (2, 3, 3, 3, 1, 1):
+            raise ValueError("the HIP SR head implements the reference configuration (x2, 3->3, 3x3, stride 1, pad 1) only")
+        self.scale_factor = scale_factor
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+
+
+class ECAMP(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=768,
+                 decoder_depth=4, decoder_num_heads=6, mlp_ratio=4.0, norm_layer=nn.LayerNorm, norm_pix_loss=False,
+                 bert_config=None, compute_dtype=torch.bfloat16, sr_window=None):
+        super().__init__()
+        if in_chans != 3 or patch_size % 4 != 0:
+            raise ValueError("in_chans must be 3 and patch_size a multiple of 4")
+        for d, h in ((embed_dim, num_heads), (decoder_embed_dim, decoder_num_heads)):
+            if d % h != 0 or d // h not in (32, 64, 128):
+                raise ValueError("head_dim must be 32, 64 or 128 (got %d/%d)" % (d, h))
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 (parity mode) or torch.bfloat16")
+        self.img_size, self.patch_size, self.embed_dim = img_size, patch_size, embed_dim
+        self.num_heads, self.decoder_embed_dim, self.decoder_num_heads = num_heads, decoder_embed_dim, decoder_num_heads
+        self.compute_dtype = compute_dtype
+        self.bert_config = bert_config if bert_config is not None else BertConfig()
+        # image encoder (model_ecamp.py:58-69)
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.num_patches = num_patches = self.patch_embed.num_patches
+        grid = img_size // patch_size
+        self.sr_window = sr_window if sr_window is not None else (12 * grid) // 14  # 12 of 14 super-patches (:208)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim), requires_grad=False)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        # image decoder + SR (model_ecamp.py:72-94)
+        self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, decoder_embed_dim), requires_grad=False)
+        self.decoder_blocks = nn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+                                             for _ in range(decoder_depth)])
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        self.decoder_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
+        self.super_res = InterpolateConvSuperResolution(scale_factor=2, in_channels=3, out_channels=3, kernel_size=3, stride=1, padding=1)
+        # report side (model_ecamp.py:96-100)
+        self.bert_encoder = MultiModalBertEncoder(self.bert_config)
+        self.bert_mlp = nn.Linear(embed_dim, self.bert_config.hidden_size, bias=True)
+        self.norm_pix_loss = norm_pix_loss  # parsed, stored, never used -- exactly like the reference (:100)
+        self.initialize_weights()
+        # runtime state (not parameters)
+        self.arena = None
+        self.keep_aux = False
+        self._aux = None
+        self._aux_logits = None
+        self._rng_seed = None
+        self._rng_ctr = 0
+        self._norm_cache = {}
+        self._register_load_state_dict_pre_hook(self._alias_old_keys)
+        self.register_load_state_dict_post_hook(lambda mod, inc: mod.arena.sync_shadow() if mod.arena is not None else None)
+
+    # ---------------------------------------------------------------------------------------------
+    def initialize_weights(self):
+        """model_ecamp.py:105-135 plus HF's embedding init (normal(0, initializer_range), PAD row zero)."""
+        g = int(self.num_patches ** 0.5)
+        self.pos_embed.data.copy_(torch.from_numpy(get_2d_sincos_pos_embed(self.pos_embed.shape[-1], g, cls_token=True)).float().unsqueeze(0))
+        self.decoder_pos_embed.data.copy_(torch.from_numpy(get_2d_sincos_pos_embed(self.decoder_pos_embed.shape[-1], g, cls_token=True)).float().unsqueeze(0))
+        w = self.patch_embed.proj.weight.data
+        torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        torch.nn.init.normal_(self.cls_token, std=.02)
+        torch.nn.init.normal_(self.mask_token, std=.02)
+        for mod in self.modules():
+            if isinstance(mod, nn.Embedding):
+                mod.weight.data.normal_(mean=0.0, std=self.bert_config.initializer_range)
+                if mod.padding_idx is not None:
+                    mod.weight.data[mod.padding_idx].zero_()
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @staticmethod
+    def _alias_old_keys(state_dict, prefix, *args):
+        """Old checkpoints name the fusion layer `cross_attn_layer` (Visualization/main_visualization.py:91-92)."""
+        for k in list(state_dict.keys()):
+            if ".bert.cross_attn_layer." in k:
+                state_dict[k.replace(".bert.cross_attn_layer.", ".bert.context_fusion_layer.")] = state_dict.pop(k)
+
+    # ---------------------------------------------------------------------------------------------
+    def arena_fuse_groups(self):
+        groups = []
+        for mod in self.modules():
+            if hasattr(mod, "query") and hasattr(mod, "key") and hasattr(mod, "value"):
+                groups.append([mod.query.weight, mod.key.weight, mod.value.weight])
+                groups.append([mod.query.bias, mod.key.bias, mod.value.bias])
+        return groups
+
+    def _apply(self, fn, *a, **k):
+        self.arena = None  # .to()/.float() re-materialise parameters: the arena is rebuilt lazily
+        return super()._apply(fn, *a, **k)
+
+    def prepare(self):
+        """Move the parameters into the flat HBM arenas (idempotent).  Called lazily by forward()."""
+        if self.arena is None:
+            from ..arena import ParamArena
+            from .. import _lib
+            _lib.load()
+            self.arena = ParamArena(self, self.compute_dtype)
+            self._rng_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) & 0xFFFFFFFFFFFFFFFF
+        else:
+            self.arena.attach_grads()
+        return self.arena
+
+    def sync_params(self):
+        """Call after editing parameters by hand (the bf16 shadow the GEMMs read is refreshed)."""
+        if self.arena is not None:
+            self.arena.sync_shadow()
+
+    def next_rng(self):
+        self._rng_ctr += 1
+        return self._rng_seed, self._rng_ctr
+
+    def _loss_norm(self, n1, n2, dev):
+        key = (n1, n2, str(dev))
+        if key not in self._norm_cache:
+            self._norm_cache[key] = torch.tensor([1.0 / n1, 1.0 / n2], dtype=torch.float32, device=dev)
+        return self._norm_cache[key]
+
+    # ---------------------------------------------------------------------------------------------
+    def forward_report_decoder(self, latent, ids_keep, caption_ids, labels, attention_mask, token_type_ids, weights, B=None, T=None):
+        """model_ecamp.py:267-273 (`ids_keep` is unused there too).  `latent` is [B*T, D] here."""
+        from ..functions import ReportStemFn
+        lat, gap = ReportStemFn.apply(latent, self, B, T)
+        out = self.bert_encoder(lat, gap, caption_ids, labels, attention_mask, token_type_ids, weights, self, B, T)
+        return out.loss
+
+    def forward(self, batch, mask_ratio=0.75, noise=None):
+        """batch: dict with the schema of pretrain_datasets.py:228-237 (CPU or device tensors).
+        noise: optional [B, L] masking noise standing in for torch.rand at model_ecamp.py:177 (parity tests)."""
+        from ..functions import DecStemFn, ImgLossFn, NormFn, StemFn, VitBlockFn
+        A = self.prepare()
+        dev = A.device
+        big = batch["image"].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        mv = lambda t, dt: t.to(dev, dtype=dt, non_blocking=True).contiguous()
+        ids, labels = mv(batch["ids"], torch.int64), mv(batch["labels"], torch.int64)
+        attention_mask, type_ids = mv(batch["attention_mask"], torch.int64), mv(batch["type_ids"], torch.int64)
+        weights = mv(batch["weights"], torch.float32)
+        column, row = mv(batch["column"], torch.int64).view(-1), mv(batch["row"], torch.int64).view(-1)
+        if ids.dim() == 1:  # the reference's collate_fn .squeeze()s a batch of one (pretrain_datasets.py:218-225)
+            ids, labels, attention_mask, type_ids, weights = (t.unsqueeze(0) for t in (ids, labels, attention_mask, type_ids, weights))
+        B = big.shape[0]
+        if big.shape[1:] != (3, 2 * self.img_size, 2 * self.img_size):
+            raise ValueError("image must be [B,3,%d,%d] (2x the encoder resolution), got %s" % (2 * self.img_size, 2 * self.img_size, tuple(big.shape)))
+        if noise is not None:
+            noise = noise.to(dev, dtype=torch.float32).contiguous()
+
+        x, imgs, mask, ids_restore, ids_keep = StemFn.apply(big, noise, self, mask_ratio, self.cls_token)   # global feature
+        T = ids_keep.shape[1] + 1
+        for blk in self.blocks:
+            x = VitBlockFn.apply(x, blk, self, B, T, self.num_heads)
+        latent = NormFn.apply(x, self.norm, self)
+        xd = DecStemFn.apply(latent, ids_restore, ids_keep, self, B)
+        for blk in self.decoder_blocks:
+            xd = VitBlockFn.apply(xd, blk, self, B, self.num_patches + 1, self.decoder_num_heads)
+        img_losses = ImgLossFn.apply(xd, imgs, big, mask, column, row, self, B)
+        mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
+        if self.keep_aux:
+            self._aux = dict(self._aux or {}, imgs=imgs, mask=mask, ids_restore=ids_restore, ids_keep=ids_keep,
+                             latent=latent.view(B, T, -1), logits=self._aux_logits)
+        return img_losses[0], img_losses[1], mlm_loss
+
+
+def ecamp(**kwargs):
+    """ViT-B/16 encoder + 512-d/4-block decoder + reference BERT -- model_ecamp.py:328-333."""
+    return ECAMP(patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512, decoder_depth=4,
+                 decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def ecamp_tiny(**kwargs):
+    """BASELINE.json configs[0]: ViT-Tiny/16 (D=192, 3 heads) + 2-layer BERT; decoder unchanged."""
+    kwargs.setdefault("bert_config", BertConfig(num_hidden_layers=2))
+    return ECAMP(patch_size=16, in_chans=3, embed_dim=192, depth=12, num_heads=3, decoder_embed_dim=512, decoder_depth=4,
+                 decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def ecamp_large_448(**kwargs):
+    """BASELINE.json configs[3]: ViT-L/16 at 448^2 encoder input (decoder sequence 785)."""
+    return ECAMP(img_size=448, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512,
+                 decoder_depth=4, decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)

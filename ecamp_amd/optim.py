@@ -1,0 +1,116 @@
+"""Optimizer side of the hot path: timm's decay / no-decay parameter grouping (timm 0.4.12
+optim_factory.add_weight_decay, call site main_pretrain.py:253) and AdamW(betas=(0.9, 0.95)) (:254) as ONE fused
+HIP launch over the parameter arena (ecamp_adamw_grouped), which also refreshes the bf16 shadow weights."""
+import torch
+
+from . import hip_ops as ops
+
+
+def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
+    """1-D tensors and names ending in '.bias' get no decay; everything else (incl. the 3-D cls/mask tokens and the
+    embedding tables) is decayed.  Returns [no_decay group, decay group] like timm."""
+    decay, no_decay = [], []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
+            no_decay.append(param)
+        else:
+            decay.append(param)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled decay, bias correction, eps outside the sqrt) on the flat arenas.
+    `param_groups` behave as usual (lr schedulers write `group['lr']`); parameters whose gradient never arrives in
+    the reference (`_ecamp_unused`, the BERT pooler) are skipped entirely, exactly as torch skips `grad is None`."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) > 8:
+            raise ValueError("FusedAdamW supports at most 8 param groups")
+        b = {tuple(g["betas"]) for g in self.param_groups}
+        e = {g["eps"] for g in self.param_groups}
+        if len(b) != 1 or len(e) != 1:
+            raise ValueError("all groups must share betas and eps")
+        self._arena = None
+        self._step = 0
+        self._ecamp_reducer = None
+        self.grad_scale = 1.0
+
+    def _bind(self):
+        if self._arena is not None:
+            return self._arena
+        arena = None
+        for g in self.param_groups:
+            for p in g["params"]:
+                a = getattr(p, "_ecamp_arena", None)
+                if a is None:
+                    raise RuntimeError("FusedAdamW: parameter is not in an ecamp_amd arena -- call model.prepare() (or run one "
+                                       "forward) after model.to('cuda') and before the first optimizer.step()")
+                arena = arena or a
+                if a is not arena:
+                    raise RuntimeError("FusedAdamW: parameters from different arenas")
+        nblk = arena.total // 64
+        table = torch.full((nblk,), 255, dtype=torch.uint8)
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if getattr(p, "_ecamp_unused", False):
+                    continue
+                i = arena.index[id(p)]
+                o, n = arena.offsets[i], arena.sizes[i]
+                table[o // 64:(o + n + 63) // 64] = gi
+        self._table = table.to(arena.device)
+        self._m = ops.zeros((arena.total,), arena.device)
+        self._v = ops.zeros((arena.total,), arena.device)
+        self._arena = arena
+        return arena
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        A = self._bind()
+        self._step += 1
+        g0 = self.param_groups[0]
+        ops.adamw_grouped(A.flat_p, A.flat_g, self._m, self._v, A.flat_p16, self._table, [g["lr"] for g in self.param_groups],
+                          [g["weight_decay"] for g in self.param_groups], g0["betas"][0], g0["betas"][1], g0["eps"], self._step,
+                          self.grad_scale)
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        """One memset of the gradient arena; p.grad stay views of it (set_to_none would detach them)."""
+        self._bind().zero_grad()
+
+    # -- checkpoint format compatible with torch.optim.AdamW (misc.py:295-338) ---------------------------------
+    def state_dict(self):
+        A = self._bind()
+        state, packed_groups, idx = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                i = A.index[id(p)]
+                o, n = A.offsets[i], A.sizes[i]
+                if self._step > 0 and not getattr(p, "_ecamp_unused", False):
+                    state[idx] = {"step": torch.tensor(float(self._step)), "exp_avg": self._m[o:o + n].view(p.shape).clone(),
+                                  "exp_avg_sq": self._v[o:o + n].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+            packed_groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        return {"state": state, "param_groups": packed_groups}
+
+    def load_state_dict(self, sd):
+        A = self._bind()
+        idx = 0
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            for k, v in sg.items():
+                if k != "params":
+                    g[k] = v
+            for p in g["params"]:
+                st = sd["state"].get(idx, sd["state"].get(str(idx)))
+                if st is not None:
+                    i = A.index[id(p)]
+                    o, n = A.offsets[i], A.sizes[i]
+                    self._m[o:o + n].view(p.shape).copy_(st["exp_avg"])
+                    self._v[o:o + n].view(p.shape).copy_(st["exp_avg_sq"])
+                    self._step = int(float(st["step"]))
+                idx += 1

@@ -1,0 +1,311 @@
+"""Runtime helpers with the API of ECAMP/Pre-training/util/misc.py (same names, argument meaning and return
+values), rebuilt for the MI355X path:
+  * init_distributed_mode  -> one process per GPU, backend "nccl" (= RCCL over xGMI on ROCm)      misc.py:216-248
+  * NativeScalerWithGradNormCount -> bf16/f32 need no loss scaling; the grad-norm is ONE fused reduction over the
+    gradient arena and the optimizer step ONE fused AdamW launch                                  misc.py:251-277
+  * get_grad_norm_ / all_reduce_mean / MetricLogger / SmoothedValue / save_model / load_model      misc.py:24-213,280-347
+Device syncs are lazy: meters accept 0-d device tensors and only read them back when a value is printed or
+averaged (the reference forces 4 host syncs per micro-step, main_pretrain.py:143-145,155).
+"""
+import builtins
+import datetime
+import os
+import time
+from collections import defaultdict, deque
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+inf = float("inf")
+
+
+class SmoothedValue(object):
+    """Window / global statistics of a scalar series (misc.py:24-83).  Values may be Python numbers or 0-d tensors."""
+
+    def __init__(self, window_size=20, fmt=None):
+        self.deque = deque(maxlen=window_size)
+        self._pending = []  # (tensor, n) pairs not yet read back from the device
+        self.total = 0.0
+        self.count = 0
+        self.fmt = fmt if fmt is not None else "{median:.4f} ({global_avg:.4f})"
+
+    def update(self, value, n=1):
+        if isinstance(value, torch.Tensor):
+            self._pending.append((value.detach(), n))
+            return
+        self.deque.append(value)
+        self.count += n
+        self.total += value * n
+
+    def _flush(self):
+        if self._pending:
+            vals = torch.stack([v.float().reshape(()) for v, _ in self._pending]).tolist()  # ONE device read-back
+            for (_, n), v in zip(self._pending, vals):
+                self.deque.append(v)
+                self.count += n
+                self.total += v * n
+            self._pending = []
+
+    def synchronize_between_processes(self):
+        """Does not synchronise the window, only count/total (as the reference)."""
+        self._flush()
+        if not is_dist_avail_and_initialized():
+            return
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(t)
+        t = t.tolist()
+        self.count = int(t[0])
+        self.total = t[1]
+
+    @property
+    def median(self):
+        self._flush()
+        return torch.tensor(list(self.deque)).median().item()
+
+    @property
+    def avg(self):
+        self._flush()
+        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+
+    @property
+    def global_avg(self):
+        self._flush()
+        return self.total / self.count
+
+    @property
+    def max(self):
+        self._flush()
+        return max(self.deque)
+
+    @property
+    def value(self):
+        self._flush()
+        return self.deque[-1]
+
+    def __str__(self):
+        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+
+
+class MetricLogger(object):
+    def __init__(self, delimiter="\t"):
+        self.meters = defaultdict(SmoothedValue)
+        self.delimiter = delimiter
+
+    def update(self, **kwargs):
+        for k, v in kwargs.items():
+            if v is None:
+                continue
+            assert isinstance(v, (float, int, torch.Tensor))
+            self.meters[k].update(v)
+
+    def __getattr__(self, attr):
+        if attr in self.meters:
+            return self.meters[attr]
+        if attr in self.__dict__:
+            return self.__dict__[attr]
+        raise AttributeError("'{}' object has no attribute '{}'".format(type(self).__name__, attr))
+
+    def __str__(self):
+        return self.delimiter.join("{}: {}".format(name, str(meter)) for name, meter in self.meters.items())
+
+    def synchronize_between_processes(self):
+        for meter in self.meters.values():
+            meter.synchronize_between_processes()
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
+    def log_every(self, iterable, print_freq, header=None):
+        header = header or ""
+        n = len(iterable)
+        start_time = end = time.time()
+        iter_time, data_time = SmoothedValue(fmt="{avg:.4f}"), SmoothedValue(fmt="{avg:.4f}")
+        width = str(len(str(n)))
+        parts = [header, "[{0:" + width + "d}/{1}]", "eta: {eta}", "{meters}", "time: {time}", "data: {data}"]
+        if torch.cuda.is_available():
+            parts.append("max mem: {memory:.0f}")
+        msg = self.delimiter.join(parts)
+        for i, obj in enumerate(iterable):
+            data_time.update(time.time() - end)
+            yield obj
+            iter_time.update(time.time() - end)
+            if i % print_freq == 0 or i == n - 1:
+                eta = str(datetime.timedelta(seconds=int(iter_time.global_avg * (n - i))))
+                kw = dict(eta=eta, meters=str(self), time=str(iter_time), data=str(data_time))
+                if torch.cuda.is_available():
+                    kw["memory"] = torch.cuda.max_memory_allocated() / (1024.0 * 1024.0)
+                print(msg.format(i, n, **kw))
+            end = time.time()
+        total = time.time() - start_time
+        print("{} Total time: {} ({:.4f} s / it)".format(header, str(datetime.timedelta(seconds=int(total))), total / max(n, 1)))
+
+
+# --------------------------------------------------------------------------------------------- distributed
+def setup_for_distributed(is_master):
+    """Mute print() on non-master ranks (misc.py:170-184)."""
+    builtin_print = builtins.print
+
+    def print(*args, **kwargs):
+        force = kwargs.pop("force", False) or (get_world_size() > 8)
+        if is_master or force:
+            builtin_print("[{}] ".format(datetime.datetime.now().time()), end="")
+            builtin_print(*args, **kwargs)
+
+    builtins.print = print
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def save_on_master(*args, **kwargs):
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
+def init_distributed_mode(args):
+    """Same environment contract as misc.py:216-248 (OMPI / torchrun RANK+WORLD_SIZE+LOCAL_RANK / SLURM)."""
+    if getattr(args, "dist_on_itp", False):
+        args.rank = int(os.environ["OMPI_COMM_WORLD_RANK"])
+        args.world_size = int(os.environ["OMPI_COMM_WORLD_SIZE"])
+        args.gpu = int(os.environ["OMPI_COMM_WORLD_LOCAL_RANK"])
+        args.dist_url = "tcp://%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])
+        os.environ["LOCAL_RANK"], os.environ["RANK"], os.environ["WORLD_SIZE"] = str(args.gpu), str(args.rank), str(args.world_size)
+    elif "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        args.rank = int(os.environ["RANK"])
+        args.world_size = int(os.environ["WORLD_SIZE"])
+        args.gpu = int(os.environ.get("LOCAL_RANK", 0))
+    elif "SLURM_PROCID" in os.environ:
+        args.rank = int(os.environ["SLURM_PROCID"])
+        args.gpu = args.rank % max(torch.cuda.device_count(), 1)
+    else:
+        print("Not using distributed mode")
+        setup_for_distributed(is_master=True)
+        args.distributed = False
+        return
+    args.distributed = True
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(args.gpu)
+    args.dist_backend = "nccl" if use_gpu else "gloo"  # "nccl" IS RCCL on ROCm
+    print("| distributed init (rank {}): {}, gpu {}".format(args.rank, args.dist_url, args.gpu), flush=True)
+    kw = {}
+    if use_gpu:
+        kw["device_id"] = torch.device("cuda", args.gpu)
+    dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size, rank=args.rank, **kw)
+    dist.barrier()
+    setup_for_distributed(args.rank == 0)
+
+
+def all_reduce_mean(x):
+    """misc.py:341-347.  Accepts a float or a 0-d/1-d tensor; tensors stay on the device (no host sync)."""
+    world_size = get_world_size()
+    if world_size == 1:
+        return x
+    if isinstance(x, torch.Tensor):
+        y = x.detach().clone()
+        dist.all_reduce(y)
+        return y / world_size
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(x, device=dev)
+    dist.all_reduce(t)
+    return (t / world_size).item()
+
+
+# --------------------------------------------------------------------------------------------- scaler / grad norm
+def get_grad_norm_(parameters, norm_type=2.0):
+    """Global L2 norm = norm of per-tensor norms (misc.py:280-292).  When the parameters live in an ecamp_amd arena
+    it is one fused sum-of-squares kernel over the flat gradient buffer; otherwise the reference formula."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    parameters = [p for p in parameters if p.grad is not None]
+    if len(parameters) == 0:
+        return torch.tensor(0.0)
+    if float(norm_type) == 2.0:
+        arena = getattr(parameters[0], "_ecamp_arena", None)
+        if arena is not None and all(getattr(p, "_ecamp_arena", None) is arena for p in parameters) and len(parameters) == len(arena.params):
+            from .. import hip_ops as ops
+            s = ops.zeros((1,), arena.device)
+            ops.sumsq(arena.flat_g, s)
+            return s.sqrt().reshape(())
+    device = parameters[0].grad.device
+    if norm_type == inf:
+        return max(p.grad.detach().abs().max().to(device) for p in parameters)
+    return torch.norm(torch.stack([torch.norm(p.grad.detach(), norm_type).to(device) for p in parameters]), norm_type)
+
+
+class NativeScalerWithGradNormCount:
+    """Call signature and return value of misc.py:251-277.  bf16 / f32 training needs no loss scaling, so the scale is
+    identically 1 (`state_dict` keeps the GradScaler keys so reference checkpoints round-trip)."""
+    state_dict_key = "amp_scaler"
+
+    def __init__(self):
+        self._state = {"scale": 1.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+        loss.backward(create_graph=create_graph)
+        if not update_grad:
+            return None
+        reducer = getattr(optimizer, "_ecamp_reducer", None)
+        if reducer is not None:
+            reducer.finalize()  # all gradient buckets reduced before anyone reads them
+        if clip_grad is not None:
+            assert parameters is not None
+            norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
+        else:
+            norm = get_grad_norm_(parameters if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]])
+        optimizer.step()
+        return norm
+
+    def state_dict(self):
+        return dict(self._state)
+
+    def load_state_dict(self, state_dict):
+        self._state.update({k: v for k, v in state_dict.items() if k in self._state})
+
+
+# --------------------------------------------------------------------------------------------- checkpoints
+def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler):
+    """`{model, optimizer, epoch, scaler, args}` -> output_dir/checkpoint-<epoch>.pth on rank 0 (misc.py:295-312)."""
+    path = Path(args.output_dir) / ("checkpoint-%s.pth" % str(epoch))
+    to_save = {"model": model_without_ddp.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch,
+               "scaler": loss_scaler.state_dict() if loss_scaler is not None else {}, "args": args}
+    save_on_master(to_save, path)
+
+
+def load_model(args, model_without_ddp, optimizer, loss_scaler):
+    """Key-intersection load (a plain MAE ViT-B checkpoint initialises the encoder + decoder blocks); optimizer /
+    epoch / scaler are restored only for paths starting with './ECAMP' -- misc.py:315-338."""
+    if not args.resume:
+        return
+    if args.resume.startswith("https"):
+        checkpoint = torch.hub.load_state_dict_from_url(args.resume, map_location="cpu", check_hash=True)
+        model_without_ddp.load_state_dict(checkpoint["model"])
+    else:
+        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
+        own = model_without_ddp.state_dict()
+        own.update({k: v for k, v in checkpoint["model"].items() if k in own and tuple(v.shape) == tuple(own[k].shape)})
+        model_without_ddp.load_state_dict(own)
+    if args.resume.startswith("./ECAMP"):
+        print("Resume checkpoint %s" % args.resume)
+        if "optimizer" in checkpoint and "epoch" in checkpoint and not (hasattr(args, "eval") and args.eval):
+            optimizer.load_state_dict(checkpoint["optimizer"])
+            args.start_epoch = checkpoint["epoch"] + 1
+            if "scaler" in checkpoint:
+                loss_scaler.load_state_dict(checkpoint["scaler"])
+            print("With optim & sched!")

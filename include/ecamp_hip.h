@@ -64,6 +64,7 @@ int ecamp_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
 
 /* ---- elementwise / reductions ---- */
 int ecamp_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, ecampStream_t stream);
+int ecamp_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, ecampStream_t stream);
 int ecamp_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, ecampStream_t stream);
 int ecamp_zero(void* p, int64_t bytes, ecampStream_t stream);
 /* out[n] += alpha * sum over rows m (optionally only rows with lo <= m % period < hi) of X[m*ld+n]: bias grads,
@@ -120,6 +121,15 @@ int ecamp_sumsq(const float* x, int64_t n, float* out, ecampStream_t stream); /*
 int ecamp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int64_t step, float grad_scale,
                 ecampStream_t stream); /* torch.optim.AdamW, main_pretrain.py:254 */
+
+int ecamp_adamw_grouped(float* p, const float* g, float* m, float* v, void* p_bf16, const uint8_t* block_group, int64_t n,
+                        int32_t ngroups, const float* lr_host, const float* wd_host, float beta1, float beta2, float eps,
+                        int64_t step, float grad_scale,
+                        ecampStream_t stream); /* whole-arena AdamW with timm's decay/no-decay groups, main_pretrain.py:253-254 */
+
+/* ---- optional in-process timing (bench.py roofline): HIP-event pairs around every GEMM / attention launch ---- */
+int ecamp_prof_enable(int on);
+int ecamp_prof_collect(int category, double* total_ms, double* total_work, int64_t* count); /* 0 gemm bf16, 1 gemm f32, 2 attention; <0 clears */
 
 #ifdef __cplusplus
 }
