@@ -32,7 +32,8 @@ struct GemmArgs {
     long ldg;
     int act;                // 0 none, 1 exact GELU
     int out_f32;            // C is f32 regardless of operand type
-    int accumulate;         // C += result with f32 atomics (requires out_f32)
+    int accumulate;         // C += result (requires an f32 output); exclusive ownership -> plain read-modify-write
+    float* partial;         // split-K: f32 slabs [gridDim.z][M*ldc-equivalent dense M x N] written with plain stores
     int k_per_split;        // multiple of the K tile; grid.z = number of splits
     int nbm, nbn;
     float alpha;            // result scale applied to the accumulator before the epilogue
@@ -72,14 +73,17 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n0, f32x
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += p[r];
     }
-    if (g.out_f32) {
+    if (g.partial) {  // split-K slab of this z-slice: reduced (and scaled / accumulated) by splitk_reduce_kernel
+        st4<float>(g.partial + ((long)blockIdx.z * g.M + m) * g.N + n0, v);
+    } else if (g.out_f32) {
         float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n0;
-        if (g.accumulate) {
+        if (g.accumulate) {  // each output element is owned by exactly one thread of one block: no atomics needed
+            float o[4];
+            ld4<float>(c, o);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
-        } else {
-            st4<float>(c, v);
+            for (int r = 0; r < 4; ++r) v[r] += o[r];
         }
+        st4<float>(c, v);
     } else {
         st4<T>(reinterpret_cast<T*>(g.C) + (long)m * g.ldc + n0, v);
     }
@@ -317,13 +321,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             epilogue4<float>(g, m0 + wm + tm * 16 + lrow, n0 + wn + tn * 16 + 4 * lk, acc[tm][tn]);
 }
 
+// C[m,n] (+)= alpha * sum_z partial[z][m][n]   -- deterministic split-K combine (no f32 atomics: 16.5 M scattered
+// atomics per weight gradient cost more than the GEMM itself on this chip)
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, long M, long N, long ldc, int splits,
+                                     float alpha, const float* __restrict__ alpha_dev, int accumulate) {
+    const long n4 = M * N / 4;
+    const float al = alpha_dev ? alpha * alpha_dev[0] : alpha;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 acc = reinterpret_cast<const float4*>(partial)[i];
+        for (int z = 1; z < splits; ++z) {
+            float4 p = reinterpret_cast<const float4*>(partial + (long)z * M * N)[i];
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        long e = i * 4, m = e / N, n = e % N;
+        float* c = C + m * ldc + n;
+        float4 o = accumulate ? *reinterpret_cast<float4*>(c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        o.x += al * acc.x; o.y += al * acc.y; o.z += al * acc.z; o.w += al * acc.w;
+        *reinterpret_cast<float4*>(c) = o;
+    }
+}
+
 // =============================================================================================
 // host entry
 // =============================================================================================
 extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda,
                           int b_kc, int64_t ldb, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
                           void* pre_out, int64_t ldp, const void* gmul, int64_t ldg, int act, float alpha, const float* alpha_dev, int dtype,
-                          int out_f32, int accumulate, int split_k, hipStream_t stream) {
+                          int out_f32, int accumulate, int split_k, float* splitk_ws, hipStream_t stream) {
     ECAMP_CHECK_ARG(A && B && C, "ecamp_gemm: null operand");
     ECAMP_CHECK_ARG(M > 0 && N > 0 && K > 0, "ecamp_gemm: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
     ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "ecamp_gemm: bad dtype %d", dtype);
@@ -336,7 +360,8 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     else ECAMP_CHECK_ARG(N % ovec == 0 && ldb % ovec == 0, "ecamp_gemm: N/ldb alignment (B n-contiguous)");
     ECAMP_CHECK_ARG(!accumulate || out_f32 || dtype == ECAMP_F32, "ecamp_gemm: accumulate needs an f32 output");
     if (split_k < 1) split_k = 1;
-    ECAMP_CHECK_ARG(split_k == 1 || accumulate, "ecamp_gemm: split_k > 1 requires accumulate");
+    ECAMP_CHECK_ARG(split_k == 1 || (out_f32 || dtype == ECAMP_F32), "ecamp_gemm: split_k > 1 requires an f32 output");
+    ECAMP_CHECK_ARG(split_k == 1 || splitk_ws, "ecamp_gemm: split_k > 1 requires a workspace of split_k*M*N floats");
     ECAMP_CHECK_ARG(split_k == 1 || (!bias && !residual && !pre_out && !gmul && !act), "ecamp_gemm: split-K has no epilogue");
 
     GemmArgs g;
@@ -352,6 +377,8 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     kps = ((kps + ktile - 1) / ktile) * ktile;
     split_k = (int)((K + kps - 1) / kps);
     g.k_per_split = (int)kps;
+    g.partial = split_k > 1 ? splitk_ws : nullptr;
+    if (split_k > 1) { g.alpha = 1.0f; g.alpha_dev = nullptr; }
     g.nbm = ceil_div(M, BM); g.nbn = ceil_div(N, BN);
     dim3 grid(g.nbm * g.nbn, 1, split_k), block(256);
 #define LAUNCH(KERN)                                                             \
@@ -365,6 +392,13 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     if (prof) ecamp_prof_begin(dtype == ECAMP_BF16 ? ECAMP_PROF_GEMM_BF16 : ECAMP_PROF_GEMM_F32, 2.0 * (double)M * (double)N * (double)K, stream);
     if (dtype == ECAMP_BF16) LAUNCH(gemm_bf16_kernel); else LAUNCH(gemm_f32_kernel);
 #undef LAUNCH
+    if (split_k > 1) {
+        long n4 = M * N / 4;
+        int nb = (int)((n4 + 255) / 256);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, splitk_ws, reinterpret_cast<float*>(C), (long)M, (long)N,
+                           (long)ldc, split_k, alpha, alpha_dev, accumulate);
+    }
     if (prof) ecamp_prof_end(stream);
     ECAMP_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,150 @@
+"""not gpu: host-side logic of the drop-in surface -- state-dict keys, parameter groups, LR schedule, sin-cos table,
+meters, the synthetic dataset schema, the run.sh command line, and the refusal to run without the HIP device."""
+import argparse
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from ecamp_amd import optim
+from ecamp_amd.data import SyntheticContextBertDataset, synthetic_batch
+from ecamp_amd.module import model_ecamp as me
+from ecamp_amd.module.bert_config import BertConfig
+from ecamp_amd.util import lr_sched, misc
+from ecamp_amd.util.pos_embed import get_2d_sincos_pos_embed
+from oracle import ecamp_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    torch.manual_seed(0)
+    return me.ecamp_tiny()
+
+
+def test_state_dict_keys_shapes_and_order_match_the_reference(tiny):
+    ref = orc.param_shapes(orc.cfg_tiny())
+    sd = tiny.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k][0]), k
+    assert not tiny.pos_embed.requires_grad and not tiny.decoder_pos_embed.requires_grad
+    pr = tiny.bert_encoder.model.cls.predictions
+    assert pr.decoder.bias is pr.bias  # one Parameter under two names, as transformers 4.42.4
+    n_train = sum(p.numel() for p in tiny.parameters() if p.requires_grad)
+    n_ref = sum(int(np.prod(ref[k][0])) for k in orc.trainable_names(orc.cfg_tiny()))
+    assert n_train == n_ref
+
+
+def test_base_model_has_the_reference_inventory():
+    ref = orc.param_shapes(orc.cfg_base())
+    assert len(ref) == 350
+    n_train = sum(int(np.prod(ref[k][0])) for k in orc.trainable_names(orc.cfg_base()))
+    assert abs(n_train / 1e6 - 183.17) < 0.4  # 183.17 M trainable (one fewer bias under the 4.42.4 tie)
+
+
+def test_weight_decay_groups_match_reference(tiny):
+    g = np.load(os.path.join(GOLD, "tiny_b4_s128.npz"))
+    groups = optim.add_weight_decay(tiny, 0.05)
+    names = {id(p): n for n, p in tiny.named_parameters()}
+    assert sorted(names[id(p)] for p in groups[0]["params"]) == sorted(g["wd/no_decay"])
+    assert sorted(names[id(p)] for p in groups[1]["params"]) == sorted(g["wd/decay"])
+    assert groups[0]["weight_decay"] == 0.0 and groups[1]["weight_decay"] == 0.05
+    assert "cls_token" in g["wd/decay"] and "mask_token" in g["wd/decay"]  # 3-D tokens ARE decayed
+
+
+def test_lr_schedule_matches_reference_table():
+    g = np.load(os.path.join(GOLD, "tiny_b4_s128.npz"))
+    args = types.SimpleNamespace(lr=1.5e-4, min_lr=0.0, warmup_epochs=40, max_epoch=200)
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}])
+    got = [lr_sched.adjust_learning_rate(opt, float(e), args) for e in g["lr/epochs"]]
+    assert np.allclose(got, g["lr/values"], rtol=1e-14, atol=0)
+    assert opt.param_groups[1]["lr"] == got[-1] * 0.5
+
+
+def test_sincos_table_matches_reference_digest():
+    from oracle.make_golden import digest
+    g = np.load(os.path.join(GOLD, "base_b2_s128.npz"))
+    for dim, key in ((768, "pos_embed"), (512, "decoder_pos_embed")):
+        t = torch.from_numpy(get_2d_sincos_pos_embed(dim, 14, cls_token=True)).float().unsqueeze(0)
+        nm, s = digest(t)
+        assert np.abs(s - g["tab/%s/s" % key]).max() < 1e-7 and abs(nm[0] - g["tab/%s/nm" % key][0]) < 1e-4
+
+
+def test_init_distributions_follow_the_reference(tiny):
+    # xavier_uniform on every nn.Linear incl. BERT's and the 30000-way decoder (model_ecamp.py:124-135)
+    w = tiny.bert_encoder.model.cls.predictions.decoder.weight
+    bound = (6.0 / (w.shape[0] + w.shape[1])) ** 0.5
+    assert w.abs().max().item() <= bound * 1.0001 and w.abs().max().item() > 0.9 * bound
+    assert (tiny.norm.weight == 1).all() and (tiny.norm.bias == 0).all()
+    emb = tiny.bert_encoder.model.bert.embeddings.word_embeddings.weight
+    assert (emb[0] == 0).all() and abs(emb[1:].std().item() - 0.02) < 2e-3  # HF init, PAD row zero
+    assert abs(tiny.cls_token.std().item() - 0.02) < 0.01
+
+
+def test_no_cpu_fallback(tiny):
+    from ecamp_amd._lib import EcampHipError
+    with pytest.raises(EcampHipError):
+        tiny(synthetic_batch(1, 32, 448))
+    from ecamp_amd import hip_ops
+    with pytest.raises(EcampHipError):
+        hip_ops.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 1e-6)
+
+
+def test_old_fusion_layer_key_alias(tiny):
+    sd = {k.replace("context_fusion_layer", "cross_attn_layer"): v.clone() for k, v in tiny.state_dict().items()}
+    m2 = me.ecamp_tiny()
+    m2.load_state_dict(sd, strict=True)
+    assert torch.equal(m2.bert_encoder.model.bert.context_fusion_layer.gap_mlp.weight, tiny.bert_encoder.model.bert.context_fusion_layer.gap_mlp.weight)
+
+
+def test_bad_configs_are_rejected():
+    with pytest.raises(ValueError):
+        me.ECAMP(embed_dim=100, num_heads=3)
+    with pytest.raises(ValueError):
+        BertConfig(hidden_act="relu")
+    with pytest.raises(ValueError):
+        me.ECAMP(compute_dtype=torch.float16)
+
+
+def test_synthetic_dataset_schema():
+    b = synthetic_batch(3, 64, 448, seed=1)
+    assert b["image"].shape == (3, 3, 448, 448) and b["image"].dtype == torch.float32
+    for k in ("ids", "labels", "attention_mask", "type_ids"):
+        assert b[k].shape == (3, 64) and b[k].dtype == torch.int64
+    assert (b["labels"][:, 0] == 2).all() and (b["ids"][b["ids"] != b["labels"]] == 3).all()
+    assert ((b["labels"] == 0) == (b["attention_mask"] == 0)).all()
+    assert b["weights"].shape == (3, 64) and b["column"].shape == (3,) and int(b["column"].max()) <= 2
+    ds = SyntheticContextBertDataset(length=4, max_caption_length=32)
+    one = ds.collate_fn([ds[0]])
+    assert one["ids"].shape == (1, 32)  # no .squeeze() bug at B == 1 (pretrain_datasets.py:218-225)
+
+
+def test_meters_accept_tensors_lazily():
+    ml = misc.MetricLogger(delimiter="  ")
+    for i in range(5):
+        ml.update(loss=torch.tensor(float(i)), lr=0.1)
+    assert ml.loss.global_avg == pytest.approx(2.0) and ml.lr.value == 0.1 and ml.loss.median == pytest.approx(2.0)
+    out = list(ml.log_every(range(3), 2, "hdr"))
+    assert out == [0, 1, 2]
+
+
+def test_run_sh_command_line_parses():
+    from ecamp_amd.main_pretrain import get_args_parser
+    argv = "--num_workers 16 --accum_iter 8 --batch_size 256 --model ecamp --norm_pix_loss --mask_ratio 0.75 --epochs 120 " \
+           "--warmup_epochs 40 --lr 1.5e-4 --weight_decay 0.05 --resume ./dataset/mae_vit_base.pth --data_path ./dataset/ " \
+           "--output_dir ../output/ --description x".split()
+    a = argparse.ArgumentParser(parents=[get_args_parser()]).parse_args(argv)
+    assert a.accum_iter == 8 and a.batch_size == 256 and a.lr == 1.5e-4 and a.max_epoch == 200 and a.norm_pix_loss
+    assert "ecamp" in me.__dict__ and callable(me.__dict__[a.model])
+
+
+def test_grad_norm_reference_formula_on_cpu_tensors():
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    n = misc.get_grad_norm_(ps)
+    assert n.item() == pytest.approx(torch.cat([p.grad.flatten() for p in ps]).norm().item(), rel=1e-6)
