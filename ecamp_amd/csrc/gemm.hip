@@ -117,41 +117,51 @@ __device__ __forceinline__ void r2s_kc(unsigned char* lds, int tid, const uint4 
         *reinterpret_cast<uint4*>(lds + row * 128 + ((kc ^ swz(row)) << 4)) = r[i];
     }
 }
-// global -> registers, output-contiguous operand P[k*ld + row]: thread owns an 8(k) x 4(row) micro-block
+// Output-contiguous operand P[k*ld + row] (weights in dgrad, both activations in wgrad): the tile is kept in LDS exactly
+// as it lies in HBM -- 64 contraction rows x 128 outputs, 16-B loads / ds_write_b128, no register transposes -- and the
+// MFMA fragments (8 consecutive k for one output) come from the gfx950 LDS transpose read ds_read_b64_tr_b16:
+// in a 16-lane group, lane i = 4r+q points at row r, columns 4q..4q+3 of a 4x16 block and RECEIVES column i of it
+// (semantics probed on hardware: tools/probes/tr16_probe.hip).  Row pitch 288 B keeps the 4 rows of a block on
+// disjoint banks.
+#define OC_PITCH 288
+typedef __attribute__((ext_vector_type(4))) short v4s16;
+
 __device__ __forceinline__ void g2r_oc(const bf16_t* P, long ld, int row0, int nrows, int k0, int kend, int tid,
-                                       uint2 (&r)[8]) {
-    int og = tid & 31, kg = tid >> 5;
-    int gr = row0 + og * 4;
+                                       uint4 (&r)[4]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        int gk = k0 + kg * 8 + j;
-        r[j] = (gr < nrows && gk < kend) ? *reinterpret_cast<const uint2*>(P + (long)gk * ld + gr) : make_uint2(0, 0);
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + 256 * i;
+        int kr = c >> 4, ch = c & 15;
+        int gk = k0 + kr, gr = row0 + ch * 8;
+        r[i] = (gr < nrows && gk < kend) ? *reinterpret_cast<const uint4*>(P + (long)gk * ld + gr) : make_uint4(0, 0, 0, 0);
     }
 }
-__device__ __forceinline__ void r2s_oc(unsigned char* lds, int tid, const uint2 (&r)[8]) {
-    int og = tid & 31, kg = tid >> 5;
-    // 8x4 -> 4x8 transpose of 16-bit elements in registers, then one 16-B store per output row
-    uint4 o0, o1, o2, o3;
-#define LO(a, b) (((a) & 0xffffu) | ((b) << 16))
-#define HI(a, b) (((a) >> 16) | ((b) & 0xffff0000u))
-    o0 = make_uint4(LO(r[0].x, r[1].x), LO(r[2].x, r[3].x), LO(r[4].x, r[5].x), LO(r[6].x, r[7].x));
-    o1 = make_uint4(HI(r[0].x, r[1].x), HI(r[2].x, r[3].x), HI(r[4].x, r[5].x), HI(r[6].x, r[7].x));
-    o2 = make_uint4(LO(r[0].y, r[1].y), LO(r[2].y, r[3].y), LO(r[4].y, r[5].y), LO(r[6].y, r[7].y));
-    o3 = make_uint4(HI(r[0].y, r[1].y), HI(r[2].y, r[3].y), HI(r[4].y, r[5].y), HI(r[6].y, r[7].y));
-#undef LO
-#undef HI
-    int row = og * 4;
-    *reinterpret_cast<uint4*>(lds + (row + 0) * 128 + ((kg ^ swz(row + 0)) << 4)) = o0;
-    *reinterpret_cast<uint4*>(lds + (row + 1) * 128 + ((kg ^ swz(row + 1)) << 4)) = o1;
-    *reinterpret_cast<uint4*>(lds + (row + 2) * 128 + ((kg ^ swz(row + 2)) << 4)) = o2;
-    *reinterpret_cast<uint4*>(lds + (row + 3) * 128 + ((kg ^ swz(row + 3)) << 4)) = o3;
+__device__ __forceinline__ void r2s_oc(unsigned char* lds, int tid, const uint4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + 256 * i;
+        int kr = c >> 4, ch = c & 15;
+        *reinterpret_cast<uint4*>(lds + kr * OC_PITCH + ch * 16) = r[i];
+    }
+}
+// fragment of 16 outputs [o0, o0+16) x 8 contraction steps starting at kb + 8*(lane>>4)
+__device__ __forceinline__ bf16x8 frag_oc(const unsigned char* lds, int o0, int kb, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned char* p = lds + (kb + g * 8 + (i >> 2)) * OC_PITCH + (o0 + (i & 3) * 4) * 2;
+    v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p));
+    v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p + 4 * OC_PITCH));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 frag_kc(const unsigned char* lds, int row, int ch) {
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((ch ^ swz(row)) << 4));
 }
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * BK * 2];
+    constexpr int TILE_BYTES = 64 * OC_PITCH;  // >= BM*BK*2: one size fits both operand layouts
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
     unsigned char* ldsA = lds;
-    unsigned char* ldsB = lds + BM * BK * 2;
+    unsigned char* ldsB = lds + TILE_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, g.nbm * g.nbn);
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra_kc[4], rb_kc[4];
-    uint2 ra_oc[8], rb_oc[8];
+    uint4 ra_oc[4], rb_oc[4];
 
     if (A_KC) g2r_kc(A, g.lda, m0, g.M, kbeg, kend, tid, ra_kc); else g2r_oc(A, g.lda, m0, g.M, kbeg, kend, tid, ra_oc);
     if (B_KC) g2r_kc(B, g.ldb, n0, g.N, kbeg, kend, tid, rb_kc); else g2r_oc(B, g.ldb, n0, g.N, kbeg, kend, tid, rb_oc);
@@ -190,10 +200,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
             bf16x8 fm[4], fn[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                int rm = wm + t * 16 + lrow, rn = wn + t * 16 + lrow;
-                int ch = kk * 4 + lk;
-                fm[t] = *reinterpret_cast<const bf16x8*>(ldsA + rm * 128 + ((ch ^ swz(rm)) << 4));
-                fn[t] = *reinterpret_cast<const bf16x8*>(ldsB + rn * 128 + ((ch ^ swz(rn)) << 4));
+                fm[t] = A_KC ? frag_kc(ldsA, wm + t * 16 + lrow, kk * 4 + lk) : frag_oc(ldsA, wm + t * 16, kk * 32, lane);
+                fn[t] = B_KC ? frag_kc(ldsB, wn + t * 16 + lrow, kk * 4 + lk) : frag_oc(ldsB, wn + t * 16, kk * 32, lane);
             }
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm)
@@ -352,7 +360,7 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     ECAMP_CHECK_ARG(M > 0 && N > 0 && K > 0, "ecamp_gemm: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
     ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "ecamp_gemm: bad dtype %d", dtype);
     const int vec = dtype == ECAMP_BF16 ? 8 : 4;   // elements per 16-B global access
-    const int ovec = dtype == ECAMP_BF16 ? 4 : 4;  // output-contiguous operands are read 4 rows at a time
+    const int ovec = dtype == ECAMP_BF16 ? 8 : 4;  // output-contiguous operands are read 16 B at a time
     ECAMP_CHECK_ARG(N % 4 == 0, "ecamp_gemm: N=%ld must be a multiple of 4", (long)N);
     if (a_kc) ECAMP_CHECK_ARG(K % vec == 0 && lda % vec == 0, "ecamp_gemm: K/lda alignment (A k-contiguous)");
     else ECAMP_CHECK_ARG(M % ovec == 0 && lda % ovec == 0, "ecamp_gemm: M/lda alignment (A m-contiguous), M=%ld", (long)M);

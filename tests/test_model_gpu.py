@@ -163,13 +163,14 @@ def test_train_mode_dropout_and_determinism(dev):
     b = [t.item() for t in model(batch, noise=noise)]
     model._rng_ctr = 0
     c = [t.item() for t in model(batch, noise=noise)]
-    assert a == pytest.approx(c, rel=1e-5) and abs(a[2] - b[2]) / a[2] > 1e-5
+    assert np.allclose(a, c, rtol=1e-5) and abs(a[2] - b[2]) / a[2] > 1e-5
     assert a[0] == pytest.approx(float(g["losses"][0]), rel=1e-4)  # no dropout on the image side
     assert abs(a[2] - float(g["losses"][2])) / float(g["losses"][2]) < 0.05
     loss = sum(model(batch, noise=noise))
     loss.backward()
     for n, p in model.named_parameters():
-        assert torch.isfinite(p.grad).all(), n
+        if p.requires_grad:
+            assert torch.isfinite(p.grad).all(), n
 
 
 def test_cls_alias_and_own_masking_noise(dev):
