@@ -13,21 +13,8 @@
 // All contractions use v_mfma_f32_16x16x4_f32 (exact f32), so one kernel serves the f32 parity mode and
 // the bf16 mode (operands widened on load).  lse = max + log(sum) is saved for the backward pass, which
 // recomputes P (no [T,T] tensor is ever written) and regenerates the dropout mask from Philox counters.
-#include "common.h"
+#include "attention.h"
 
-struct AttnArgs {
-    const void* q; const void* k; const void* v; void* o;
-    const void* dout; void* dq; void* dk; void* dv;
-    float* lse; float* delta;
-    const int32_t* key_mask;  // [B, Tk], nonzero = attend; or null
-    long q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh;
-    long dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh, do_sb, do_st, do_sh;
-    int B, H, Tq, Tk;
-    float scale, drop_p;
-    uint64_t seed, offset;
-};
-
-#define NEG_BIG (-1.0e30f)
 
 // stage rows [r0, r0+64) x [0,HD) of a (b,h) slice into LDS as f32 with the given pitch (zeros past nrows)
 template <typename T, int HD, int PITCH>
@@ -373,9 +360,11 @@ static int attn_check(const AttnArgs& a, int hd, int dtype, bool bwd) {
     ECAMP_CHECK_ARG(a.Tk >= 1 && a.Tk <= 256 && a.Tq >= 1, "attention: Tk=%d must be in [1,256] (tiled long-sequence path not built yet)", a.Tk);
     ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "attention: bad dtype");
     ECAMP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f, "attention: bad dropout p");
-    const long m = 4;
+    const long m = dtype == ECAMP_BF16 ? 8 : 4;
+    if (dtype == ECAMP_BF16) ECAMP_CHECK_ARG(a.q_st % m == 0 && a.q_sb % m == 0 && a.q_sh % m == 0 && a.o_st % 4 == 0 && a.o_sb % 4 == 0 && a.o_sh % 4 == 0,
+                                             "attention(bf16): q strides must be multiples of 8, o strides of 4 elements");
     ECAMP_CHECK_ARG(a.k_st % m == 0 && a.k_sb % m == 0 && a.k_sh % m == 0 && a.v_st % m == 0 && a.v_sb % m == 0 && a.v_sh % m == 0,
-                    "attention: k/v strides must be multiples of 4 elements");
+                    "attention: k/v strides must be multiples of 4 (f32) / 8 (bf16) elements");
     if (bwd) ECAMP_CHECK_ARG(a.q_st % m == 0 && a.q_sb % m == 0 && a.q_sh % m == 0 && a.do_st % m == 0 && a.do_sb % m == 0 && a.do_sh % m == 0,
                              "attention: q/dO strides must be multiples of 4 elements");
     return 0;
@@ -435,7 +424,7 @@ extern "C" int ecamp_attn_fwd(const void* q, const void* k, const void* v, void*
         else if (hd == 64) fwd_dispatch<T_, 64>(a, stream);    \
         else fwd_dispatch<T_, 128>(a, stream);                 \
     } while (0)
-    if (dtype == ECAMP_F32) D(float); else D(bf16_t);
+    if (dtype == ECAMP_F32) D(float); else attn_bf16_fwd(a, hd, stream);
 #undef D
     if (prof) ecamp_prof_end(stream);
     ECAMP_LAUNCH_CHECK();
@@ -471,7 +460,7 @@ extern "C" int ecamp_attn_bwd(const void* q, const void* k, const void* v, const
         else if (hd == 64) bwd_dispatch<T_, 64>(a, stream);    \
         else bwd_dispatch<T_, 128>(a, stream);                 \
     } while (0)
-    if (dtype == ECAMP_F32) D(float); else D(bf16_t);
+    if (dtype == ECAMP_F32) D(float); else attn_bf16_bwd(a, hd, stream);
 #undef D
     if (prof) ecamp_prof_end(stream);
     ECAMP_LAUNCH_CHECK();

@@ -1,0 +1,373 @@
+// bf16 attention on v_mfma_f32_16x16x32_bf16 -- the production path; the exact-f32 variant
+// in attention.hip stays as the parity-mode path.
+//
+// One workgroup = 4 waves = 64 query rows (fwd, dQ) or 64 keys (dK/dV) of one (batch, head).  K/V/Q/dO chunks of 64 rows
+// are staged ONCE per workgroup into LDS exactly as they lie in HBM (row-major, 16-B copies, pitch hd*2+32 B) and feed the
+// matrix cores two ways from the same image:
+//   frag_rows : ds_read_b128 -> 8 consecutive head-dim elements of one row        (contraction over head_dim:  Q K^T, dO V^T)
+//   frag_tr   : ds_read_b64_tr_b16 x2 -> 8 consecutive ROWS of one head-dim column (contraction over tokens: P V, dS K, P^T dO, dS^T Q)
+// so no [B,H,T,hd] permute, no K^T / V^T copy and no score matrix ever touches HBM.  MFMA operands are ordered so that each
+// lane owns 4 consecutive elements of the OUTPUT's contiguous axis: probabilities are written to the per-wave LDS tile with
+// 8-B stores and row reductions need 2 wave shuffles (xor 16, 32) instead of 4.
+// Softmax / lse / delta / dropout (Philox, regenerated in backward) are f32 in registers; P and dS are rounded to bf16 only as
+// MFMA operands, like the reference's autocast attention.
+#include "attention.h"
+
+typedef __attribute__((ext_vector_type(4))) short v4s16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0)
+
+template <int HD> struct TileCfg { static constexpr int PB = HD * 2 + 32; static constexpr int BYTES = 64 * PB; };
+
+// rows [r0, r0+64) x HD of a (b,h) slice -> LDS (zeros past nrows)
+template <int HD>
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* base, long st, int r0, int nrows, int tid) {
+    constexpr int CPR = HD / 8, PB = TileCfg<HD>::PB;
+#pragma unroll
+    for (int i = 0; i < (64 * CPR) / 256; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx / CPR, ch = idx % CPR;
+        uint4 v = (r0 + row < nrows) ? *reinterpret_cast<const uint4*>(base + (long)(r0 + row) * st + ch * 8) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(lds + row * PB + ch * 16) = v;
+    }
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* lds, int row, int kchunk) {
+    return *reinterpret_cast<const bf16x8*>(lds + row * TileCfg<HD>::PB + kchunk * 16);
+}
+// 16 head-dim columns [o0, o0+16) x 8 consecutive rows starting at kb + 8*(lane>>4)
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* lds, int o0, int kb, int lane) {
+    constexpr int PB = TileCfg<HD>::PB;
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned char* p = lds + (kb + g * 8 + (i >> 2)) * PB + (o0 + (i & 3) * 4) * 2;
+    v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p));
+    v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p + 4 * PB));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// A/B fragments straight from global memory for the 16 rows a wave owns (row = r0 + lane&15, 8 elems at ks*32 + 8*(lane>>4))
+template <int HD>
+__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[HD / 32], const bf16_t* base, long st, int r0, int nrows, int lane) {
+    const int row = r0 + (lane & 15);
+    const bf16_t* p = base + (long)row * st + (lane >> 4) * 8;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+        uint4 v = row < nrows ? *reinterpret_cast<const uint4*>(p + ks * 32) : make_uint4(0, 0, 0, 0);
+        f[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+// per-wave 16 x 64 bf16 tile (P or dS), 128-B rows, 16-B chunks XOR-swizzled by row
+__device__ __forceinline__ void ptile_write4(unsigned char* t, int row, int col0, const float (&v)[4]) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    int chunk = col0 >> 3;
+    *reinterpret_cast<uint2*>(t + row * 128 + ((chunk ^ (row & 7)) << 4) + (col0 & 7) * 2) = u;
+}
+__device__ __forceinline__ bf16x8 ptile_frag(const unsigned char* t, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(t + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ float red4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float red4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v, float mul) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v[0] * mul) | ((uint32_t)f2bf(v[1] * mul) << 16);
+    u.y = (uint32_t)f2bf(v[2] * mul) | ((uint32_t)f2bf(v[3] * mul) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+// =============================================================================================
+template <int HD, int KCH>
+__global__ __launch_bounds__(256) void attn16_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* KV = smem;                         // 64-row K (then V) chunk
+    unsigned char* PT = smem + TileCfg<HD>::BYTES;    // 4 per-wave P tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const long bh = (long)b * a.H + h;
+    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
+    bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_sb + h * a.o_sh;
+
+    bf16x8 qf[HD / 32];
+    load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
+
+    f32x4 s[KCH * 4];  // s[c*4+jt][r] = S[i = q0+li][j = c*64 + jt*16 + 4g + r]
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        __syncthreads();
+        stage_tile<HD>(KV, kb, a.k_st, c * 64, a.Tk, tid);
+        __syncthreads();
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) acc = MFMA(frag_rows<HD>(KV, jt * 16 + li, ks * 4 + g), qf[ks], acc);
+            s[c * 4 + jt] = acc;
+        }
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int t = 0; t < KCH * 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int j = t * 16 + 4 * g + r;
+            bool ok = j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
+            s[t][r] = ok ? s[t][r] * a.scale : NEG_BIG;
+            mx = fmaxf(mx, s[t][r]);
+        }
+    mx = red4_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < KCH * 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float p = s[t][r] > 0.5f * NEG_BIG ? __expf(s[t][r] - mx) : 0.f;
+            s[t][r] = p;
+            sum += p;
+        }
+    sum = red4_sum(sum);
+    const int qi = q0 + li;
+    if (g == 0 && qi < a.Tq) a.lse[bh * a.Tq + qi] = mx + __logf(sum);
+    const float inv = 1.0f / sum;
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+
+    f32x4 o[HD / 16];  // o[dt][r] = O[i = q0+li][d = dt*16 + 4g + r]
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned char* pt = PT + wave * 2048;
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        __syncthreads();
+        stage_tile<HD>(KV, vb, a.v_st, c * 64, a.Tk, tid);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = s[c * 4 + jt][r] * inv;
+                if (a.drop_p > 0.f) {
+                    uint64_t e = ((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk + (c * 64 + jt * 16 + 4 * g + r);
+                    p[r] *= dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
+                }
+            }
+            ptile_write4(pt, li, jt * 16 + 4 * g, p);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 pf = ptile_frag(pt, li, kk * 4 + g);
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) o[dt] = MFMA(frag_tr<HD>(KV, dt * 16, kk * 32, lane), pf, o[dt]);
+        }
+    }
+    if (qi < a.Tq) {
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) store4(ob + (long)qi * a.o_st + dt * 16 + 4 * g, o[dt], 1.0f);
+    }
+}
+
+// =============================================================================================
+// dQ (+ delta).  D layouts: S/dP [j = 4g+r][i = li]; dQ [d = 4g+r][i = li]
+template <int HD, int KCH>
+__global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* KT = smem;
+    unsigned char* VT = smem + TileCfg<HD>::BYTES;
+    unsigned char* ST = smem + 2 * TileCfg<HD>::BYTES;  // 4 per-wave dS tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const long bh = (long)b * a.H + h;
+    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
+    const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_sb + h * a.o_sh;
+    const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_sb + h * a.do_sh;
+    bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_sb + h * a.dq_sh;
+
+    bf16x8 qf[HD / 32], gf[HD / 32], of[HD / 32];
+    load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
+    load_row_frags<HD>(gf, gb, a.do_st, q0, a.Tq, lane);
+    load_row_frags<HD>(of, ob, a.o_st, q0, a.Tq, lane);
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)gf[ks][e]) * bf2f((bf16_t)of[ks][e]);
+    dl = red4_sum(dl);
+    const int qi = q0 + li;
+    const bool qok = qi < a.Tq;
+    if (g == 0 && qok) a.delta[bh * a.Tq + qi] = dl;
+    const float lse = qok ? a.lse[bh * a.Tq + qi] : 0.f;
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+
+    f32x4 dq[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned char* st = ST + wave * 2048;
+#pragma unroll 1
+    for (int c = 0; c < KCH; ++c) {
+        __syncthreads();
+        stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
+        stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
+        __syncthreads();
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                s = MFMA(frag_rows<HD>(KT, jt * 16 + li, ks * 4 + g), qf[ks], s);
+                dp = MFMA(frag_rows<HD>(VT, jt * 16 + li, ks * 4 + g), gf[ks], dp);
+            }
+            float ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int j = c * 64 + jt * 16 + 4 * g + r;
+                bool ok = qok && j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
+                float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+                float gg = dp[r];
+                if (a.drop_p > 0.f) {
+                    uint64_t e = ((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk + j;
+                    gg *= dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
+                }
+                ds[r] = p * (gg - dl);
+            }
+            ptile_write4(st, li, jt * 16 + 4 * g, ds);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 sf = ptile_frag(st, li, kk * 4 + g);
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = MFMA(frag_tr<HD>(KT, dt * 16, kk * 32, lane), sf, dq[dt]);
+        }
+    }
+    if (qok) {
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) store4(dqb + (long)qi * a.dq_st + dt * 16 + 4 * g, dq[dt], a.scale);
+    }
+}
+
+// =============================================================================================
+// dK, dV.  D layouts: S/dP [i = 4g+r][j = li]; dK/dV [d = 4g+r][j = li]
+template <int HD>
+__global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* QT = smem;
+    unsigned char* GT = smem + TileCfg<HD>::BYTES;
+    unsigned char* PT = smem + 2 * TileCfg<HD>::BYTES;  // 4 per-wave P_dropped^T tiles [j][i]
+    unsigned char* ST = PT + 4 * 2048;                  // 4 per-wave dS^T tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int j0 = blockIdx.x * 64 + wave * 16;
+    const long bh = (long)b * a.H + h;
+    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
+    const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_sb + h * a.do_sh;
+    bf16_t* dkb = reinterpret_cast<bf16_t*>(a.dk) + b * a.dk_sb + h * a.dk_sh;
+    bf16_t* dvb = reinterpret_cast<bf16_t*>(a.dv) + b * a.dv_sb + h * a.dv_sh;
+
+    bf16x8 kf[HD / 32], vf[HD / 32];
+    load_row_frags<HD>(kf, kb, a.k_st, j0, a.Tk, lane);
+    load_row_frags<HD>(vf, vb, a.v_st, j0, a.Tk, lane);
+    const int kj = j0 + li;
+    const bool jok = kj < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + kj] != 0);
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    f32x4 dk[HD / 16], dv[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned char* pt = PT + wave * 2048;
+    unsigned char* st = ST + wave * 2048;
+    const int nqc = (a.Tq + 63) / 64;
+#pragma unroll 1
+    for (int c = 0; c < nqc; ++c) {
+        __syncthreads();
+        stage_tile<HD>(QT, qb, a.q_st, c * 64, a.Tq, tid);
+        stage_tile<HD>(GT, gb, a.do_st, c * 64, a.Tq, tid);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                s = MFMA(frag_rows<HD>(QT, it * 16 + li, ks * 4 + g), kf[ks], s);
+                dp = MFMA(frag_rows<HD>(GT, it * 16 + li, ks * 4 + g), vf[ks], dp);
+            }
+            float pd[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int i = c * 64 + it * 16 + 4 * g + r;
+                bool ok = jok && i < a.Tq;
+                float lse = ok ? a.lse[bh * a.Tq + i] : 0.f;
+                float dl = ok ? a.delta[bh * a.Tq + i] : 0.f;
+                float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+                float m = 1.0f;
+                if (a.drop_p > 0.f) {
+                    uint64_t e = ((uint64_t)bh * a.Tq + i) * (uint64_t)a.Tk + kj;
+                    m = dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
+                }
+                pd[r] = p * m;
+                ds[r] = p * (dp[r] * m - dl);
+            }
+            ptile_write4(pt, li, it * 16 + 4 * g, pd);
+            ptile_write4(st, li, it * 16 + 4 * g, ds);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 pf = ptile_frag(pt, li, kk * 4 + g), sf = ptile_frag(st, li, kk * 4 + g);
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) {
+                dv[dt] = MFMA(frag_tr<HD>(GT, dt * 16, kk * 32, lane), pf, dv[dt]);
+                dk[dt] = MFMA(frag_tr<HD>(QT, dt * 16, kk * 32, lane), sf, dk[dt]);
+            }
+        }
+    }
+    if (kj < a.Tk) {
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+            store4(dkb + (long)kj * a.dk_st + dt * 16 + 4 * g, dk[dt], a.scale);
+            store4(dvb + (long)kj * a.dv_st + dt * 16 + 4 * g, dv[dt], 1.0f);
+        }
+    }
+}
+
+// =============================================================================================
+template <int HD>
+static void fwd16(const AttnArgs& a, hipStream_t st) {
+    dim3 grid(ceil_div(a.Tq, 64), a.B * a.H), block(256);
+    size_t shm = TileCfg<HD>::BYTES + 4 * 2048;
+    if (a.Tk <= 64) hipLaunchKernelGGL((attn16_fwd_kernel<HD, 1>), grid, block, shm, st, a);
+    else if (a.Tk <= 128) hipLaunchKernelGGL((attn16_fwd_kernel<HD, 2>), grid, block, shm, st, a);
+    else hipLaunchKernelGGL((attn16_fwd_kernel<HD, 4>), grid, block, shm, st, a);
+}
+template <int HD>
+static void bwd16(const AttnArgs& a, hipStream_t st) {
+    dim3 grid(ceil_div(a.Tq, 64), a.B * a.H), block(256);
+    size_t shm = 2 * TileCfg<HD>::BYTES + 4 * 2048;
+    if (a.Tk <= 64) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 1>), grid, block, shm, st, a);
+    else if (a.Tk <= 128) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 2>), grid, block, shm, st, a);
+    else hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 4>), grid, block, shm, st, a);
+    dim3 grid2(ceil_div(a.Tk, 64), a.B * a.H);
+    size_t shm2 = 2 * TileCfg<HD>::BYTES + 8 * 2048;
+    hipLaunchKernelGGL((attn16_bwd_dkv_kernel<HD>), grid2, block, shm2, st, a);
+}
+void attn_bf16_fwd(const AttnArgs& a, int hd, hipStream_t st) {
+    if (hd == 32) fwd16<32>(a, st); else if (hd == 64) fwd16<64>(a, st); else fwd16<128>(a, st);
+}
+void attn_bf16_bwd(const AttnArgs& a, int hd, hipStream_t st) {
+    if (hd == 32) bwd16<32>(a, st); else if (hd == 64) bwd16<64>(a, st); else bwd16<128>(a, st);
+}
