@@ -395,110 +395,97 @@ __device__ __forceinline__ void up2_taps(int Y, int H, int& y0, int& y1, float& 
     w0 = 1.0f - w1;
 }
 
-template <typename T>
-__global__ void sr_up_kernel(const float* __restrict__ pred_img, T* __restrict__ u, long planes, int R) {
+// ---- fused, LDS-resident SR head -------------------------------------------------------------------------
+// One workgroup walks 32x32 high-resolution tiles (= one super-patch each, so a tile is wholly inside or outside the
+// loss window).  u, c1 (and in backward ds, dc1, du) live only in LDS: the forward reads pred_img + big once and
+// writes one float; the backward re-derives everything from pred_img (cheap ALU) and writes only d/d pred_img.
+// Zero padding of both convs is applied at the IMAGE border (values outside the image are 0, not conv outputs).
+#define SRT 32
+
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ pl, int Y, int X, int R) {
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    up2_taps(Y, R, y0, y1, wy0, wy1);
+    up2_taps(X, R, x0, x1, wx0, wx1);
+    return wy0 * (wx0 * pl[y0 * R + x0] + wx1 * pl[y0 * R + x1]) + wy1 * (wx0 * pl[y1 * R + x0] + wx1 * pl[y1 * R + x1]);
+}
+// U[c][y][x] for the tile at (Y0, X0) extended by HALO; 0 outside the image
+template <int HALO>
+__device__ __forceinline__ void sr_fill_u(float* U, const float* __restrict__ pred_img, long b, int Y0, int X0, int R) {
+    constexpr int E = SRT + 2 * HALO;
     const int R2 = 2 * R;
-    long n = planes * R2 * R2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int X = (int)(i % R2), Y = (int)((i / R2) % R2);
-        long pl = i / ((long)R2 * R2);
-        int y0, y1, x0, x1;
-        float wy0, wy1, wx0, wx1;
-        up2_taps(Y, R, y0, y1, wy0, wy1);
-        up2_taps(X, R, x0, x1, wx0, wx1);
-        const float* p = pred_img + pl * (long)R * R;
-        float v = wy0 * (wx0 * p[y0 * R + x0] + wx1 * p[y0 * R + x1]) + wy1 * (wx0 * p[y1 * R + x0] + wx1 * p[y1 * R + x1]);
-        u[i] = from_f<T>(v);
+    for (int idx = threadIdx.x; idx < 3 * E * E; idx += 256) {
+        int c = idx / (E * E), y = (idx / E) % E, x = idx % E;
+        int Y = Y0 - HALO + y, X = X0 - HALO + x;
+        U[idx] = (Y < 0 || Y >= R2 || X < 0 || X >= R2) ? 0.f : bilinear_at(pred_img + (b * 3 + c) * (long)R * R, Y, X, R);
+    }
+}
+// dst (edge ED, halo HD) = relu?(bias + conv3x3(src (edge ES = ED+2))) ; 0 outside the image
+template <int ED, int HD, bool RELU>
+__device__ __forceinline__ void sr_conv_stage(float* dst, const float* src, const float* w, const float* bias, int Y0, int X0, int R2) {
+    constexpr int ES = ED + 2;
+    for (int idx = threadIdx.x; idx < ED * ED; idx += 256) {
+        int y = idx / ED, x = idx % ED;
+        int Y = Y0 - HD + y, X = X0 - HD + x;
+        float acc[3] = {bias[0], bias[1], bias[2]};
+        const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+        if (in) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float v = src[(i * ES + y + ky) * ES + x + kx];
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) acc[o] += w[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
+                    }
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) dst[(o * ED + y) * ED + x] = in ? (RELU ? fmaxf(acc[o], 0.f) : acc[o]) : 0.f;
     }
 }
 
-// out[b,o,Y,X] = (relu?)( bias[o] + sum_{i,ky,kx} w[o,i,ky,kx] * in[b,i,Y+ky-1,X+kx-1] )
-template <typename T>
-__device__ __forceinline__ void conv3_at(const T* __restrict__ in, long b, int Y, int X, int R2, const float* w, float (&acc)[3]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const T* pl = in + (b * 3 + i) * (long)R2 * R2;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            int yy = Y + ky - 1;
-            if (yy < 0 || yy >= R2) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                int xx = X + kx - 1;
-                if (xx < 0 || xx >= R2) continue;
-                float v = to_f<T>(pl[(long)yy * R2 + xx]);
-#pragma unroll
-                for (int o = 0; o < 3; ++o) acc[o] += w[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
-            }
-        }
-    }
-}
-// transposed conv: out[b,i,Y,X] = sum_{o,ky,kx} w[o,i,ky,kx] * g[b,o,Y-ky+1,X-kx+1]
-template <typename T>
-__device__ __forceinline__ void conv3t_at(const T* __restrict__ g, long b, int Y, int X, int R2, const float* w, float (&acc)[3]) {
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const T* pl = g + (b * 3 + o) * (long)R2 * R2;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            int yy = Y - ky + 1;
-            if (yy < 0 || yy >= R2) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                int xx = X - kx + 1;
-                if (xx < 0 || xx >= R2) continue;
-                float v = to_f<T>(pl[(long)yy * R2 + xx]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc[i] += w[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
-            }
-        }
-    }
-}
-
-template <typename T>
-__global__ void sr_conv1_kernel(const T* __restrict__ u, T* __restrict__ c1, SrP P, long B, int R2) {
+__global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+                                                           const long* __restrict__ column, const long* __restrict__ row, SrP P,
+                                                           float* __restrict__ loss_sum, long B, int R, int win) {
     __shared__ SrW W;
-    load_srw(W, P);
-    long n = B * (long)R2 * R2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int X = (int)(i % R2), Y = (int)((i / R2) % R2);
-        long b = i / ((long)R2 * R2);
-        float acc[3] = {W.b1[0], W.b1[1], W.b1[2]};
-        conv3_at<T>(u, b, Y, X, R2, W.w1, acc);
-#pragma unroll
-        for (int o = 0; o < 3; ++o) c1[((b * 3 + o) * (long)R2 + Y) * R2 + X] = from_f<T>(fmaxf(acc[o], 0.f));
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void sr_conv2_loss_kernel(const T* __restrict__ u, const T* __restrict__ c1,
-                                                            const float* __restrict__ big, const long* __restrict__ column,
-                                                            const long* __restrict__ row, T* __restrict__ ds,
-                                                            float* __restrict__ loss_sum, SrP P, long B, int R2, int sp, int win) {
+    __shared__ float U[3 * 36 * 36];
+    __shared__ float C1[3 * 34 * 34];
     __shared__ float sh[4];
-    __shared__ SrW W;
     load_srw(W, P);
-    long n = B * (long)R2 * R2;
+    const int R2 = 2 * R, G = R2 / SRT;
     float part = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int X = (int)(i % R2), Y = (int)((i / R2) % R2);
-        long b = i / ((long)R2 * R2);
-        int gy = Y / sp, gx = X / sp;
-        int c0 = (int)column[b], r0 = (int)row[b];
-        bool in = gy >= c0 && gy < c0 + win && gx >= r0 && gx < r0 + win;
-        float acc[3] = {W.b2[0], W.b2[1], W.b2[2]};
-        if (in) conv3_at<T>(c1, b, Y, X, R2, W.w2, acc);
+    for (long t = blockIdx.x; t < B * G * G; t += gridDim.x) {
+        const long b = t / (G * G);
+        const int ty = (int)((t / G) % G), tx = (int)(t % G);
+        const int c0 = (int)column[b], r0 = (int)row[b];
+        if (ty < c0 || ty >= c0 + win || tx < r0 || tx >= r0 + win) continue;  // block-uniform
+        const int Y0 = ty * SRT, X0 = tx * SRT;
+        __syncthreads();
+        sr_fill_u<2>(U, pred_img, b, Y0, X0, R);
+        __syncthreads();
+        sr_conv_stage<34, 1, true>(C1, U, W.w1, W.b1, Y0, X0, R2);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < SRT * SRT; idx += 256) {
+            int y = idx / SRT, x = idx % SRT;
+            float acc[3] = {W.b2[0], W.b2[1], W.b2[2]};
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            long idx = ((b * 3 + o) * (long)R2 + Y) * R2 + X;
-            float g = 0.f;
-            if (in) {
-                float s = fmaxf(acc[o] + to_f<T>(u[idx]), 0.f);
-                float d = s - big[idx];
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float v = C1[(i * 34 + y + ky) * 34 + x + kx];
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) acc[o] += W.w2[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
+                    }
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                float s = fmaxf(acc[o] + U[(o * 36 + y + 2) * 36 + x + 2], 0.f);
+                float d = s - big[((b * 3 + o) * (long)R2 + Y0 + y) * R2 + X0 + x];
                 part += d * d;
-                g = s > 0.f ? d : 0.f;
             }
-            ds[idx] = from_f<T>(g);
         }
     }
     part = block_sum_256(part, sh);
@@ -518,173 +505,216 @@ __device__ __forceinline__ void reduce_to_global(float (&v)[NV], float* __restri
     for (int k = threadIdx.x; k < NV; k += 256) atomicAdd(out + k, sh[k] + sh[NV + k] + sh[2 * NV + k] + sh[3 * NV + k]);
 }
 
-// dc1 = conv2^T(ds) * [c1 > 0] ; dW2[o,i,ky,kx] += ds[o,Y,X] * c1[i,Y+ky-1,X+kx-1] ; db2[o] += ds[o,Y,X]
-template <typename T>
-__global__ __launch_bounds__(256) void sr_bwd2_kernel(const T* __restrict__ ds, const T* __restrict__ c1, T* __restrict__ dc1,
-                                                      float* __restrict__ dw2 /*[81]*/, float* __restrict__ db2 /*[3]*/, SrP P,
-                                                      long B, int R2) {
-    __shared__ float sh[4 * 84];
+// backward: dsr = d(0.5 * res_sum)/d pred_img (f32 [B,3,R,R]); gw[168] += {dW1[81], db1[3], dW2[81], db2[3]} (unscaled)
+__global__ __launch_bounds__(256) void sr_fused_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+                                                           const long* __restrict__ column, const long* __restrict__ row, SrP P,
+                                                           float* __restrict__ dsr, float* __restrict__ gw, long B, int R, int win) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* U = smem;                       // 3 x 42 x 42   (halo 5)
+    float* C1 = U + 3 * 42 * 42;           // 3 x 40 x 40   (halo 4)  -- reused for DU 3 x 34 x 34 (halo 1)
+    float* DS = C1 + 3 * 40 * 40;          // 3 x 38 x 38   (halo 3)
+    float* DC1 = DS + 3 * 38 * 38;         // 3 x 36 x 36   (halo 2)
+    float* RED = DC1 + 3 * 36 * 36;        // 4 x 84 reduction scratch
     __shared__ SrW W;
     load_srw(W, P);
-    long n = B * (long)R2 * R2;
-    float g[84];
+    const int R2 = 2 * R, G = R2 / SRT, PT = SRT / 2;
+    float g1[84], g2[84];
 #pragma unroll
-    for (int k = 0; k < 84; ++k) g[k] = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int X = (int)(i % R2), Y = (int)((i / R2) % R2);
-        long b = i / ((long)R2 * R2);
-        float acc[3] = {0.f, 0.f, 0.f};
-        conv3t_at<T>(ds, b, Y, X, R2, W.w2, acc);
-        float d[3];
+    for (int k = 0; k < 84; ++k) g1[k] = g2[k] = 0.f;
+    for (long t = blockIdx.x; t < B * G * G; t += gridDim.x) {
+        const long b = t / (G * G);
+        const int ty = (int)((t / G) % G), tx = (int)(t % G);
+        const int c0 = (int)column[b], r0 = (int)row[b];
+        const int Y0 = ty * SRT, X0 = tx * SRT;
+        const int py = threadIdx.x / PT, px = threadIdx.x % PT;  // this thread's pred_img pixel of the 16x16 tile
+        if (ty < c0 - 1 || ty > c0 + win || tx < r0 - 1 || tx > r0 + win) {  // no window pixel within reach: gradient is zero
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            long idx = ((b * 3 + o) * (long)R2 + Y) * R2 + X;
-            dc1[idx] = from_f<T>(to_f<T>(c1[idx]) > 0.f ? acc[o] : 0.f);
-            d[o] = to_f<T>(ds[idx]);
-            g[81 + o] += d[o];
+            for (int c = 0; c < 3; ++c) dsr[((b * 3 + c) * (long)R + ty * PT + py) * R + tx * PT + px] = 0.f;
+            continue;
         }
-        if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
+        __syncthreads();
+        sr_fill_u<5>(U, pred_img, b, Y0, X0, R);
+        __syncthreads();
+        sr_conv_stage<40, 4, true>(C1, U, W.w1, W.b1, Y0, X0, R2);
+        __syncthreads();
+        // ds on halo 3: [pixel in window] * (s - big) * [s > 0]
+        for (int idx = threadIdx.x; idx < 38 * 38; idx += 256) {
+            int y = idx / 38, x = idx % 38;
+            int Y = Y0 - 3 + y, X = X0 - 3 + x;
+            bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+            if (in) {
+                int gy = Y / SRT, gx = X / SRT;
+                in = gy >= c0 && gy < c0 + win && gx >= r0 && gx < r0 + win;
+            }
+            float acc[3] = {W.b2[0], W.b2[1], W.b2[2]};
+            if (in) {
 #pragma unroll
-            for (int ii = 0; ii < 3; ++ii) {
-                const T* pl = c1 + (b * 3 + ii) * (long)R2 * R2;
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    int yy = Y + ky - 1;
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        int xx = X + kx - 1;
-                        float v = (yy >= 0 && yy < R2 && xx >= 0 && xx < R2) ? to_f<T>(pl[(long)yy * R2 + xx]) : 0.f;
+                        for (int kx = 0; kx < 3; ++kx) {
+                            float v = C1[(i * 40 + y + ky) * 40 + x + kx];
 #pragma unroll
-                        for (int o = 0; o < 3; ++o) g[((o * 3 + ii) * 3 + ky) * 3 + kx] += d[o] * v;
+                            for (int o = 0; o < 3; ++o) acc[o] += W.w2[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
+                        }
+            }
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                float d = 0.f;
+                if (in) {
+                    float s = fmaxf(acc[o] + U[(o * 42 + y + 2) * 42 + x + 2], 0.f);
+                    d = s > 0.f ? s - big[((b * 3 + o) * (long)R2 + Y) * R2 + X] : 0.f;
+                }
+                DS[(o * 38 + y) * 38 + x] = d;
+            }
+        }
+        __syncthreads();
+        // dc1 on halo 2 = [c1 > 0] * conv2^T(ds) ; conv2 weight grads over the 32x32 centre
+        for (int idx = threadIdx.x; idx < 36 * 36; idx += 256) {
+            int y = idx / 36, x = idx % 36;
+            int Y = Y0 - 2 + y, X = X0 - 2 + x;
+            const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+            float acc[3] = {0.f, 0.f, 0.f};
+            if (in) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            float v = DS[(o * 38 + y + 2 - ky) * 38 + x + 2 - kx];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) acc[i] += W.w2[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
+                        }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) DC1[(i * 36 + y) * 36 + x] = (in && C1[(i * 40 + y + 2) * 40 + x + 2] > 0.f) ? acc[i] : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < SRT * SRT; idx += 256) {
+            int y = idx / SRT, x = idx % SRT;
+            float d[3] = {DS[(0 * 38 + y + 3) * 38 + x + 3], DS[(1 * 38 + y + 3) * 38 + x + 3], DS[(2 * 38 + y + 3) * 38 + x + 3]};
+            if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) g2[81 + o] += d[o];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            float v = C1[(i * 40 + y + 3 + ky) * 40 + x + 3 + kx];
+#pragma unroll
+                            for (int o = 0; o < 3; ++o) g2[((o * 3 + i) * 3 + ky) * 3 + kx] += d[o] * v;
+                        }
+            }
+        }
+        __syncthreads();
+        // du on halo 1 (into the C1 buffer) = ds + conv1^T(dc1) ; conv1 weight grads over the centre
+        float* DU = C1;
+        for (int idx = threadIdx.x; idx < 34 * 34; idx += 256) {
+            int y = idx / 34, x = idx % 34;
+            int Y = Y0 - 1 + y, X = X0 - 1 + x;
+            const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+            float acc[3] = {0.f, 0.f, 0.f};
+            if (in) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            float v = DC1[(o * 36 + y + 2 - ky) * 36 + x + 2 - kx];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) acc[i] += W.w1[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
+                        }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i] += DS[(i * 38 + y + 2) * 38 + x + 2];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) DU[(i * 34 + y) * 34 + x] = in ? acc[i] : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < SRT * SRT; idx += 256) {
+            int y = idx / SRT, x = idx % SRT;
+            float d[3] = {DC1[(0 * 36 + y + 2) * 36 + x + 2], DC1[(1 * 36 + y + 2) * 36 + x + 2], DC1[(2 * 36 + y + 2) * 36 + x + 2]};
+            if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) g1[81 + o] += d[o];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            float v = U[(i * 42 + y + 4 + ky) * 42 + x + 4 + kx];
+#pragma unroll
+                            for (int o = 0; o < 3; ++o) g1[((o * 3 + i) * 3 + ky) * 3 + kx] += d[o] * v;
+                        }
+            }
+        }
+        __syncthreads();
+        // transpose of the bilinear x2: each pred_img pixel gathers the <= 4x4 du values whose footprint touches it
+        {
+            const int y = ty * PT + py, x = tx * PT + px;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.f;
+                for (int Y = max(2 * y - 1, 0); Y <= min(2 * y + 2, R2 - 1); ++Y) {
+                    int y0, y1;
+                    float wy0, wy1;
+                    up2_taps(Y, R, y0, y1, wy0, wy1);
+                    float wy = (y0 == y ? wy0 : 0.f) + (y1 == y ? wy1 : 0.f);
+                    if (wy == 0.f) continue;
+                    for (int X = max(2 * x - 1, 0); X <= min(2 * x + 2, R2 - 1); ++X) {
+                        int x0, x1;
+                        float wx0, wx1;
+                        up2_taps(X, R, x0, x1, wx0, wx1);
+                        float wx = (x0 == x ? wx0 : 0.f) + (x1 == x ? wx1 : 0.f);
+                        if (wx != 0.f) acc += wy * wx * DU[(c * 34 + (Y - Y0 + 1)) * 34 + (X - X0 + 1)];
                     }
                 }
+                dsr[((b * 3 + c) * (long)R + y) * R + x] = acc;
             }
         }
     }
-    reduce_to_global<84>(g, dw2, sh);  // dw2[0..80], db2 must directly follow: dw2[81..83]
-    (void)db2;
+    __syncthreads();
+    reduce_to_global<84>(g1, gw, RED);
+    __syncthreads();
+    reduce_to_global<84>(g2, gw + 84, RED);
 }
 
-// du = ds + conv1^T(dc1) ; dW1[o,i,ky,kx] += dc1[o,Y,X] * u[i,Y+ky-1,X+kx-1] ; db1[o] += dc1[o,Y,X]
-template <typename T>
-__global__ __launch_bounds__(256) void sr_bwd1_kernel(const T* __restrict__ ds, const T* __restrict__ dc1, const T* __restrict__ u,
-                                                      T* __restrict__ du, float* __restrict__ dw1 /*[84]*/, SrP P, long B, int R2) {
-    __shared__ float sh[4 * 84];
-    __shared__ SrW W;
-    load_srw(W, P);
-    long n = B * (long)R2 * R2;
-    float g[84];
-#pragma unroll
-    for (int k = 0; k < 84; ++k) g[k] = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int X = (int)(i % R2), Y = (int)((i / R2) % R2);
-        long b = i / ((long)R2 * R2);
-        float acc[3] = {0.f, 0.f, 0.f};
-        conv3t_at<T>(dc1, b, Y, X, R2, W.w1, acc);
-        float d[3];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            long idx = ((b * 3 + o) * (long)R2 + Y) * R2 + X;
-            du[idx] = from_f<T>(acc[o] + to_f<T>(ds[idx]));
-            d[o] = to_f<T>(dc1[idx]);
-            g[81 + o] += d[o];
-        }
-        if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
-#pragma unroll
-            for (int ii = 0; ii < 3; ++ii) {
-                const T* pl = u + (b * 3 + ii) * (long)R2 * R2;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    int yy = Y + ky - 1;
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        int xx = X + kx - 1;
-                        float v = (yy >= 0 && yy < R2 && xx >= 0 && xx < R2) ? to_f<T>(pl[(long)yy * R2 + xx]) : 0.f;
-#pragma unroll
-                        for (int o = 0; o < 3; ++o) g[((o * 3 + ii) * 3 + ky) * 3 + kx] += d[o] * v;
-                    }
-                }
-            }
-        }
-    }
-    reduce_to_global<84>(g, dw1, sh);
-}
-
-// dsr[b,c,y,x] = sum over the <=4x4 upsampled pixels whose bilinear footprint touches (y,x) (transpose of sr_up)
-template <typename T>
-__global__ void sr_up_bwd_kernel(const T* __restrict__ du, float* __restrict__ dsr, long planes, int R) {
-    const int R2 = 2 * R;
-    long n = planes * (long)R * R;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int x = (int)(i % R), y = (int)((i / R) % R);
-        long pl = i / ((long)R * R);
-        const T* p = du + pl * (long)R2 * R2;
-        float acc = 0.f;
-        for (int Y = max(2 * y - 1, 0); Y <= min(2 * y + 2, R2 - 1); ++Y) {
-            int y0, y1;
-            float wy0, wy1;
-            up2_taps(Y, R, y0, y1, wy0, wy1);
-            float wy = (y0 == y ? wy0 : 0.f) + (y1 == y ? wy1 : 0.f);
-            if (wy == 0.f) continue;
-            for (int X = max(2 * x - 1, 0); X <= min(2 * x + 2, R2 - 1); ++X) {
-                int x0, x1;
-                float wx0, wx1;
-                up2_taps(X, R, x0, x1, wx0, wx1);
-                float wx = (x0 == x ? wx0 : 0.f) + (x1 == x ? wx1 : 0.f);
-                if (wx != 0.f) acc += wy * wx * to_f<T>(p[(long)Y * R2 + X]);
-            }
-        }
-        dsr[i] = acc;
-    }
-}
-
-extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row,
-                            const float* w1, const float* b1, const float* w2, const float* b2, void* u, void* c1, void* ds,
-                            float* loss_sum, int64_t B, int32_t R, int32_t super_patch, int32_t window, int32_t dtype,
-                            hipStream_t stream) {
-    ECAMP_CHECK_ARG(pred_img && big && column && row && w1 && b1 && w2 && b2 && u && c1 && ds && loss_sum, "sr_fwd: null pointer");
+extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
+                            const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B, int32_t R,
+                            int32_t super_patch, int32_t window, hipStream_t stream) {
+    ECAMP_CHECK_ARG(pred_img && big && column && row && w1 && b1 && w2 && b2 && loss_sum, "sr_fwd: null pointer");
+    ECAMP_CHECK_ARG(super_patch == SRT && (2 * R) % SRT == 0, "sr_fwd: the fused SR head is built for 32-px super-patches (patch 16)");
     SrP W = {w1, b1, w2, b2};
-    const int R2 = 2 * R;
-    long n = B * 3 * (long)R2 * R2, npx = B * (long)R2 * R2;
-    int nb = (int)((n + 255) / 256), nbp = (int)((npx + 255) / 256);
-    if (nb > 16384) nb = 16384;
-    if (nbp > 16384) nbp = 16384;
-    int nbl = nbp > 4096 ? 4096 : nbp;
-    if (dtype == ECAMP_F32) {
-        hipLaunchKernelGGL(sr_up_kernel<float>, dim3(nb), dim3(256), 0, stream, pred_img, (float*)u, (long)B * 3, R);
-        hipLaunchKernelGGL(sr_conv1_kernel<float>, dim3(nbp), dim3(256), 0, stream, (const float*)u, (float*)c1, W, (long)B, R2);
-        hipLaunchKernelGGL(sr_conv2_loss_kernel<float>, dim3(nbl), dim3(256), 0, stream, (const float*)u, (const float*)c1, big, (const long*)column, (const long*)row, (float*)ds, loss_sum, W, (long)B, R2, super_patch, window);
-    } else {
-        hipLaunchKernelGGL(sr_up_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, pred_img, (bf16_t*)u, (long)B * 3, R);
-        hipLaunchKernelGGL(sr_conv1_kernel<bf16_t>, dim3(nbp), dim3(256), 0, stream, (const bf16_t*)u, (bf16_t*)c1, W, (long)B, R2);
-        hipLaunchKernelGGL(sr_conv2_loss_kernel<bf16_t>, dim3(nbl), dim3(256), 0, stream, (const bf16_t*)u, (const bf16_t*)c1, big, (const long*)column, (const long*)row, (bf16_t*)ds, loss_sum, W, (long)B, R2, super_patch, window);
-    }
+    long tiles = B * (2 * R / SRT) * (2 * R / SRT);
+    int nb = (int)(tiles < 2048 ? tiles : 2048);
+    hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
+                       (long)B, R, window);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
 
-// Produces dsr (f32 [B,3,R,R], unscaled: d(0.5*res_sum)/d pred_img) and accumulates the UNSCALED conv gradients
-// into gw_ws[168] = {dW1[81], db1[3], dW2[81], db2[3]} (caller scales by g_res*2/N when folding into .grad).
-extern "C" int ecamp_sr_bwd(const void* u, const void* c1, const void* ds, const float* w1, const float* b1, const float* w2,
-                            const float* b2, void* dc1, void* du, float* dsr, float* gw_ws, int64_t B, int32_t R, int32_t dtype,
-                            hipStream_t stream) {
-    ECAMP_CHECK_ARG(u && c1 && ds && w1 && b1 && w2 && b2 && dc1 && du && dsr && gw_ws, "sr_bwd: null pointer");
+// dsr: f32 [B,3,R,R] = d(0.5*res_sum)/d pred_img;  gw_ws[168] += {dW1[81], db1[3], dW2[81], db2[3]} (unscaled; the caller
+// folds g_res*2/N in when adding into the .grad views).
+extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
+                            const float* b1, const float* w2, const float* b2, float* dsr, float* gw_ws, int64_t B, int32_t R,
+                            int32_t super_patch, int32_t window, hipStream_t stream) {
+    ECAMP_CHECK_ARG(pred_img && big && column && row && w1 && b1 && w2 && b2 && dsr && gw_ws, "sr_bwd: null pointer");
+    ECAMP_CHECK_ARG(super_patch == SRT && (2 * R) % SRT == 0, "sr_bwd: the fused SR head is built for 32-px super-patches (patch 16)");
     SrP W = {w1, b1, w2, b2};
-    const int R2 = 2 * R;
-    long npx = B * (long)R2 * R2, nlo = B * 3 * (long)R * R;
-    int nbp = (int)((npx + 255) / 256);
-    if (nbp > 2048) nbp = 2048;
-    int nbl = (int)((nlo + 255) / 256);
-    if (nbl > 8192) nbl = 8192;
-    if (dtype == ECAMP_F32) {
-        hipLaunchKernelGGL(sr_bwd2_kernel<float>, dim3(nbp), dim3(256), 0, stream, (const float*)ds, (const float*)c1, (float*)dc1, gw_ws + 84, gw_ws + 84 + 81, W, (long)B, R2);
-        hipLaunchKernelGGL(sr_bwd1_kernel<float>, dim3(nbp), dim3(256), 0, stream, (const float*)ds, (const float*)dc1, (const float*)u, (float*)du, gw_ws, W, (long)B, R2);
-        hipLaunchKernelGGL(sr_up_bwd_kernel<float>, dim3(nbl), dim3(256), 0, stream, (const float*)du, dsr, (long)B * 3, R);
-    } else {
-        hipLaunchKernelGGL(sr_bwd2_kernel<bf16_t>, dim3(nbp), dim3(256), 0, stream, (const bf16_t*)ds, (const bf16_t*)c1, (bf16_t*)dc1, gw_ws + 84, gw_ws + 84 + 81, W, (long)B, R2);
-        hipLaunchKernelGGL(sr_bwd1_kernel<bf16_t>, dim3(nbp), dim3(256), 0, stream, (const bf16_t*)ds, (const bf16_t*)dc1, (const bf16_t*)u, (bf16_t*)du, gw_ws, W, (long)B, R2);
-        hipLaunchKernelGGL(sr_up_bwd_kernel<bf16_t>, dim3(nbl), dim3(256), 0, stream, (const bf16_t*)du, dsr, (long)B * 3, R);
+    long tiles = B * (2 * R / SRT) * (2 * R / SRT);
+    int nb = (int)(tiles < 1024 ? tiles : 1024);
+    size_t shm = (size_t)(3 * (42 * 42 + 40 * 40 + 38 * 38 + 36 * 36) + 4 * 84) * sizeof(float);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sr_fused_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        once = true;
     }
+    hipLaunchKernelGGL(sr_fused_bwd_kernel, dim3(nb), dim3(256), shm, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr, gw_ws,
+                       (long)B, R, window);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }

@@ -180,16 +180,16 @@ class ImgLossFn(torch.autograd.Function):
         sums = ops.zeros((2,), xd.device)
         pred_img = ops.unpatchify_mim(pred, imgs, mask, sums[0:], B, R, p)
         sr = m.super_res
-        u, c1, ds = ops.sr_fwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data,
-                               sr.conv2.bias.data, sums[1:], 2 * p, m.sr_window, cd)
+        ops.sr_fwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data, sr.conv2.bias.data,
+                   sums[1:], 2 * p, m.sr_window)
         n1, n2 = B * 3 * R * R, B * 3 * 4 * R * R
-        ctx.s = (xd, mean, rstd, h, pred_img, imgs, mask, u, c1, ds, m, B, n1, n2)
+        ctx.s = (xd, mean, rstd, h, pred_img, imgs, mask, big, column, row, m, B, n1, n2)
         m._aux = dict(pred=pred, pred_img=pred_img) if m.keep_aux else None
         return sums * m._loss_norm(n1, n2, xd.device)
 
     @staticmethod
     def backward(ctx, g):
-        xd, mean, rstd, h, pred_img, imgs, mask, u, c1, ds, m, B, n1, n2 = ctx.s
+        xd, mean, rstd, h, pred_img, imgs, mask, big, column, row, m, B, n1, n2 = ctx.s
         A = m.arena
         G = A.grad
         cd = m.compute_dtype
@@ -197,7 +197,8 @@ class ImgLossFn(torch.autograd.Function):
         gm_gs = (g * (2.0 * m._loss_norm(n1, n2, g.device))).contiguous()  # [g_mim*2/N1, g_res*2/N2] (2 floats, on device)
         sr = m.super_res
         ws = ops.zeros((168,), xd.device)
-        dsr = ops.sr_bwd(u, c1, ds, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data, sr.conv2.bias.data, ws)
+        dsr = ops.sr_bwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data,
+                         sr.conv2.bias.data, ws, 2 * p, m.sr_window)
         ops.scaled_accum(ws[0:81], G(sr.conv1.weight), gm_gs, 1)
         ops.scaled_accum(ws[81:84], G(sr.conv1.bias), gm_gs, 1)
         ops.scaled_accum(ws[84:165], G(sr.conv2.weight), gm_gs, 1)

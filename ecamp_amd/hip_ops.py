@@ -258,25 +258,17 @@ def img_loss_bwd(pred_img, imgs, mask, dsr, gm_gs, B, R, p, dtype):
     return dpred
 
 
-def sr_fwd(pred_img, big, column, row, w1, b1, w2, b2, loss_sum, super_patch, window, dtype):
+def sr_fwd(pred_img, big, column, row, w1, b1, w2, b2, loss_sum, super_patch, window):
     B, _, R, _ = pred_img.shape
-    shp = (B, 3, 2 * R, 2 * R)
-    u = torch.empty(shp, device=big.device, dtype=dtype)
-    c1 = torch.empty(shp, device=big.device, dtype=dtype)
-    ds = torch.empty(shp, device=big.device, dtype=dtype)
-    call("ecamp_sr_fwd", ptr(pred_img), ptr(big), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(u), ptr(c1), ptr(ds),
-         ptr(loss_sum), B, R, super_patch, window, code(dtype), stream())
-    return u, c1, ds
+    call("ecamp_sr_fwd", ptr(pred_img), ptr(big), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(loss_sum), B, R,
+         super_patch, window, stream())
 
 
-def sr_bwd(u, c1, ds, w1, b1, w2, b2, gw_ws):
-    B, _, R2, _ = u.shape
-    R = R2 // 2
-    dc1 = torch.empty_like(u)
-    du = torch.empty_like(u)
-    dsr = torch.empty((B, 3, R, R), device=u.device, dtype=torch.float32)
-    call("ecamp_sr_bwd", ptr(u), ptr(c1), ptr(ds), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dc1), ptr(du), ptr(dsr), ptr(gw_ws), B, R,
-         code(u.dtype), stream())
+def sr_bwd(pred_img, big, column, row, w1, b1, w2, b2, gw_ws, super_patch, window):
+    B, _, R, _ = pred_img.shape
+    dsr = torch.empty((B, 3, R, R), device=pred_img.device, dtype=torch.float32)
+    call("ecamp_sr_bwd", ptr(pred_img), ptr(big), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dsr), ptr(gw_ws), B, R,
+         super_patch, window, stream())
     return dsr
 
 

@@ -353,19 +353,18 @@ def test_image_losses_and_sr_head(dev, dtype, R, win):
     pimg_d = o.unpatchify_mim(pd, imgs.to(dev), mask.to(dev), sums[0:], B, R, p)
     check("unpatchify", pimg_d, pimg, 1e-6)
     wd = [t.to(dev).contiguous() for t in (w1, b1, w2, b2)]
-    ud, c1d, dsd = o.sr_fwd(pimg_d, big.to(dev), column.to(dev), row.to(dev), *wd, sums[1:], 2 * p, win, dtype)
+    o.sr_fwd(pimg_d, big.to(dev), column.to(dev), row.to(dev), *wd, sums[1:], 2 * p, win)
     n1, n2 = B * 3 * R * R, B * 3 * 4 * R * R
     tol = TOL[dtype]
     check("mim loss", sums[0:1] / n1, mim.view(1), 1e-5)
-    check("res loss", sums[1:2] / n2, res.view(1), 1e-5 if dtype == torch.float32 else 1e-2)
+    check("res loss", sums[1:2] / n2, res.view(1), 1e-5)
     gw = torch.zeros(168, device=dev)
-    dsr = o.sr_bwd(ud, c1d, dsd, *wd, gw)
+    dsr = o.sr_bwd(pimg_d, big.to(dev), column.to(dev), row.to(dev), *wd, gw, 2 * p, win)
     gmgs = torch.tensor([g_mim * 2 / n1, g_res * 2 / n2], device=dev)
     dpred = o.img_loss_bwd(pimg_d, imgs.to(dev), mask.to(dev), dsr, gmgs, B, R, p, dtype)
-    # bf16 mode keeps the five SR intermediates (u, c1, ds, dc1, du) in bf16: errors compound through two 3x3 convs
-    check("d pred (mim + SR branch)", dpred.view(B, L + 1, -1), pr.grad, 5e-2 if dtype == torch.bfloat16 else 1e-4)
+    check("d pred (mim + SR branch)", dpred.view(B, L + 1, -1), pr.grad, 1e-2 if dtype == torch.bfloat16 else 1e-4)
     s = g_res * 2 / n2
-    gtol = 1e-4 if dtype == torch.float32 else 3e-2
+    gtol = 1e-4  # the fused SR head is f32 in LDS whatever the activation dtype
     check("d conv1.weight", gw[0:81] * s, ws[0].grad.view(-1), gtol)
     check("d conv1.bias", gw[81:84] * s, ws[1].grad, gtol)
     check("d conv2.weight", gw[84:165] * s, ws[2].grad.view(-1), gtol)
