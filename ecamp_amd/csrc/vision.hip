@@ -506,21 +506,42 @@ __device__ __forceinline__ void reduce_to_global(float (&v)[NV], float* __restri
 }
 
 // backward: dsr = d(0.5 * res_sum)/d pred_img (f32 [B,3,R,R]); gw[168] += {dW1[81], db1[3], dW2[81], db2[3]} (unscaled)
-__global__ __launch_bounds__(256) void sr_fused_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+// Weight gradients: the 27 taps of each conv are split over the 4 waves (7,7,7,6); a lane walks 16 of the tile's 1024
+// centre pixels and keeps 7 taps x 3 output channels per conv in registers ACROSS tiles (42 accumulators instead of 168),
+// reduced across lanes once at the end of the kernel.
+__device__ __forceinline__ int sr_tap_off(int tap, int E) {  // tap = (i*3 + ky)*3 + kx  ->  offset of (i, ky, kx) in a [3][E][E] tile
+    int i = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    return (i * E + ky) * E + kx;
+}
+
+__global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
                                                            const long* __restrict__ column, const long* __restrict__ row, SrP P,
                                                            float* __restrict__ dsr, float* __restrict__ gw, long B, int R, int win) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* U = smem;                       // 3 x 42 x 42   (halo 5)
     float* C1 = U + 3 * 42 * 42;           // 3 x 40 x 40   (halo 4)  -- reused for DU 3 x 34 x 34 (halo 1)
     float* DS = C1 + 3 * 40 * 40;          // 3 x 38 x 38   (halo 3)
-    float* DC1 = DS + 3 * 38 * 38;         // 3 x 36 x 36   (halo 2)
-    float* RED = DC1 + 3 * 36 * 36;        // 4 x 84 reduction scratch
+    float* DC1 = DS + 3 * 38 * 38;         // 3 x 36 x 36   (halo 2)  -- first holds the 3 x 24 x 24 pred_img patch
     __shared__ SrW W;
     load_srw(W, P);
     const int R2 = 2 * R, G = R2 / SRT, PT = SRT / 2;
-    float g1[84], g2[84];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tap0 = wave * 7, ntap = wave == 3 ? 6 : 7;
+    int off1[7], off2[7];
 #pragma unroll
-    for (int k = 0; k < 84; ++k) g1[k] = g2[k] = 0.f;
+    for (int t = 0; t < 7; ++t) {
+        int tap = min(tap0 + t, 26);
+        off1[t] = sr_tap_off(tap, 42);  // conv1 taps index U  (edge 42)
+        off2[t] = sr_tap_off(tap, 40);  // conv2 taps index C1 (edge 40)
+    }
+    float a1[7][3], a2[7][3], bb1[3], bb2[3];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) a1[t][o] = a2[t][o] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) bb1[o] = bb2[o] = 0.f;
+
     for (long t = blockIdx.x; t < B * G * G; t += gridDim.x) {
         const long b = t / (G * G);
         const int ty = (int)((t / G) % G), tx = (int)(t % G);
@@ -533,44 +554,83 @@ __global__ __launch_bounds__(256) void sr_fused_bwd_kernel(const float* __restri
             continue;
         }
         __syncthreads();
-        sr_fill_u<5>(U, pred_img, b, Y0, X0, R);
-        __syncthreads();
-        sr_conv_stage<40, 4, true>(C1, U, W.w1, W.b1, Y0, X0, R2);
-        __syncthreads();
-        // ds on halo 3: [pixel in window] * (s - big) * [s > 0]
-        for (int idx = threadIdx.x; idx < 38 * 38; idx += 256) {
+        // (1) pred_img patch (24 x 24 x 3, clamped at the border) -> LDS with independent coalesced loads
+        float* PP = DC1;
+        const int ylo = Y0 / 2 - 4, xlo = X0 / 2 - 4;
+        for (int idx = threadIdx.x; idx < 3 * 24 * 24; idx += 256) {
+            int c = idx / 576, yy = (idx / 24) % 24, xx = idx % 24;
+            int y = min(max(ylo + yy, 0), R - 1), x = min(max(xlo + xx, 0), R - 1);
+            PP[idx] = pred_img[((b * 3 + c) * (long)R + y) * R + x];
+        }
+        // prefetch the `big` values this thread needs for ds (halo 3 region, window pixels only)
+        float bigv[6][3];
+        bool inw[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            int idx = threadIdx.x + 256 * j;
             int y = idx / 38, x = idx % 38;
             int Y = Y0 - 3 + y, X = X0 - 3 + x;
-            bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+            bool in = idx < 38 * 38 && Y >= 0 && Y < R2 && X >= 0 && X < R2;
             if (in) {
                 int gy = Y / SRT, gx = X / SRT;
                 in = gy >= c0 && gy < c0 + win && gx >= r0 && gx < r0 + win;
             }
-            float acc[3] = {W.b2[0], W.b2[1], W.b2[2]};
-            if (in) {
+            inw[j] = in;
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            float v = C1[(i * 40 + y + ky) * 40 + x + kx];
-#pragma unroll
-                            for (int o = 0; o < 3; ++o) acc[o] += W.w2[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
-                        }
+            for (int o = 0; o < 3; ++o) bigv[j][o] = in ? big[((b * 3 + o) * (long)R2 + Y) * R2 + X] : 0.f;
+        }
+        __syncthreads();
+        // (2) u on halo 5 from the patch
+        for (int idx = threadIdx.x; idx < 3 * 42 * 42; idx += 256) {
+            int c = idx / (42 * 42), y = (idx / 42) % 42, x = idx % 42;
+            int Y = Y0 - 5 + y, X = X0 - 5 + x;
+            float v = 0.f;
+            if (Y >= 0 && Y < R2 && X >= 0 && X < R2) {
+                int y0, y1, x0, x1;
+                float wy0, wy1, wx0, wx1;
+                up2_taps(Y, R, y0, y1, wy0, wy1);
+                up2_taps(X, R, x0, x1, wx0, wx1);
+                const float* pl = PP + c * 576;
+                y0 -= ylo; y1 -= ylo; x0 -= xlo; x1 -= xlo;
+                v = wy0 * (wx0 * pl[y0 * 24 + x0] + wx1 * pl[y0 * 24 + x1]) + wy1 * (wx0 * pl[y1 * 24 + x0] + wx1 * pl[y1 * 24 + x1]);
             }
+            U[idx] = v;
+        }
+        __syncthreads();
+        sr_conv_stage<40, 4, true>(C1, U, W.w1, W.b1, Y0, X0, R2);
+        __syncthreads();
+        // (3) ds on halo 3: [pixel in window] * (s - big) * [s > 0]
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                float d = 0.f;
-                if (in) {
-                    float s = fmaxf(acc[o] + U[(o * 42 + y + 2) * 42 + x + 2], 0.f);
-                    d = s > 0.f ? s - big[((b * 3 + o) * (long)R2 + Y) * R2 + X] : 0.f;
+        for (int j = 0; j < 6; ++j) {
+            int idx = threadIdx.x + 256 * j;
+            if (idx < 38 * 38) {
+                int y = idx / 38, x = idx % 38;
+                float acc[3] = {W.b2[0], W.b2[1], W.b2[2]};
+                if (inw[j]) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                float v = C1[(i * 40 + y + ky) * 40 + x + kx];
+#pragma unroll
+                                for (int o = 0; o < 3; ++o) acc[o] += W.w2[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
+                            }
                 }
-                DS[(o * 38 + y) * 38 + x] = d;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    float d = 0.f;
+                    if (inw[j]) {
+                        float s = fmaxf(acc[o] + U[(o * 42 + y + 2) * 42 + x + 2], 0.f);
+                        d = s > 0.f ? s - bigv[j][o] : 0.f;
+                    }
+                    DS[(o * 38 + y) * 38 + x] = d;
+                }
             }
         }
         __syncthreads();
-        // dc1 on halo 2 = [c1 > 0] * conv2^T(ds) ; conv2 weight grads over the 32x32 centre
+        // (4) dc1 on halo 2 = [c1 > 0] * conv2^T(ds)
         for (int idx = threadIdx.x; idx < 36 * 36; idx += 256) {
             int y = idx / 36, x = idx % 36;
             int Y = Y0 - 2 + y, X = X0 - 2 + x;
@@ -591,26 +651,37 @@ __global__ __launch_bounds__(256) void sr_fused_bwd_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 3; ++i) DC1[(i * 36 + y) * 36 + x] = (in && C1[(i * 40 + y + 2) * 40 + x + 2] > 0.f) ? acc[i] : 0.f;
         }
-        for (int idx = threadIdx.x; idx < SRT * SRT; idx += 256) {
-            int y = idx / SRT, x = idx % SRT;
-            float d[3] = {DS[(0 * 38 + y + 3) * 38 + x + 3], DS[(1 * 38 + y + 3) * 38 + x + 3], DS[(2 * 38 + y + 3) * 38 + x + 3]};
-            if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
+        __syncthreads();
+        // (5) weight gradients over the 32x32 centre: conv2 from (ds, c1), conv1 from (dc1, u)
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            int idx = lane + 64 * j;
+            int y = idx >> 5, x = idx & 31;
+            float d2[3] = {DS[(0 * 38 + y + 3) * 38 + x + 3], DS[(1 * 38 + y + 3) * 38 + x + 3], DS[(2 * 38 + y + 3) * 38 + x + 3]};
+            float d1[3] = {DC1[(0 * 36 + y + 2) * 36 + x + 2], DC1[(1 * 36 + y + 2) * 36 + x + 2], DC1[(2 * 36 + y + 2) * 36 + x + 2]};
+            const float* c1p = C1 + (y + 3) * 40 + x + 3;   // tap (ky,kx) reads centre + (ky-1, kx-1) -> base shifted by (-1,-1) below
+            const float* up = U + (y + 4) * 42 + x + 4;
 #pragma unroll
-                for (int o = 0; o < 3; ++o) g2[81 + o] += d[o];
+            for (int tt = 0; tt < 7; ++tt) {
+                if (tt < ntap) {
+                    float v2 = c1p[off2[tt]], v1 = up[off1[tt]];
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                    for (int o = 0; o < 3; ++o) {
+                        a2[tt][o] += d2[o] * v2;
+                        a1[tt][o] += d1[o] * v1;
+                    }
+                }
+            }
+            if (wave == 3) {
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            float v = C1[(i * 40 + y + 3 + ky) * 40 + x + 3 + kx];
-#pragma unroll
-                            for (int o = 0; o < 3; ++o) g2[((o * 3 + i) * 3 + ky) * 3 + kx] += d[o] * v;
-                        }
+                for (int o = 0; o < 3; ++o) {
+                    bb2[o] += d2[o];
+                    bb1[o] += d1[o];
+                }
             }
         }
         __syncthreads();
-        // du on halo 1 (into the C1 buffer) = ds + conv1^T(dc1) ; conv1 weight grads over the centre
+        // (6) du on halo 1 (into the C1 buffer) = ds + conv1^T(dc1)
         float* DU = C1;
         for (int idx = threadIdx.x; idx < 34 * 34; idx += 256) {
             int y = idx / 34, x = idx % 34;
@@ -634,26 +705,8 @@ __global__ __launch_bounds__(256) void sr_fused_bwd_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 3; ++i) DU[(i * 34 + y) * 34 + x] = in ? acc[i] : 0.f;
         }
-        for (int idx = threadIdx.x; idx < SRT * SRT; idx += 256) {
-            int y = idx / SRT, x = idx % SRT;
-            float d[3] = {DC1[(0 * 36 + y + 2) * 36 + x + 2], DC1[(1 * 36 + y + 2) * 36 + x + 2], DC1[(2 * 36 + y + 2) * 36 + x + 2]};
-            if (d[0] != 0.f || d[1] != 0.f || d[2] != 0.f) {
-#pragma unroll
-                for (int o = 0; o < 3; ++o) g1[81 + o] += d[o];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            float v = U[(i * 42 + y + 4 + ky) * 42 + x + 4 + kx];
-#pragma unroll
-                            for (int o = 0; o < 3; ++o) g1[((o * 3 + i) * 3 + ky) * 3 + kx] += d[o] * v;
-                        }
-            }
-        }
         __syncthreads();
-        // transpose of the bilinear x2: each pred_img pixel gathers the <= 4x4 du values whose footprint touches it
+        // (7) transpose of the bilinear x2: each pred_img pixel gathers the <= 4x4 du values whose footprint touches it
         {
             const int y = ty * PT + py, x = tx * PT + px;
 #pragma unroll
@@ -677,10 +730,25 @@ __global__ __launch_bounds__(256) void sr_fused_bwd_kernel(const float* __restri
             }
         }
     }
-    __syncthreads();
-    reduce_to_global<84>(g1, gw, RED);
-    __syncthreads();
-    reduce_to_global<84>(g2, gw + 84, RED);
+    // one cross-lane reduction per kernel: gw layout {dW1[81], db1[3], dW2[81], db2[3]}, dW[o][i][ky][kx] = index o*27 + tap
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float s1 = wave_sum(a1[tt][o]), s2 = wave_sum(a2[tt][o]);
+            if (lane == 0 && tt < ntap) {
+                atomicAdd(gw + o * 27 + tap0 + tt, s1);
+                atomicAdd(gw + 84 + o * 27 + tap0 + tt, s2);
+            }
+        }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float s1 = wave_sum(bb1[o]), s2 = wave_sum(bb2[o]);
+        if (lane == 0 && wave == 3) {
+            atomicAdd(gw + 81 + o, s1);
+            atomicAdd(gw + 84 + 81 + o, s2);
+        }
+    }
 }
 
 extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
@@ -707,7 +775,7 @@ extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64
     SrP W = {w1, b1, w2, b2};
     long tiles = B * (2 * R / SRT) * (2 * R / SRT);
     int nb = (int)(tiles < 1024 ? tiles : 1024);
-    size_t shm = (size_t)(3 * (42 * 42 + 40 * 40 + 38 * 38 + 36 * 36) + 4 * 84) * sizeof(float);
+    size_t shm = (size_t)(3 * (42 * 42 + 40 * 40 + 38 * 38 + 36 * 36)) * sizeof(float);
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sr_fused_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
