@@ -96,7 +96,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n0, f32x
 #define BN 128
 #define BK 64
 
-__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+// 128-B rows: two rows share one 256-B LDS bank row, so the 16-B chunk index is XORed with row>>1 -- the 16 rows of an MFMA
+// fragment then land on 16 distinct 16-B slots for every b128 lane group (conflict-free reads and writes)
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
 // global -> registers, contraction-contiguous operand: 4 x 16 B per thread (row = c/8, chunk = c%8)
 __device__ __forceinline__ void g2r_kc(const bf16_t* P, long ld, int row0, int nrows, int k0, int kend, int tid,
