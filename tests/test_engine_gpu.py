@@ -1,0 +1,89 @@
+"""-m gpu: the driver level -- BASELINE.json configs[0] (ViT-Tiny/16 + 2-layer BERT, 32 synthetic 448^2 image-report pairs,
+mask_ratio 0.75, 1+ epochs) through `ecamp_amd.main_pretrain` with the reference's command-line flags, checkpoint format
+round trip and optimizer-state compatibility with torch.optim.AdamW."""
+import argparse
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(tmp, extra=()):
+    from ecamp_amd.main_pretrain import get_args_parser
+    argv = ["--model", "ecamp_tiny", "--batch_size", "8", "--accum_iter", "2", "--epochs", "3", "--warmup_epochs", "1", "--max_epoch", "4",
+            "--lr", "5e-4", "--weight_decay", "0.05", "--mask_ratio", "0.75", "--norm_pix_loss", "--num_workers", "0",
+            "--output_dir", str(tmp), "--data_path", str(tmp), "--synthetic_len", "32", "--max_caption_length", "64", "--print_freq", "2",
+            "--compute_dtype", "bf16"] + list(extra)
+    return argparse.ArgumentParser(parents=[get_args_parser()]).parse_args(argv)
+
+
+def test_main_pretrain_tiny_three_epochs(dev, tmp_path):
+    from ecamp_amd import main_pretrain
+    args = _args(tmp_path)
+    main_pretrain.main(args)
+    lines = open(os.path.join(tmp_path, "log.txt")).read().strip().split("\n")
+    assert lines[0] == "ecamp_pretrain"
+    stats = [json.loads(l) for l in lines[1:]]
+    assert [s["epoch"] for s in stats] == [0, 1, 2]
+    for s in stats:
+        for k in ("train_mim_loss", "train_res_loss", "train_mlm_loss", "train_lr"):
+            assert k in s and s[k] == s[k]  # present and not NaN
+    assert stats[-1]["train_mlm_loss"] < stats[0]["train_mlm_loss"], "MLM loss should fall within 3 epochs on 32 memorisable pairs"
+    assert stats[-1]["train_mim_loss"] < stats[0]["train_mim_loss"]
+    ck = torch.load(os.path.join(tmp_path, "checkpoint-0.pth"), map_location="cpu", weights_only=False)  # cadence: epoch 0 is saved
+    assert set(ck.keys()) == {"model", "optimizer", "epoch", "scaler", "args"} and ck["epoch"] == 0
+    assert os.path.exists(os.path.join(tmp_path, "config.yaml"))
+
+
+def test_checkpoint_round_trip_and_torch_adamw_compat(dev, tmp_path):
+    from ecamp_amd import optim
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.util import misc
+    torch.manual_seed(1)
+    model = me.ecamp_tiny(compute_dtype=torch.float32).to(dev)
+    model.prepare()
+    opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    scaler = misc.NativeScalerWithGradNormCount()
+    batch = synthetic_batch(4, 32, 448, seed=3)
+    model.eval()
+    opt.zero_grad()
+    scaler(sum(model(batch)), opt, parameters=model.parameters(), update_grad=True)
+    args = argparse.Namespace(output_dir=str(tmp_path), resume="")
+    misc.save_model(args=args, epoch=7, model=model, model_without_ddp=model, optimizer=opt, loss_scaler=scaler)
+    path = os.path.join(tmp_path, "checkpoint-7.pth")
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    # (a) the optimizer entry is a valid torch.optim.AdamW state dict for the same parameter grouping
+    twin = me.ecamp_tiny(compute_dtype=torch.float32)
+    twin.load_state_dict(ck["model"])
+    topt = torch.optim.AdamW(optim.add_weight_decay(twin, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    topt.load_state_dict(ck["optimizer"])
+    st = topt.state[twin.blocks[0].attn.qkv.weight]
+    assert float(st["step"]) == 1.0 and st["exp_avg"].abs().sum() > 0
+    # (b) resume into a fresh HIP model + optimizer: the next step is identical to continuing the original
+    m2 = me.ecamp_tiny(compute_dtype=torch.float32).to(dev)
+    m2.prepare()
+    o2 = optim.FusedAdamW(optim.add_weight_decay(m2, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    args2 = argparse.Namespace(resume="./ECAMP_ckpt.pth", start_epoch=0)
+    os.symlink(path, "./ECAMP_ckpt.pth") if not os.path.exists("./ECAMP_ckpt.pth") else None
+    try:
+        misc.load_model(args=args2, model_without_ddp=m2, optimizer=o2, loss_scaler=misc.NativeScalerWithGradNormCount())
+    finally:
+        os.remove("./ECAMP_ckpt.pth")
+    assert args2.start_epoch == 8
+    m2.eval()
+    for mdl, op in ((model, opt), (m2, o2)):
+        op.zero_grad()
+        scaler(sum(mdl(batch, noise=torch.linspace(0, 1, 196).repeat(4, 1))), op, parameters=mdl.parameters(), update_grad=True)
+    a, b = model.blocks[3].mlp.fc1.weight.detach().float().cpu(), m2.blocks[3].mlp.fc1.weight.detach().float().cpu()
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    # (c) a plain MAE encoder checkpoint (subset of keys) loads by key intersection (misc.py:322-329)
+    mae = {k: v for k, v in ck["model"].items() if k.startswith(("patch_embed", "blocks", "norm", "cls_token", "pos_embed"))}
+    torch.save({"model": mae}, os.path.join(tmp_path, "mae.pth"))
+    m3 = me.ecamp_tiny(compute_dtype=torch.float32).to(dev)
+    m3.prepare()
+    misc.load_model(args=argparse.Namespace(resume=os.path.join(tmp_path, "mae.pth")), model_without_ddp=m3, optimizer=None, loss_scaler=None)
+    assert torch.equal(m3.blocks[0].norm1.weight.cpu(), ck["model"]["blocks.0.norm1.weight"])
