@@ -177,6 +177,96 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(AttnArgs a) {
 }
 
 // =============================================================================================
+// Forward for ANY key length: keys streamed in chunks of 64 with the online-softmax recurrence (running max m, running
+// sum l, O rescaled by exp(m_old - m_new)).  Used when Tk > 256 (ViT-L/16 at 448^2: decoder sequence 785).
+template <int HD>
+__global__ __launch_bounds__(256) void attn16_fwd_long_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* KT = smem;
+    unsigned char* VT = smem + TileCfg<HD>::BYTES;
+    unsigned char* PT = smem + 2 * TileCfg<HD>::BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const long bh = (long)b * a.H + h;
+    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
+    bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_sb + h * a.o_sh;
+    bf16x8 qf[HD / 32];
+    load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
+    const int qi = q0 + li;
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    float m = NEG_BIG, l = 0.f;
+    f32x4 o[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned char* pt = PT + wave * 2048;
+    const int nkc = (a.Tk + 63) / 64;
+#pragma unroll 1
+    for (int c = 0; c < nkc; ++c) {
+        __syncthreads();
+        stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
+        stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
+        __syncthreads();
+        f32x4 s[4];
+        float cmx = NEG_BIG;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) acc = MFMA(frag_rows<HD>(KT, jt * 16 + li, ks * 4 + g), qf[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int j = c * 64 + jt * 16 + 4 * g + r;
+                bool ok = j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
+                acc[r] = ok ? acc[r] * a.scale : NEG_BIG;
+                cmx = fmaxf(cmx, acc[r]);
+            }
+            s[jt] = acc;
+        }
+        cmx = red4_max(cmx);
+        const float mn = fmaxf(m, cmx);
+        const float alpha = __expf(m - mn);  // first chunk: exp(-1e30 - finite) = 0, and l = o = 0 anyway
+        float csum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = s[jt][r] > 0.5f * NEG_BIG ? __expf(s[jt][r] - mn) : 0.f;
+                csum += p[r];
+                if (a.drop_p > 0.f) {
+                    uint64_t e = ((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk + (c * 64 + jt * 16 + 4 * g + r);
+                    p[r] *= dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
+                }
+            }
+            ptile_write4(pt, li, jt * 16 + 4 * g, p);
+        }
+        l = l * alpha + red4_sum(csum);
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 pf = ptile_frag(pt, li, kk * 4 + g);
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) o[dt] = MFMA(frag_tr<HD>(VT, dt * 16, kk * 32, lane), pf, o[dt]);
+        }
+    }
+    if (qi < a.Tq) {
+        if (g == 0) a.lse[bh * a.Tq + qi] = m + __logf(l);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) store4(ob + (long)qi * a.o_st + dt * 16 + 4 * g, o[dt], inv);
+    }
+}
+
+// =============================================================================================
 // dQ (+ delta).  D layouts: S/dP [j = 4g+r][i = li]; dQ [d = 4g+r][i = li]
 template <int HD, int KCH>
 __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(AttnArgs a) {
@@ -215,8 +305,9 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     unsigned char* st = ST + wave * 2048;
+    const int nkc = KCH ? KCH : (a.Tk + 63) / 64;  // KCH == 0: any key length (ViT-L/448 decoder, T = 785)
 #pragma unroll 1
-    for (int c = 0; c < KCH; ++c) {
+    for (int c = 0; c < nkc; ++c) {
         __syncthreads();
         stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
         stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
@@ -639,6 +730,11 @@ static void lds_optin(K kern, size_t bytes) {
 // =============================================================================================
 template <int HD>
 static void fwd16(const AttnArgs& a, hipStream_t st) {
+    if (a.Tk > 256) {
+        dim3 grid(ceil_div(a.Tq, 64), a.B * a.H);
+        hipLaunchKernelGGL((attn16_fwd_long_kernel<HD>), grid, dim3(256), (size_t)2 * TileCfg<HD>::BYTES + 4 * 2048, st, a);
+        return;
+    }
     {
         const int kch = a.Tk <= 64 ? 1 : a.Tk <= 128 ? 2 : 4;
         const size_t shm = (size_t)2 * kch * TileCfg<HD>::BYTES + 4 * 2048;
@@ -673,7 +769,8 @@ static void bwd16(const AttnArgs& a, hipStream_t st) {
         size_t shm = 2 * TileCfg<HD>::BYTES + 4 * 2048;
         if (a.Tk <= 64) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 1>), grid, block, shm, st, a);
         else if (a.Tk <= 128) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 2>), grid, block, shm, st, a);
-        else hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 4>), grid, block, shm, st, a);
+        else if (a.Tk <= 256) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 4>), grid, block, shm, st, a);
+        else hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 0>), grid, block, shm, st, a);
     }
     const int qch = a.Tq <= 64 ? 1 : a.Tq <= 128 ? 2 : 4;
     const size_t shq = (size_t)2 * qch * TileCfg<HD>::BYTES + 8 * 2048;

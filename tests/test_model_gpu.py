@@ -186,3 +186,32 @@ def test_cls_alias_and_own_masking_noise(dev):
     assert all(np.isfinite(l1)) and l1[0] != l2[0]  # a different random mask each call
     l0 = [t.item() for t in model(batch, mask_ratio=0.0)]  # Visualization/ uses mask_ratio=0
     assert l0[0] == 0.0 and np.isfinite(l0[1]) and np.isfinite(l0[2])
+
+
+def test_vit_large_448_bf16_matches_oracle(dev):
+    """BASELINE.json configs[3]: ViT-L/16 at 448^2 encoder input (197 encoder tokens, decoder sequence 785 -> long-sequence
+    attention path), B=1, bf16, against the oracle (fp32, host) on identical recipe inputs."""
+    from ecamp_amd.module import model_ecamp as me
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    torch.set_num_threads(16)
+    cfg = orc.cfg_large448()
+    B, S = 1, 64
+    state = recipe.recipe_state(cfg, seed=0)
+    batch = recipe.recipe_batch(cfg, B, S, seed=0)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=0)
+    P = orc.load_state(orc.new_params(cfg), state)
+    with torch.no_grad():
+        ref = [t.item() for t in orc.forward(P, cfg, batch, 0.75, noise)]
+    model = me.ecamp_large_448(compute_dtype=torch.bfloat16)
+    model.load_state_dict(state, strict=True)
+    model.to(dev).eval()
+    out = model(batch, noise=noise)
+    got = [t.item() for t in out]
+    print("ViT-L/448 bf16", got, "oracle", ref)
+    assert (np.abs(np.array(got) - np.array(ref)) / np.array(ref)).max() < 3e-2
+    sum(out).backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.isfinite(p.grad).all(), n
+    assert model.decoder_blocks[0].attn.qkv.weight.grad.abs().sum().item() > 0
