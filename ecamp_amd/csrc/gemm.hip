@@ -33,10 +33,13 @@ struct GemmArgs {
     int act;                // 0 none, 1 exact GELU
     int out_f32;            // C is f32 regardless of operand type
     int accumulate;         // C += result (requires an f32 output); exclusive ownership -> plain read-modify-write
+    float* rowsum;          // optional f32 [M]: rowsum[m] += alpha * sum_k opA[m,k]  (bias gradient inside the wgrad GEMM)
     float* partial;         // split-K: f32 slabs [gridDim.z][M*ldc-equivalent dense M x N] written with plain stores
     int k_per_split;        // multiple of the K tile; grid.z = number of splits
     int nbm, nbn;
     float alpha;            // result scale applied to the accumulator before the epilogue
+    float alpha_out;        // the caller's alpha / alpha_dev, kept for the row-sum even when split-K resets the tile's own scale
+    const float* alpha_dev_out;
     const float* alpha_dev; // optional device scalar multiplied into alpha (upstream loss gradient; avoids a host sync)
 };
 
@@ -158,7 +161,7 @@ __device__ __forceinline__ bf16x8 frag_kc(const unsigned char* lds, int row, int
     return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((ch ^ swz(row)) << 4));
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool ROWSUM>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int TILE_BYTES = 64 * OC_PITCH;  // >= BM*BK*2: one size fits both operand layouts
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
@@ -178,6 +181,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // bias gradient for free: blocks of the first N-tile column also multiply the M-side fragments by an all-ones fragment
+    // ROWSUM is a compile-time flag: its 16 extra accumulators would cost every other GEMM form a wave of occupancy
+    const bool do_rowsum = ROWSUM && g.rowsum != nullptr && (wg % g.nbn) == 0 && (wave & 1) == 0;
+    f32x4 accr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     uint4 ra_kc[4], rb_kc[4];
     uint4 ra_oc[4], rb_oc[4];
@@ -212,6 +223,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fn[tn]),
                         __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), acc[tm][tn], 0, 0, 0);
+            if (do_rowsum) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    accr[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ones),
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), accr[tm], 0, 0, 0);
+            }
         }
         __syncthreads();
         if (has_next) {
@@ -227,6 +245,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
             epilogue4<bf16_t>(g, m0 + wm + tm * 16 + lrow, n0 + wn + tn * 16 + 4 * lk, acc[tm][tn]);
+    if (do_rowsum && lk == 0) {  // every row of the ones-product is the same sum; lane (lk = 0, r = 0) owns column lrow
+        const float al = g.alpha_dev_out ? g.alpha_out * g.alpha_dev_out[0] : g.alpha_out;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            int m = m0 + wm + tm * 16 + lrow;
+            if (m < g.M) atomicAdd(g.rowsum + m, al * accr[tm][0]);
+        }
+    }
 }
 
 // =============================================================================================
@@ -270,7 +296,7 @@ __device__ __forceinline__ void f32_r2s(float* S, int tid, const float4 (&r)[2])
     }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool ROWSUM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float SA[FK * FP];
     __shared__ __attribute__((aligned(16))) float SB[FK * FP];
@@ -287,6 +313,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ROWSUM is a compile-time flag: its 16 extra accumulators would cost every other GEMM form a wave of occupancy
+    const bool do_rowsum = ROWSUM && g.rowsum != nullptr && (wg % g.nbn) == 0 && (wave & 1) == 0;
+    f32x4 accr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 ra[2], rb[2];
     f32_g2r<A_KC>(A, g.lda, m0, g.M, kbeg, kend, tid, ra);
@@ -316,6 +348,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fn[tn], fm[tm], acc[tm][tn], 0, 0, 0);
+            if (do_rowsum) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) accr[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, fm[tm], accr[tm], 0, 0, 0);
+            }
         }
         __syncthreads();
         if (has_next) {
@@ -329,6 +365,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
             epilogue4<float>(g, m0 + wm + tm * 16 + lrow, n0 + wn + tn * 16 + 4 * lk, acc[tm][tn]);
+    if (do_rowsum && lk == 0) {
+        const float al = g.alpha_dev_out ? g.alpha_out * g.alpha_dev_out[0] : g.alpha_out;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            int m = m0 + wm + tm * 16 + lrow;
+            if (m < g.M) atomicAdd(g.rowsum + m, al * accr[tm][0]);
+        }
+    }
 }
 
 // C[m,n] (+)= alpha * sum_z partial[z][m][n]   -- deterministic split-K combine (no f32 atomics: 16.5 M scattered
@@ -357,7 +401,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda,
                           int b_kc, int64_t ldb, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
                           void* pre_out, int64_t ldp, const void* gmul, int64_t ldg, int act, float alpha, const float* alpha_dev, int dtype,
-                          int out_f32, int accumulate, int split_k, float* splitk_ws, hipStream_t stream) {
+                          int out_f32, int accumulate, int split_k, float* splitk_ws, float* rowsum, hipStream_t stream) {
     ECAMP_CHECK_ARG(A && B && C, "ecamp_gemm: null operand");
     ECAMP_CHECK_ARG(M > 0 && N > 0 && K > 0, "ecamp_gemm: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
     ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "ecamp_gemm: bad dtype %d", dtype);
@@ -369,6 +413,7 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     if (b_kc) ECAMP_CHECK_ARG(K % vec == 0 && ldb % vec == 0, "ecamp_gemm: K/ldb alignment (B k-contiguous)");
     else ECAMP_CHECK_ARG(N % ovec == 0 && ldb % ovec == 0, "ecamp_gemm: N/ldb alignment (B n-contiguous)");
     ECAMP_CHECK_ARG(!accumulate || out_f32 || dtype == ECAMP_F32, "ecamp_gemm: accumulate needs an f32 output");
+    ECAMP_CHECK_ARG(!rowsum || (!a_kc && !b_kc), "ecamp_gemm: rowsum is built for the weight-gradient form (both operands strided) only");
     if (split_k < 1) split_k = 1;
     ECAMP_CHECK_ARG(split_k == 1 || (out_f32 || dtype == ECAMP_F32), "ecamp_gemm: split_k > 1 requires an f32 output");
     ECAMP_CHECK_ARG(split_k == 1 || splitk_ws, "ecamp_gemm: split_k > 1 requires a workspace of split_k*M*N floats");
@@ -381,6 +426,9 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.pre_out = pre_out; g.ldp = ldp; g.gmul = gmul; g.ldg = ldg;
     g.alpha = alpha;
     g.alpha_dev = alpha_dev;
+    g.alpha_out = alpha;
+    g.alpha_dev_out = alpha_dev;
+    g.rowsum = rowsum;
     g.act = act; g.out_f32 = (out_f32 || dtype == ECAMP_F32) ? 1 : 0; g.accumulate = accumulate;
     const int ktile = dtype == ECAMP_BF16 ? BK : FK;
     long kps = (K + split_k - 1) / split_k;
@@ -393,10 +441,11 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     dim3 grid(g.nbm * g.nbn, 1, split_k), block(256);
 #define LAUNCH(KERN)                                                             \
     do {                                                                         \
-        if (a_kc && b_kc) hipLaunchKernelGGL((KERN<true, true>), grid, block, 0, stream, g);        \
-        else if (a_kc && !b_kc) hipLaunchKernelGGL((KERN<true, false>), grid, block, 0, stream, g); \
-        else if (!a_kc && b_kc) hipLaunchKernelGGL((KERN<false, true>), grid, block, 0, stream, g); \
-        else hipLaunchKernelGGL((KERN<false, false>), grid, block, 0, stream, g);                   \
+        if (a_kc && b_kc) hipLaunchKernelGGL((KERN<true, true, false>), grid, block, 0, stream, g);        \
+        else if (a_kc && !b_kc) hipLaunchKernelGGL((KERN<true, false, false>), grid, block, 0, stream, g); \
+        else if (!a_kc && b_kc) hipLaunchKernelGGL((KERN<false, true, false>), grid, block, 0, stream, g); \
+        else if (rowsum) hipLaunchKernelGGL((KERN<false, false, true>), grid, block, 0, stream, g);        \
+        else hipLaunchKernelGGL((KERN<false, false, false>), grid, block, 0, stream, g);                   \
     } while (0)
     const bool prof = ecamp_prof_active();
     if (prof) ecamp_prof_begin(dtype == ECAMP_BF16 ? ECAMP_PROF_GEMM_BF16 : ECAMP_PROF_GEMM_F32, 2.0 * (double)M * (double)N * (double)K, stream);

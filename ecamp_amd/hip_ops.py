@@ -36,12 +36,12 @@ def ptr(t):
 
 # --------------------------------------------------------------------------------------------- gemm
 def gemm(A, B, C, M, N, K, a_kc, lda, b_kc, ldb, ldc, bias=None, residual=None, ldr=0, pre_out=None, ldp=0, gmul=None,
-         ldg=0, act=0, alpha=1.0, alpha_dev=None, out_f32=False, accumulate=False, split_k=1):
+         ldg=0, act=0, alpha=1.0, alpha_dev=None, out_f32=False, accumulate=False, split_k=1, rowsum=None):
     _chk(A, B, C)
     ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32) if split_k > 1 else None
     call("ecamp_gemm", ptr(A), ptr(B), ptr(C), M, N, K, int(a_kc), lda, int(b_kc), ldb, ldc, ptr(bias), ptr(residual), ldr,
          ptr(pre_out), ldp, ptr(gmul), ldg, int(act), float(alpha), ptr(alpha_dev), code(A.dtype), int(out_f32), int(accumulate), int(split_k),
-         ptr(ws), stream())
+         ptr(ws), ptr(rowsum), stream())
     return C
 
 
@@ -74,13 +74,13 @@ def _split_k(n_out, k_in, m):
     return max(1, min(s, (m + 255) // 256))
 
 
-def linear_wgrad(dy, x, gw, alpha=1.0, alpha_dev=None):
-    """gw[N,K] (f32, accumulated) += alpha * dy[M,N]^T @ x[M,K]."""
+def linear_wgrad(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None):
+    """gw[N,K] (f32, accumulated) += alpha * dy[M,N]^T @ x[M,K];  gb[N] (f32, accumulated) += alpha * sum_m dy[m,:] if given."""
     M, N = dy.shape
     K = x.shape[1]
     assert gw.dtype == torch.float32 and gw.is_contiguous() and gw.numel() == N * K
     gemm(dy, x, gw, N, K, M, False, dy.stride(0), False, x.stride(0), K, alpha=alpha, alpha_dev=alpha_dev, out_f32=True, accumulate=True,
-         split_k=_split_k(N, K, M))
+         split_k=_split_k(N, K, M), rowsum=gb)
 
 
 def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):

@@ -33,11 +33,13 @@ const char* ecamp_last_error(void);
  * Bert* dense layers (bert_modeling.py:113-131, context_fusion.py:32-72), MLM decoder (bert_modeling.py:209), and
  * their autograd dgrad/wgrad.  Epilogue: +bias[n]; save pre-activation; exact-erf GELU; *gelu'(gmul[m,n]);
  * +residual[m,n].  out_f32/accumulate: f32 output added into C (weight gradients).  split_k > 1: the contraction is cut
- * into slabs written to `splitk_ws` (split_k*M*N floats) and combined by a deterministic reduce kernel (no atomics). */
+ * into slabs written to `splitk_ws` (split_k*M*N floats) and combined by a deterministic reduce kernel (no atomics).
+ * rowsum (optional, f32 [M]): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient, computed inside the wgrad GEMM by one
+ * extra MFMA against an all-ones fragment instead of a separate pass over dY. */
 int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda, int b_kc,
                int64_t ldb, int64_t ldc, const float* bias, const void* residual, int64_t ldr, void* pre_out, int64_t ldp,
                const void* gmul, int64_t ldg, int act, float alpha, const float* alpha_dev, int dtype, int out_f32, int accumulate,
-               int split_k, float* splitk_ws, ecampStream_t stream);
+               int split_k, float* splitk_ws, float* rowsum, ecampStream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm eps 1e-6: model_ecamp.py:69,84,235,256 + timm Block norms; HF LN eps 1e-12:
  * BertSelfOutput/BertOutput/BertEmbeddings/transform).  y = LN(z), z = dropout(x) + residual (both optional). */

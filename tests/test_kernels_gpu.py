@@ -85,6 +85,10 @@ def test_gemm_dgrad_wgrad(dev, dtype, M, N, K):
     gb = torch.zeros(N, device=dev)
     o.colsum(dyd, gb, alpha=2.0)
     check("bias grad", gb, 2.0 * dy.sum(0), 2e-5 if dtype == torch.float32 else 1e-2)
+    gw2, gb2 = torch.zeros(N, K, device=dev), gen(N, seed=9).to(dev)
+    o.linear_wgrad(dyd, xd, gw2, alpha=0.5, gb=gb2)  # bias gradient fused into the wgrad GEMM (ones-fragment MFMA)
+    check("wgrad + fused bias grad (w)", gw2, 0.5 * (dy.T @ x), 2e-5 if dtype == torch.float32 else 1e-2)
+    check("wgrad + fused bias grad (b)", gb2, gen(N, seed=9) + 0.5 * dy.sum(0), 2e-5 if dtype == torch.float32 else 1e-2)
 
 
 def test_gemm_rejects_bad_alignment(dev):
