@@ -320,3 +320,45 @@ def adamw_grouped(p, g, m, v, p16, block_group, lrs, wds, beta1, beta2, eps, ste
     arr = ctypes.c_float * n
     call("ecamp_adamw_grouped", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), ptr(block_group), p.numel(), n, arr(*lrs), arr(*wds),
          float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream())
+
+
+# --------------------------------------------------------------------------------------------- side-stream weight gradients
+# Weight gradients are leaves of the backward dependency graph: nothing in backward waits for them.  Launching them on a
+# second HIP stream lets their workgroups fill the tail-quantisation gaps of the dgrad / attention / LayerNorm kernels on the
+# main stream (and vice versa).  The main stream re-joins at the end of backward (autograd engine callback).
+OVERLAP_WGRAD = True
+_side = {}
+
+
+def side_stream(device):
+    st = _side.get(device)
+    if st is None:
+        st = _side[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _join_side():
+    dev = torch.cuda.current_device()
+    st = _side.get(torch.device("cuda", dev))
+    if st is not None:
+        torch.cuda.current_stream().wait_stream(st)
+    _side["cb"] = False
+
+
+def linear_wgrad_async(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None):
+    if not OVERLAP_WGRAD:
+        return linear_wgrad(dy, x, gw, alpha, alpha_dev, gb)
+    st = side_stream(dy.device)
+    st.wait_stream(torch.cuda.current_stream())  # dy, x (and earlier accumulations into gw) are ready
+    with torch.cuda.stream(st):
+        linear_wgrad(dy, x, gw, alpha, alpha_dev, gb)
+    dy.record_stream(st)  # the caching allocator must not recycle these while the side stream reads them
+    x.record_stream(st)
+    if alpha_dev is not None:
+        alpha_dev.record_stream(st)
+    if not _side.get("cb"):
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+            _side["cb"] = True
+        except RuntimeError:  # not inside a backward pass: join immediately
+            _join_side()

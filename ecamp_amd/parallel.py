@@ -59,6 +59,10 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
+            from . import hip_ops  # weight gradients may still be running on the wgrad side stream
+            wst = hip_ops._side.get(self.flat_g.device)
+            if wst is not None:
+                self.side.wait_stream(wst)
             with torch.cuda.stream(self.side):
                 w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
         else:
