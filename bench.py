@@ -119,9 +119,6 @@ def main():
     for _ in range(args.warmup):
         out = step()
     lib = _lib.load()
-    if not args.no_prof:
-        lib.ecamp_prof_collect(-1, None, None, None)
-        lib.ecamp_prof_enable(1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -132,8 +129,26 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    lib.ecamp_prof_enable(0)
     losses = [float(t.detach()) for t in out[:3]]
+    # Roofline pass (not part of `value`): the same step, with the weight-gradient GEMMs back on the main stream so that every
+    # launch runs alone and its HIP-event duration is its own (in the timed region above they overlap the dgrad chain on a side
+    # stream, which makes the step faster but per-launch durations meaningless).
+    from ecamp_amd import hip_ops
+    prof_steps = 0
+    if not args.no_prof:  # every rank runs it (the steps contain collectives)
+        hip_ops.OVERLAP_WGRAD = False
+        step()
+        torch.cuda.synchronize()
+        lib.ecamp_prof_collect(-1, None, None, None)
+        lib.ecamp_prof_enable(1)
+        prof_steps = min(args.steps, 3)
+        tp = time.perf_counter()
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        serial_ms = 1e3 * (time.perf_counter() - tp) / prof_steps
+        lib.ecamp_prof_enable(0)
+        hip_ops.OVERLAP_WGRAD = True
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,12 +174,15 @@ def main():
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": None, "kernel": "gemm_%s_kernel" % ("bf16" if args.dtype == "bf16" else "f32"),
-                               "launches_per_step": n.value // max(args.steps, 1),
+                               "launches_per_step": n.value // max(prof_steps, 1),
                                "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2),
                                "algorithmic_gflop_per_launch": round(fl.value / max(n.value, 1) / 1e9, 3),
-                               "gemm_ms_per_step": round(ms.value / args.steps, 3),
-                               "attention_ms_per_step": round(ams.value / args.steps, 3),
-                               "note": "achieved = sum(2MNK) of every GEMM launch in the timed region / sum of their HIP-event durations"}
+                               "gemm_ms_per_step": round(ms.value / prof_steps, 3),
+                               "attention_ms_per_step": round(ams.value / prof_steps, 3),
+                               "serialized_ms_per_step": round(serial_ms, 3),
+                               "note": "achieved = sum(2MNK) over every GEMM launch / sum of their HIP-event durations, taken in a "
+                                       "serialized pass of the same step (%d steps, wgrad GEMMs on the main stream); `value` is timed on the "
+                                       "production path where wgrad GEMMs overlap the dgrad chain on a side stream" % prof_steps}
             # whole-step view with SURVEY.md 8(d)'s algorithmic FLOPs per pair
             gflop_pair = 88.99 if args.seq == 128 else 136.64
             res["roofline"]["whole_step_tflops"] = round(gflop_pair * 1e9 * args.batch / (dt / args.steps) / 1e12, 2)
