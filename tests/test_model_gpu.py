@@ -215,3 +215,32 @@ def test_vit_large_448_bf16_matches_oracle(dev):
         if p.requires_grad:
             assert torch.isfinite(p.grad).all(), n
     assert model.decoder_blocks[0].attn.qkv.weight.grad.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("B,S,mask_ratio", [(1, 37, 0.75), (3, 200, 0.5), (2, 256, 0.9)])
+def test_ragged_shapes_fp32_match_oracle(dev, B, S, mask_ratio):
+    """Ragged inputs: a batch of one, report lengths that are not multiples of anything (37, 200), the maximum length (256),
+    other mask ratios -- fp32 parity mode against the oracle run live on the host."""
+    from ecamp_amd.module import model_ecamp as me
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    torch.set_num_threads(16)
+    cfg = orc.cfg_tiny()
+    state = recipe.recipe_state(cfg, seed=0)
+    batch = recipe.recipe_batch(cfg, B, S, seed=7)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=7)
+    P = orc.set_requires_grad(orc.load_state(orc.new_params(cfg), state), cfg)
+    ref = orc.forward(P, cfg, batch, mask_ratio, noise)
+    sum(ref).backward()
+    model = me.ecamp_tiny(compute_dtype=torch.float32)
+    model.load_state_dict(state)
+    model.to(dev).eval()
+    out = model(batch, mask_ratio=mask_ratio, noise=noise)
+    sum(out).backward()
+    for a, b in zip(out, ref):
+        assert abs(a.item() - b.item()) / abs(b.item()) < 2e-4, (a.item(), b.item())
+    for n in ("blocks.5.mlp.fc1.weight", "decoder_blocks.1.attn.qkv.bias", "mask_token", "bert_encoder.model.bert.embeddings.position_embeddings.weight",
+              "bert_encoder.model.bert.context_fusion_layer.cross_self_attention.value.weight", "bert_encoder.model.cls.predictions.decoder.weight"):
+        g, gr = dict(model.named_parameters())[n].grad.float().cpu(), P[n].grad
+        err = (g - gr).norm().item() / (gr.norm().item() + 1e-12)
+        assert err < 1e-3, (n, err)
