@@ -462,13 +462,14 @@ __global__ __launch_bounds__(256) void attn16r_fwd_kernel(AttnArgs a) {
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     unsigned char* pt = PT + wave * 2048;
-    bool kok[KCH * 4][4];
+    unsigned long long kok = 0ull;  // bit (t*4 + r): key t*16 + 4g + r is attended (one register pair instead of a spilled bool array)
 #pragma unroll
     for (int t = 0; t < KCH * 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int j = t * 16 + 4 * g + r;
-            kok[t][r] = j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
+            bool ok = j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
+            kok |= (unsigned long long)(ok ? 1 : 0) << (t * 4 + r);
         }
     for (int q0 = wave * 16; q0 < a.Tq; q0 += 64) {
         bf16x8 qf[HD / 32];
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256) void attn16r_fwd_kernel(AttnArgs a) {
         for (int t = 0; t < KCH * 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[t][r] = kok[t][r] ? s[t][r] * a.scale : NEG_BIG;
+                s[t][r] = ((kok >> (t * 4 + r)) & 1ull) ? s[t][r] * a.scale : NEG_BIG;
                 mx = fmaxf(mx, s[t][r]);
             }
         mx = red4_max(mx);
@@ -730,7 +731,9 @@ static void lds_optin(K kern, size_t bytes) {
 // =============================================================================================
 template <int HD>
 static void fwd16(const AttnArgs& a, hipStream_t st) {
-    if (a.Tk > 256) {
+    // Tk > 128: the all-scores-in-registers kernels need 64 score registers per lane and spill (272 B/lane of scratch at 4 chunks);
+    // the online-softmax kernel keeps one chunk of scores live and is faster from 129 keys up (decoder T=197, S=256, ViT-L T=785)
+    if (a.Tk > 128) {
         dim3 grid(ceil_div(a.Tq, 64), a.B * a.H);
         hipLaunchKernelGGL((attn16_fwd_long_kernel<HD>), grid, dim3(256), (size_t)2 * TileCfg<HD>::BYTES + 4 * 2048, st, a);
         return;
