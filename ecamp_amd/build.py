@@ -51,6 +51,8 @@ def build(force=False, verbose=True):
                     print("[ecamp_amd.build] hipcc %s -> rc %d" % (os.path.basename(src), rc), flush=True)
                 if rc != 0:
                     raise RuntimeError("hipcc failed on %s:\n%s" % (src, err))
+                if verbose and "warning:" in err:  # e.g. "loop not unrolled": an accumulator array indexed at run time lives in scratch
+                    print(err, flush=True)
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)

@@ -60,8 +60,8 @@ __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[HD / 32], const bf16_
 // per-wave 16 x 64 bf16 tile (P or dS), 128-B rows, 16-B chunks XOR-swizzled by row
 __device__ __forceinline__ void ptile_write4(unsigned char* t, int row, int col0, const float (&v)[4]) {
     uint2 u;
-    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    u.x = pack_bf16x2(v[0], v[1]);
+    u.y = pack_bf16x2(v[2], v[3]);
     int chunk = col0 >> 3;
     *reinterpret_cast<uint2*>(t + row * 128 + ((chunk ^ (row & 7)) << 4) + (col0 & 7) * 2) = u;
 }
@@ -78,8 +78,8 @@ __device__ __forceinline__ float red4_sum(float v) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, f32x4 v, float mul) {
     uint2 u;
-    u.x = (uint32_t)f2bf(v[0] * mul) | ((uint32_t)f2bf(v[1] * mul) << 16);
-    u.y = (uint32_t)f2bf(v[2] * mul) | ((uint32_t)f2bf(v[3] * mul) << 16);
+    u.x = pack_bf16x2(v[0] * mul, v[1] * mul);
+    u.y = pack_bf16x2(v[2] * mul, v[3] * mul);
     *reinterpret_cast<uint2*>(p) = u;
 }
 

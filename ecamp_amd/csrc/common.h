@@ -28,11 +28,13 @@ int ecamp_set_error(int code, const char* fmt, ...);
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// f32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per instruction);
+// the integer emulation it replaces cost ~8 VALU operations per value and dominated the GEMM epilogues
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((hw_f32x2){lo, hi}, hw_bf16x2));
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
@@ -61,8 +63,8 @@ template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o
 }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&o)[4]) {
     uint2 v;
-    v.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-    v.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    v.x = pack_bf16x2(o[0], o[1]);
+    v.y = pack_bf16x2(o[2], o[3]);
     *reinterpret_cast<uint2*>(p) = v;
 }
 

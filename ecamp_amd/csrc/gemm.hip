@@ -16,6 +16,8 @@
 // and the epilogue stores 8 B (bf16) / 16 B (f32) per lane instead of scattered 2-B stores.
 // f32 path (parity mode): same tiling with BK=16 on v_mfma_f32_16x16x4_f32 (exact f32 fma chain).
 #include "common.h"
+#include <stdlib.h>
+#include <stdint.h>
 
 struct GemmArgs {
     const void* A;
@@ -41,6 +43,9 @@ struct GemmArgs {
     float alpha_out;        // the caller's alpha / alpha_dev, kept for the row-sum even when split-K resets the tile's own scale
     const float* alpha_dev_out;
     const float* alpha_dev; // optional device scalar multiplied into alpha (upstream loss gradient; avoids a host sync)
+    int dbg;                // development switches of the P8 kernel (ECAMP_P8_DBG); 0 in production
+    int wide;               // every [M, ld] epilogue operand is 16-B aligned at 8-column granularity (P8's 16-B epilogue)
+    int nsplit;             // P8: number of split-K slices (the persistent kernel walks tiles x slices itself)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -51,7 +56,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 template <typename T>
-__device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n0, f32x4 acc) {
+__device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n0, f32x4 acc, int z) {
     if (m >= g.M || n0 >= g.N) return;
     const float al = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
     float v[4] = {acc[0] * al, acc[1] * al, acc[2] * al, acc[3] * al};
@@ -77,7 +82,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n0, f32x
         for (int r = 0; r < 4; ++r) v[r] += p[r];
     }
     if (g.partial) {  // split-K slab of this z-slice: reduced (and scaled / accumulated) by splitk_reduce_kernel
-        st4<float>(g.partial + ((long)blockIdx.z * g.M + m) * g.N + n0, v);
+        st4<float>(g.partial + ((long)z * g.M + m) * g.N + n0, v);
     } else if (g.out_f32) {
         float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n0;
         if (g.accumulate) {  // each output element is owned by exactly one thread of one block: no atomics needed
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
-            epilogue4<bf16_t>(g, m0 + wm + tm * 16 + lrow, n0 + wn + tn * 16 + 4 * lk, acc[tm][tn]);
+            epilogue4<bf16_t>(g, m0 + wm + tm * 16 + lrow, n0 + wn + tn * 16 + 4 * lk, acc[tm][tn], blockIdx.z);
     if (do_rowsum && lk == 0) {  // every row of the ones-product is the same sum; lane (lk = 0, r = 0) owns column lrow
         const float al = g.alpha_dev_out ? g.alpha_out * g.alpha_dev_out[0] : g.alpha_out;
 #pragma unroll
@@ -253,6 +258,337 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
             if (m < g.M) atomicAdd(g.rowsum + m, al * accr[tm][0]);
         }
     }
+}
+
+// =============================================================================================
+// "P8": persistent 256x256-tile kernel, 8 waves (2 x 4) of 128x64, one workgroup per CU, for GEMMs with enough tiles to fill
+// the chip.  Measured on MI355X the operand stream L2 -> LDS tops out near 12.5 TB/s (~21 B/clk/CU): the 128^2 kernel above
+// moves 2 x 128 x K operand bytes per 128^2 outputs and sits on that roof; a 256^2 tile halves the bytes per flop.
+//  * Operands arrive by direct L2 -> LDS DMA (global_load_lds_dwordx4) into a 4-stage ring of K=32 tiles (32 KB per stage).
+//    The ring is ONE flat stream of K tiles over all the output tiles a workgroup processes: the DMA cursor runs three K tiles
+//    ahead of the MFMAs and simply moves on to the next output tile, so the next tile's first operands are already in LDS
+//    while the current tile's epilogue stores drain (with one resident workgroup per CU nothing else would hide them).
+//  * A DMA is issued in four pieces BETWEEN the MFMA groups of a K tile (an issue blocks the wave while the texture path is
+//    busy; the SIMD's other wave keeps the matrix pipe fed) and is only ever waited for with a COUNTED s_waitcnt vmcnt(8|4|0)
+//    followed by one raw s_barrier per K tile.  Stores and epilogue loads also count in vmcnt on gfx9; loads retire in order,
+//    so "at most 8 outstanding" still implies "this K tile's four DMAs have landed" -- the wait is conservative, never early.
+//  * LDS images are DMA-linear, so the bank swizzles are applied to each lane's SOURCE address (kc: 64-B rows, 16-B chunk ^
+//    key(row); strided: 512-B rows, 32-B unit ^ key(k-row)) and again on the fragment reads.
+//  * Fragment row i of the N-side operand is mapped to output column (i>>2)*8 + (tn&1)*4 + (i&3) of a 32-column group, so
+//    after the MFMA (N fragment as the A operand: a lane owns 4 consecutive D rows = columns) a lane holds 8 CONSECUTIVE
+//    output columns over two accumulators and every epilogue access is 16 B per lane.
+// =============================================================================================
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+#define P8_STAGE_BYTES 32768
+#define GLDS16(SRC, DST) \
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(SRC), (void __attribute__((address_space(3)))*)(DST), 16, 0, 0)
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&o)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&o)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&o)[8]) {
+    uint4 v;
+    v.x = pack_bf16x2(o[0], o[1]);
+    v.y = pack_bf16x2(o[2], o[3]);
+    v.z = pack_bf16x2(o[4], o[5]);
+    v.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(p) = v;
+}
+
+// one output tile (and split-K slice) of the persistent kernel; every field is wave-uniform
+struct P8Item {
+    int m0, n0, kbeg, kend, nt, z, ncol;
+};
+__device__ __forceinline__ P8Item p8_decode(const GemmArgs& g, int v, int total) {
+    const unsigned f = (unsigned)xcd_remap(v, total), ntile = (unsigned)(g.nbm * g.nbn);
+    const unsigned z = f / ntile, tile = f - z * ntile, mb = tile / (unsigned)g.nbn, nb = tile - mb * (unsigned)g.nbn;
+    P8Item it;
+    it.m0 = (int)mb * 256; it.n0 = (int)nb * 256; it.z = (int)z; it.ncol = (int)nb;
+    it.kbeg = (int)z * g.k_per_split;
+    it.kend = min(g.K, it.kbeg + g.k_per_split);
+    it.nt = (it.kend - it.kbeg + 31) >> 5;
+    return it;
+}
+
+// Rows mbase + 16*i (i < NM), columns n0 + 32*h + [0, 8) (h < 2): NM*2 groups of 8 consecutive outputs per lane.
+// All loads of the batch (gelu' operand, residual, old f32 value) are issued before the first store: written group by group,
+// every load would wait behind the previous group's store (they may alias as far as the compiler knows) and the epilogue
+// would be serialised on memory latency.
+template <int TM0, int NM>
+__device__ __forceinline__ void p8_epilogue_rows(const GemmArgs& g, const f32x4 (&acc)[8][4], int mbase, int n0, int z,
+                                                 const float (&bias)[2][8]) {
+    if (!g.wide || n0 + 40 > g.N) {   // ragged / unaligned: 4-column pieces
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                epilogue4<bf16_t>(g, mbase + i * 16, n0 + (tn >> 1) * 32 + (tn & 1) * 4, acc[TM0 + i][tn], z);
+        return;
+    }
+    const float al = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+    const bf16_t* gm = reinterpret_cast<const bf16_t*>(g.gmul);
+    const bf16_t* rs = reinterpret_cast<const bf16_t*>(g.residual);
+    const bool acc_old = !g.partial && g.out_f32 && g.accumulate;
+    uint4 qg[NM][2], qr[NM][2];
+    if (gm) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m = min(mbase + i * 16, g.M - 1);
+                qg[i][h] = *reinterpret_cast<const uint4*>(gm + (long)m * g.ldg + n0 + h * 32);
+            }
+    }
+    if (rs) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m = min(mbase + i * 16, g.M - 1);
+                qr[i][h] = *reinterpret_cast<const uint4*>(rs + (long)m * g.ldr + n0 + h * 32);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NM; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = mbase + i * 16, n = n0 + h * 32;
+            if (m >= g.M) continue;
+            const f32x4 a0 = acc[TM0 + i][2 * h], a1 = acc[TM0 + i][2 * h + 1];
+            float v[8] = {a0[0] * al, a0[1] * al, a0[2] * al, a0[3] * al, a1[0] * al, a1[1] * al, a1[2] * al, a1[3] * al};
+            if (g.bias) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += bias[h][r];
+            }
+            if (g.pre_out) st8<bf16_t>(reinterpret_cast<bf16_t*>(g.pre_out) + (long)m * g.ldp + n, v);
+            if (g.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = gelu_f(g.pre_out ? rnd<bf16_t>(v[r]) : v[r]);
+            }
+            if (gm) {
+                const uint32_t w[4] = {qg[i][h].x, qg[i][h].y, qg[i][h].z, qg[i][h].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[2 * r] *= gelu_grad_f(__uint_as_float(w[r] << 16));
+                    v[2 * r + 1] *= gelu_grad_f(__uint_as_float(w[r] & 0xffff0000u));
+                }
+            }
+            if (rs) {
+                const uint32_t w[4] = {qr[i][h].x, qr[i][h].y, qr[i][h].z, qr[i][h].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[2 * r] += __uint_as_float(w[r] << 16);
+                    v[2 * r + 1] += __uint_as_float(w[r] & 0xffff0000u);
+                }
+            }
+            if (g.partial) {
+                st8<float>(g.partial + ((long)z * g.M + m) * g.N + n, v);
+            } else if (g.out_f32) {
+                float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n;
+                if (acc_old) {
+                    float o[8];
+                    ld8<float>(c, o);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += o[r];
+                }
+                st8<float>(c, v);
+            } else {
+                st8<bf16_t>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n, v);
+            }
+        }
+}
+
+// bank keys.  kc tiles (64-B rows, 4 rows per 256-B bank row): a ds_read_b128 lane group holds the fragment rows {0-3, 12-15}
+// at chunk c and {4-11} at chunk c^1, so the key must differ per 4-row group: (-(row >> KS)) & 3 with KS = 2 for the M side
+// (consecutive rows) and KS = 3 for the N side (whose 4-row groups lie 8 rows apart, see the column remap above).
+template <int KS> __device__ __forceinline__ int p8_kc_key(int row) { return (0 - (row >> KS)) & 3; }
+__device__ __forceinline__ int p8_key(int row) { return (row & 7) ^ (((row >> 3) & 1) << 2); }
+
+// one DMA piece = 512 lanes x 16 B = 8 KB = half an operand tile; i in {0, 1}
+template <int KS>
+__device__ __forceinline__ void p8_dma_kc(const bf16_t* P, long ld, int row0, int nrows, int k0, int kend, unsigned char* tile, int i,
+                                          int wave, int lane) {
+    const long zoff = reinterpret_cast<const bf16_t*>(g_zero16) - P;  // element offset from P to the 16-B zero word
+    int c = (i * 8 + wave) * 64 + lane;               // 1024 chunks of 16 B: row = c>>2 (256 rows), 4 chunks per 64-B row
+    int row = c >> 2, kc = (c & 3) ^ p8_kc_key<KS>(row);
+    int gr = min(row0 + row, nrows - 1), gk = k0 + kc * 8;
+    // one DMA instruction per lane whatever the predicate (a ?: between two pointers compiles to two exec-masked DMAs)
+    const long off = gk < kend ? (long)gr * ld + gk : zoff;
+    GLDS16(P + off, tile + (i * 8 + wave) * 1024);
+}
+__device__ __forceinline__ void p8_dma_oc(const bf16_t* P, long ld, int row0, int nrows, int k0, int kend, unsigned char* tile, int i,
+                                          int wave, int lane) {
+    const long zoff = reinterpret_cast<const bf16_t*>(g_zero16) - P;
+    int c = (i * 8 + wave) * 64 + lane;               // 32 k-rows x 32 chunks (512-B rows)
+    int kr = c >> 5, oc = (c & 31) ^ (p8_key(kr) << 1);
+    int gk = k0 + kr, gr = min(row0 + oc * 8, nrows - 8);
+    const long off = gk < kend ? (long)gk * ld + gr : zoff;
+    GLDS16(P + off, tile + (i * 8 + wave) * 1024);
+}
+template <int KS>
+__device__ __forceinline__ bf16x8 p8_frag_kc(const unsigned char* tile, int row, int lk) {
+    return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((lk ^ p8_kc_key<KS>(row)) << 4));
+}
+// 16 outputs x 32 k from a strided tile: lane i = 4r+q of a 16-lane group supplies 4 outputs at o0 + q*QS (QS = 4: 16
+// consecutive outputs; QS = 8: the N-side column remap, 2-way bank conflicts accepted -- LDS is not the bottleneck), k-row r
+template <int QS>
+__device__ __forceinline__ bf16x8 p8_frag_oc(const unsigned char* tile, int o0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int r0 = g * 8 + (i >> 2), r1 = r0 + 4;
+    const int col = o0 + (i & 3) * QS, ch = col >> 3, within = (col & 7) * 2;
+    const unsigned char* p0 = tile + r0 * 512 + ((ch ^ (p8_key(r0) << 1)) << 4) + within;
+    const unsigned char* p1 = tile + r1 * 512 + ((ch ^ (p8_key(r1) << 1)) << 4) + within;
+    v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p0));
+    v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p1));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <bool A_KC, bool B_KC, bool ROWSUM>
+__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 stages x {A 16 KB, B 16 KB}; the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = g.nbm * g.nbn * g.nsplit, G = (int)gridDim.x;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int nrow = (lrow >> 2) * 8 + (lrow & 3);   // N-side fragment row -> column within a 32-column group (+ (tn&1)*4)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient inside the weight-gradient GEMM: the first wave column of the first N-tile column also multiplies its
+    // M-side fragments by an all-ones fragment (compile-time flag: 32 more accumulator registers)
+    f32x4 accr[ROWSUM ? 8 : 1];
+#pragma unroll
+    for (int i = 0; i < (ROWSUM ? 8 : 1); ++i) accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+    // ---- DMA cursor: (output tile pit, K tile pt of it), stream position pg (ring stage = pg & 3)
+    int pv = (int)blockIdx.x;
+    P8Item pit = p8_decode(g, pv, total);
+    int pt = 0, pg = 0;
+    bool pdone = false;
+#define P8_PIECE(PC)                                                                                                \
+    do {                                                                                                            \
+        unsigned char* sA_ = lds + (pg & 3) * P8_STAGE_BYTES;                                                        \
+        unsigned char* sB_ = sA_ + 16384;                                                                           \
+        const int k0_ = pit.kbeg + pt * 32;                                                                         \
+        if ((PC) < 2) {                                                                                             \
+            if (A_KC) p8_dma_kc<2>(A, g.lda, pit.m0, g.M, k0_, pit.kend, sA_, (PC), wave, lane);                     \
+            else p8_dma_oc(A, g.lda, pit.m0, g.M, k0_, pit.kend, sA_, (PC), wave, lane);                             \
+        } else {                                                                                                    \
+            if (B_KC) p8_dma_kc<3>(B, g.ldb, pit.n0, g.N, k0_, pit.kend, sB_, (PC) - 2, wave, lane);                 \
+            else p8_dma_oc(B, g.ldb, pit.n0, g.N, k0_, pit.kend, sB_, (PC) - 2, wave, lane);                         \
+        }                                                                                                           \
+    } while (0)
+#define P8_ADVANCE()                                                                                                \
+    do {                                                                                                            \
+        ++pg;                                                                                                       \
+        if (++pt == pit.nt) {                                                                                       \
+            pt = 0;                                                                                                 \
+            pv += G;                                                                                                \
+            if (pv < total) pit = p8_decode(g, pv, total); else pdone = true;                                       \
+        }                                                                                                           \
+    } while (0)
+
+    // prologue: up to three K tiles in flight
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i)
+        if (!pdone) {
+            P8_PIECE(0); P8_PIECE(1); P8_PIECE(2); P8_PIECE(3);
+            P8_ADVANCE();
+        }
+
+    int cg = 0;
+    for (int cv = (int)blockIdx.x; cv < total; cv += G) {
+        const P8Item cit = p8_decode(g, cv, total);
+        const bool do_rowsum = ROWSUM && g.rowsum != nullptr && cit.ncol == 0 && (wave & 3) == 0;
+        for (int t = 0; t < cit.nt; ++t, ++cg) {
+            // this K tile's DMAs have landed (mine); the younger tiles stay in flight
+            const int ahead = pg - cg - 1;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // ... everyone's have, and everyone is done reading K tile cg-1
+            const unsigned char* sA = lds + (cg & 3) * P8_STAGE_BYTES;
+            const unsigned char* sB = sA + 16384;
+            const bool more = !pdone;
+            bf16x8 fm[8], fn[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = wn + (i >> 1) * 32 + (i & 1) * 4;
+                fn[i] = B_KC ? p8_frag_kc<3>(sB, o + nrow, lk) : p8_frag_oc<8>(sB, o, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fm[i] = A_KC ? p8_frag_kc<2>(sA, wm + i * 16 + lrow, lk) : p8_frag_oc<4>(sA, wm + i * 16, lane);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+                for (int tm = 2 * grp; tm < 2 * grp + 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fn[tn]),
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(grp);                     // refill the stage K tile cg-1 vacated, one piece per MFMA group
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ROWSUM && do_rowsum) {
+#pragma unroll
+                for (int tm = 0; tm < 8; ++tm)
+                    accr[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ones),
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), accr[tm], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (more) P8_ADVANCE();
+        }
+        // ---- epilogue of this output tile (the DMA cursor is already up to three K tiles into the next one)
+        if (!(g.dbg & 4)) {
+            const int nb = cit.n0 + wn + lk * 8;
+            float bias[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) bias[h][r] = 0.f;
+            if (g.bias && g.wide && nb + 40 <= g.N) {
+                ld8<float>(g.bias + nb, bias[0]);
+                ld8<float>(g.bias + nb + 32, bias[1]);
+            }
+            p8_epilogue_rows<0, 4>(g, acc, cit.m0 + wm + lrow, nb, cit.z, bias);
+            p8_epilogue_rows<4, 4>(g, acc, cit.m0 + wm + 64 + lrow, nb, cit.z, bias);
+            if (ROWSUM && do_rowsum && lk == 0) {  // every row of the ones-product is the same sum; lane (lk = 0, r = 0) owns column lrow
+                const float al = g.alpha_dev_out ? g.alpha_out * g.alpha_dev_out[0] : g.alpha_out;
+#pragma unroll
+                for (int tm = 0; tm < 8; ++tm) {
+                    int m = cit.m0 + wm + tm * 16 + lrow;
+                    if (m < g.M) atomicAdd(g.rowsum + m, al * accr[tm][0]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ROWSUM) {
+#pragma unroll
+            for (int i = 0; i < (ROWSUM ? 8 : 1); ++i) accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#undef P8_PIECE
+#undef P8_ADVANCE
 }
 
 // =============================================================================================
@@ -364,7 +700,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
-            epilogue4<float>(g, m0 + wm + tm * 16 + lrow, n0 + wn + tn * 16 + 4 * lk, acc[tm][tn]);
+            epilogue4<float>(g, m0 + wm + tm * 16 + lrow, n0 + wn + tn * 16 + 4 * lk, acc[tm][tn], blockIdx.z);
     if (do_rowsum && lk == 0) {
         const float al = g.alpha_dev_out ? g.alpha_out * g.alpha_dev_out[0] : g.alpha_out;
 #pragma unroll
@@ -398,6 +734,57 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 // =============================================================================================
 // host entry
 // =============================================================================================
+// ---- kernel selection ------------------------------------------------------------------------------------------
+// ECAMP_GEMM_P8: unset = automatic, 0 = never, 2 = always (development).  Automatic: the persistent 256^2 kernel takes the
+// forward (both operands contraction-contiguous) and weight-gradient (both strided) forms when there are enough 256^2 work
+// items to give ~every CU one; the data-gradient form stays on the 128^2 kernel, which measured equal or better there.
+static int p8_env() {
+    static const int v = getenv("ECAMP_GEMM_P8") ? atoi(getenv("ECAMP_GEMM_P8")) : -1;
+    return v;
+}
+static int p8_num_cu() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+static bool p8_selected(int64_t M, int64_t N, int a_kc, int b_kc, int dtype, int split_k) {
+    const int env = p8_env();
+    if (dtype != ECAMP_BF16 || env == 0) return false;
+    if (env == 2) return true;
+    const long items = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
+    return (a_kc != 0) == (b_kc != 0) && items >= (long)(0.75 * p8_num_cu());
+}
+
+extern "C" int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype) {
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    const int ncu = p8_num_cu();
+    // 128^2 kernel: about four resident workgroups per CU
+    const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    long s_old = 1024 / tiles;
+    if (s_old < 1) s_old = 1;
+    const long cap = (K + 255) / 256;
+    if (s_old > cap) s_old = cap;
+    if (dtype != ECAMP_BF16 || p8_env() == 0 || (a_kc != 0) != (b_kc != 0)) return (int)s_old;
+    // persistent 256^2 kernel: one workgroup per CU walks the work items; pick the split count whose item count fills whole
+    // rounds of the chip, preferring fewer splits (each split writes and re-reads an M x N f32 slab)
+    const long t8 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    int best = 1;
+    double best_score = -1.0;
+    for (int sp = 1; sp <= 32; ++sp) {
+        if (sp > 1 && K / sp < 512) break;
+        const long items = t8 * sp;
+        const long rounds = (items + ncu - 1) / ncu;
+        const double score = (double)items / (double)(rounds * ncu) - 0.012 * (sp - 1);
+        if (score > best_score + 1e-9) { best_score = score; best = sp; }
+    }
+    if (!p8_selected(M, N, a_kc, b_kc, dtype, best)) return (int)s_old;
+    return best;
+}
+
 extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda,
                           int b_kc, int64_t ldb, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
                           void* pre_out, int64_t ldp, const void* gmul, int64_t ldg, int act, float alpha, const float* alpha_dev, int dtype,
@@ -420,6 +807,7 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     ECAMP_CHECK_ARG(split_k == 1 || (!bias && !residual && !pre_out && !gmul && !act), "ecamp_gemm: split-K has no epilogue");
 
     GemmArgs g;
+    g.dbg = 0; g.wide = 0; g.nsplit = 1;
     g.A = A; g.B = B; g.C = C;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -439,6 +827,51 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     if (split_k > 1) { g.alpha = 1.0f; g.alpha_dev = nullptr; }
     g.nbm = ceil_div(M, BM); g.nbn = ceil_div(N, BN);
     dim3 grid(g.nbm * g.nbn, 1, split_k), block(256);
+    if (p8_selected(M, N, a_kc, b_kc, dtype, split_k)) {
+        const int nbm8 = ceil_div(M, 256), nbn8 = ceil_div(N, 256);
+        {
+            g.nbm = nbm8; g.nbn = nbn8;
+            static const int p8_dbg = getenv("ECAMP_P8_DBG") ? atoi(getenv("ECAMP_P8_DBG")) : 0;
+            g.dbg = p8_dbg;
+            long kps8 = ((long)g.k_per_split + 31) / 32 * 32;
+            g.k_per_split = (int)kps8;
+            auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+            g.wide = (ldc % 8 == 0 || g.partial) && al16(C) && (!pre_out || (ldp % 8 == 0 && al16(pre_out))) &&
+                     (!gmul || (ldg % 8 == 0 && al16(gmul))) && (!residual || (ldr % 8 == 0 && al16(residual))) && (!bias || al16(bias)) &&
+                     (!g.partial || (N % 4 == 0 && al16(g.partial)));
+            g.nsplit = split_k;
+            const int ncu = p8_num_cu();
+            const long total8 = (long)nbm8 * nbn8 * split_k;
+            dim3 grid8((unsigned)(total8 < ncu ? total8 : ncu), 1, 1);
+            const size_t shm8 = 4 * P8_STAGE_BYTES;
+            static bool once8 = false;
+            if (!once8) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
+                once8 = true;
+            }
+            const bool prof8 = ecamp_prof_active();
+            if (prof8) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream);
+            if (rowsum) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, true>), grid8, dim3(512), shm8, stream, g);
+            else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, true, false>), grid8, dim3(512), shm8, stream, g);
+            else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, false, false>), grid8, dim3(512), shm8, stream, g);
+            else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, true, false>), grid8, dim3(512), shm8, stream, g);
+            else hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, false>), grid8, dim3(512), shm8, stream, g);
+            if (split_k > 1) {
+                long n4 = M * N / 4;
+                int nb = (int)((n4 + 255) / 256);
+                if (nb > 2048) nb = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, splitk_ws, reinterpret_cast<float*>(C), (long)M, (long)N,
+                                   (long)ldc, split_k, alpha, alpha_dev, accumulate);
+            }
+            if (prof8) ecamp_prof_end(stream);
+            ECAMP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define LAUNCH(KERN)                                                             \
     do {                                                                         \
         if (a_kc && b_kc) hipLaunchKernelGGL((KERN<true, true, false>), grid, block, 0, stream, g);        \

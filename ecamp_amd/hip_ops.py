@@ -68,10 +68,16 @@ def linear_dgrad(dy, w, gmul=None, alpha=1.0, alpha_dev=None, residual=None):
     return dx
 
 
-def _split_k(n_out, k_in, m):
-    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
-    s = max(1, 1024 // tiles)
-    return max(1, min(s, (m + 255) // 256))
+_SPLIT_CACHE = {}
+
+
+def _split_k(n_out, k_in, m, dtype=torch.bfloat16):
+    """Split count of the weight-gradient GEMM (M=n_out, N=k_in, K=m): asked of the library, which knows which kernel runs."""
+    key = (n_out, k_in, m, dtype)
+    s = _SPLIT_CACHE.get(key)
+    if s is None:
+        s = _SPLIT_CACHE[key] = max(1, int(_lib.load().ecamp_gemm_suggest_split(n_out, k_in, m, 0, 0, code(dtype))))
+    return s
 
 
 def linear_wgrad(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None):
@@ -80,7 +86,7 @@ def linear_wgrad(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None):
     K = x.shape[1]
     assert gw.dtype == torch.float32 and gw.is_contiguous() and gw.numel() == N * K
     gemm(dy, x, gw, N, K, M, False, dy.stride(0), False, x.stride(0), K, alpha=alpha, alpha_dev=alpha_dev, out_f32=True, accumulate=True,
-         split_k=_split_k(N, K, M), rowsum=gb)
+         split_k=_split_k(N, K, M, dy.dtype), rowsum=gb)
 
 
 def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):
@@ -326,7 +332,7 @@ def adamw_grouped(p, g, m, v, p16, block_group, lrs, wds, beta1, beta2, eps, ste
 # Weight gradients are leaves of the backward dependency graph: nothing in backward waits for them.  Launching them on a
 # second HIP stream lets their workgroups fill the tail-quantisation gaps of the dgrad / attention / LayerNorm kernels on the
 # main stream (and vice versa).  The main stream re-joins at the end of backward (autograd engine callback).
-OVERLAP_WGRAD = True
+OVERLAP_WGRAD = __import__("os").environ.get("ECAMP_OVERLAP_WGRAD", "1") != "0"
 _side = {}
 
 

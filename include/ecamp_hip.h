@@ -40,6 +40,10 @@ int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int6
                int64_t ldb, int64_t ldc, const float* bias, const void* residual, int64_t ldr, void* pre_out, int64_t ldp,
                const void* gmul, int64_t ldg, int act, float alpha, const float* alpha_dev, int dtype, int out_f32, int accumulate,
                int split_k, float* splitk_ws, float* rowsum, ecampStream_t stream);
+/* Split count the library recommends for ecamp_gemm(M, N, K, ...) with an f32 accumulated output (the weight-gradient call of
+ * torch.autograd for nn.Linear, e.g. timm Mlp.fc1 at model_ecamp.py:233): it depends on which kernel the shape selects
+ * (128^2 tiles, or the persistent 256^2 kernel whose work items should fill whole rounds of the chip).  Pure host arithmetic. */
+int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype);
 
 /* ---- LayerNorm (nn.LayerNorm eps 1e-6: model_ecamp.py:69,84,235,256 + timm Block norms; HF LN eps 1e-12:
  * BertSelfOutput/BertOutput/BertEmbeddings/transform).  y = LN(z), z = dropout(x) + residual (both optional). */
