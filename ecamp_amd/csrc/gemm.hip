@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 // "P8": persistent 256x256-tile kernel, 8 waves (2 x 4) of 128x64, one workgroup per CU, for GEMMs with enough tiles to fill
 // the chip.  Measured on MI355X the operand stream L2 -> LDS tops out near 12.5 TB/s (~21 B/clk/CU): the 128^2 kernel above
 // moves 2 x 128 x K operand bytes per 128^2 outputs and sits on that roof; a 256^2 tile halves the bytes per flop.
-//  * Operands arrive by direct L2 -> LDS DMA (global_load_lds_dwordx4) into a 4-stage ring of K=32 tiles (32 KB per stage).
-//    The ring is ONE flat stream of K tiles over all the output tiles a workgroup processes: the DMA cursor runs three K tiles
+//  * Operands arrive by direct L2 -> LDS DMA (global_load_lds_dwordx4) into a 5-stage ring of K=32 tiles (32 KB per stage: all 160 KB of a CU).
+//    The ring is ONE flat stream of K tiles over all the output tiles a workgroup processes: the DMA cursor runs four K tiles
 //    ahead of the MFMAs and simply moves on to the next output tile, so the next tile's first operands are already in LDS
 //    while the current tile's epilogue stores drain (with one resident workgroup per CU nothing else would hide them).
 //  * A DMA is issued in four pieces BETWEEN the MFMA groups of a K tile (an issue blocks the wave while the texture path is
@@ -452,7 +452,7 @@ __device__ __forceinline__ bf16x8 p8_frag_oc(const unsigned char* tile, int o0, 
 
 template <bool A_KC, bool B_KC, bool ROWSUM>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 stages x {A 16 KB, B 16 KB}; the ONLY LDS object
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 5 stages x {A 16 KB, B 16 KB}; the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total = g.nbm * g.nbn * g.nsplit, G = (int)gridDim.x;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
@@ -476,11 +476,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs g) {
     // ---- DMA cursor: (output tile pit, K tile pt of it), stream position pg (ring stage = pg & 3)
     int pv = (int)blockIdx.x;
     P8Item pit = p8_decode(g, pv, total);
-    int pt = 0, pg = 0;
+    int pt = 0, pg = 0, ps = 0;   // ps = pg % 5, the ring stage the cursor fills next
     bool pdone = false;
 #define P8_PIECE(PC)                                                                                                \
     do {                                                                                                            \
-        unsigned char* sA_ = lds + (pg & 3) * P8_STAGE_BYTES;                                                        \
+        unsigned char* sA_ = lds + ps * P8_STAGE_BYTES;                                                              \
         unsigned char* sB_ = sA_ + 16384;                                                                           \
         const int k0_ = pit.kbeg + pt * 32;                                                                         \
         if ((PC) < 2) {                                                                                             \
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs g) {
 #define P8_ADVANCE()                                                                                                \
     do {                                                                                                            \
         ++pg;                                                                                                       \
+        ps = ps == 4 ? 0 : ps + 1;                                                                                  \
         if (++pt == pit.nt) {                                                                                       \
             pt = 0;                                                                                                 \
             pv += G;                                                                                                \
@@ -501,63 +502,49 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs g) {
         }                                                                                                           \
     } while (0)
 
-    // prologue: up to three K tiles in flight
+    // prologue: up to four K tiles in flight
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
         if (!pdone) {
             P8_PIECE(0); P8_PIECE(1); P8_PIECE(2); P8_PIECE(3);
             P8_ADVANCE();
         }
 
-    int cg = 0;
-    for (int cv = (int)blockIdx.x; cv < total; cv += G) {
-        const P8Item cit = p8_decode(g, cv, total);
-        const bool do_rowsum = ROWSUM && g.rowsum != nullptr && cit.ncol == 0 && (wave & 3) == 0;
-        for (int t = 0; t < cit.nt; ++t, ++cg) {
-            // this K tile's DMAs have landed (mine); the younger tiles stay in flight
-            const int ahead = pg - cg - 1;
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                    // ... everyone's have, and everyone is done reading K tile cg-1
-            const unsigned char* sA = lds + (cg & 3) * P8_STAGE_BYTES;
-            const unsigned char* sB = sA + 16384;
-            const bool more = !pdone;
-            bf16x8 fm[8], fn[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int o = wn + (i >> 1) * 32 + (i & 1) * 4;
-                fn[i] = B_KC ? p8_frag_kc<3>(sB, o + nrow, lk) : p8_frag_oc<8>(sB, o, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) fm[i] = A_KC ? p8_frag_kc<2>(sA, wm + i * 16 + lrow, lk) : p8_frag_oc<4>(sA, wm + i * 16, lane);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-#pragma unroll
-                for (int tm = 2 * grp; tm < 2 * grp + 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fn[tn]),
-                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), acc[tm][tn], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(grp);                     // refill the stage K tile cg-1 vacated, one piece per MFMA group
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (ROWSUM && do_rowsum) {
-#pragma unroll
-                for (int tm = 0; tm < 8; ++tm)
-                    accr[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ones),
-                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), accr[tm], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            if (more) P8_ADVANCE();
-        }
-        // ---- epilogue of this output tile (the DMA cursor is already up to three K tiles into the next one)
+#define P8_WAIT_DMA(AHEAD)                                                     \
+    do {                                                                       \
+        const int ah_ = (AHEAD);                                               \
+        if (ah_ >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");        \
+        else if (ah_ == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    \
+        else if (ah_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
+    } while (0)
+#define P8_READ_FN(DST, SB)                                                                                          \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+            const int o = wn + (i >> 1) * 32 + (i & 1) * 4;                                                          \
+            DST[i] = B_KC ? p8_frag_kc<3>((SB), o + nrow, lk) : p8_frag_oc<8>((SB), o, lane);                        \
+        }                                                                                                            \
+    } while (0)
+#define P8_READ_FM(I, SA) (fm[(I)] = A_KC ? p8_frag_kc<2>((SA), wm + (I) * 16 + lrow, lk) : p8_frag_oc<4>((SA), wm + (I) * 16, lane))
+#define P8_MFMA_GROUP(GRP)                                                                                           \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int tm = 2 * (GRP); tm < 2 * (GRP) + 2; ++tm)                                         \
+            _Pragma("unroll") for (int tn = 0; tn < 4; ++tn)                                                         \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                               \
+                    __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fn[tn]),                          \
+                    __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), acc[tm][tn], 0, 0, 0);   \
+    } while (0)
+#define P8_ROWSUM_MFMA()                                                                                             \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int tm = 0; tm < 8; ++tm)                                                             \
+            accr[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                      \
+                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ones),                                \
+                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), accr[tm], 0, 0, 0);          \
+    } while (0)
+    // epilogue of one output tile + reset of the accumulators
+    auto finish_tile = [&](const P8Item& it, bool rowsum_here) {
         if (!(g.dbg & 4)) {
-            const int nb = cit.n0 + wn + lk * 8;
+            const int nb = it.n0 + wn + lk * 8;
             float bias[2][8];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -567,13 +554,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs g) {
                 ld8<float>(g.bias + nb, bias[0]);
                 ld8<float>(g.bias + nb + 32, bias[1]);
             }
-            p8_epilogue_rows<0, 4>(g, acc, cit.m0 + wm + lrow, nb, cit.z, bias);
-            p8_epilogue_rows<4, 4>(g, acc, cit.m0 + wm + 64 + lrow, nb, cit.z, bias);
-            if (ROWSUM && do_rowsum && lk == 0) {  // every row of the ones-product is the same sum; lane (lk = 0, r = 0) owns column lrow
+            p8_epilogue_rows<0, 4>(g, acc, it.m0 + wm + lrow, nb, it.z, bias);
+            p8_epilogue_rows<4, 4>(g, acc, it.m0 + wm + 64 + lrow, nb, it.z, bias);
+            if (ROWSUM && rowsum_here && lk == 0) {  // every row of the ones-product is the same sum; lane (lk = 0, r = 0) owns column lrow
                 const float al = g.alpha_dev_out ? g.alpha_out * g.alpha_dev_out[0] : g.alpha_out;
 #pragma unroll
                 for (int tm = 0; tm < 8; ++tm) {
-                    int m = cit.m0 + wm + tm * 16 + lrow;
+                    int m = it.m0 + wm + tm * 16 + lrow;
                     if (m < g.M) atomicAdd(g.rowsum + m, al * accr[tm][0]);
                 }
             }
@@ -586,7 +573,95 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < (ROWSUM ? 8 : 1); ++i) accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    };
+
+    int cg = 0;
+    bf16x8 fm[8], fn[4];
+    // One barrier per K tile; the DMA pieces of K tile cg+4 go between the MFMA groups of K tile cg (5-stage ring).
+    //  * contraction-contiguous M operand (forward, data gradient): the second half of the M-side fragments is read one MFMA
+    //    group ahead of its use (into registers the first groups have freed), so only eight of the twelve fragment reads of a
+    //    K tile are exposed: -10% loop time.  Going further -- publishing K tile cg+1 at the barrier of cg and reading its first
+    //    fragments during the MFMAs of cg -- measured 5-30% SLOWER (LDS reads between MFMA groups cost more than they hide).
+    //  * strided M operand (weight gradient; LDS transpose reads): all twelve fragments are read after the barrier -- spreading
+    //    the transpose reads between the MFMA groups measured 40% slower.
+    // (A two-barrier schedule with the two M halves running one phase apart -- one wave of a SIMD multiplying while its
+    // neighbour reads and issues DMAs -- measured 20% slower; waiting for the next tile's DMAs before the epilogue so that
+    // later counted waits do not also wait for the stores made no difference: DESIGN.md, rejected experiments.)
+    int cs = 0;   // cg % 5
+    for (int cv = (int)blockIdx.x; cv < total; cv += G) {
+        const P8Item cit = p8_decode(g, cv, total);
+        const bool do_rowsum = ROWSUM && g.rowsum != nullptr && cit.ncol == 0 && (wave & 3) == 0;
+        for (int t = 0; t < cit.nt; ++t, ++cg) {
+            const int cs1 = cs == 4 ? 0 : cs + 1;
+            const unsigned char* sA = lds + cs * P8_STAGE_BYTES;
+            const unsigned char* sB = sA + 16384;
+            if (A_KC) {
+                P8_WAIT_DMA(pg - cg - 1);                    // this K tile's DMAs have landed (mine); younger tiles stay in flight
+                __builtin_amdgcn_s_barrier();                // ... everyone's have, and everyone is done reading K tile cg-1
+                const bool more = !pdone;
+                P8_READ_FN(fn, sB);
+                P8_READ_FM(0, sA); P8_READ_FM(1, sA); P8_READ_FM(2, sA); P8_READ_FM(3, sA);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                P8_MFMA_GROUP(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(0);                       // K tile cg+4 into the stage K tile cg-1 vacated
+                P8_READ_FM(4, sA); P8_READ_FM(5, sA);
+                __builtin_amdgcn_sched_barrier(0);
+                P8_MFMA_GROUP(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(1);
+                P8_READ_FM(6, sA); P8_READ_FM(7, sA);
+                __builtin_amdgcn_sched_barrier(0);
+                P8_MFMA_GROUP(2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(2);
+                __builtin_amdgcn_sched_barrier(0);
+                P8_MFMA_GROUP(3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(3);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);
+                if (more) P8_ADVANCE();
+            } else {
+                P8_WAIT_DMA(pg - cg - 1);                    // this K tile's DMAs have landed (mine); younger tiles stay in flight
+                __builtin_amdgcn_s_barrier();                // ... everyone's have, and everyone is done reading K tile cg-1
+                const bool more = !pdone;
+                P8_READ_FN(fn, sB);
+                P8_READ_FM(0, sA); P8_READ_FM(1, sA); P8_READ_FM(2, sA); P8_READ_FM(3, sA);
+                P8_READ_FM(4, sA); P8_READ_FM(5, sA); P8_READ_FM(6, sA); P8_READ_FM(7, sA);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                P8_MFMA_GROUP(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(0);
+                __builtin_amdgcn_sched_barrier(0);
+                P8_MFMA_GROUP(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(1);
+                __builtin_amdgcn_sched_barrier(0);
+                P8_MFMA_GROUP(2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(2);
+                __builtin_amdgcn_sched_barrier(0);
+                P8_MFMA_GROUP(3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P8_PIECE(3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ROWSUM && do_rowsum) P8_ROWSUM_MFMA();
+                __builtin_amdgcn_s_setprio(0);
+                if (more) P8_ADVANCE();
+            }
+            cs = cs1;
+        }
+        // the DMA cursor is already up to four K tiles into the next output tile
+        finish_tile(cit, do_rowsum);
     }
+#undef P8_WAIT_DMA
+#undef P8_READ_FN
+#undef P8_READ_FM
+#undef P8_MFMA_GROUP
+#undef P8_ROWSUM_MFMA
 #undef P8_PIECE
 #undef P8_ADVANCE
 }
@@ -843,23 +918,22 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
             const int ncu = p8_num_cu();
             const long total8 = (long)nbm8 * nbn8 * split_k;
             dim3 grid8((unsigned)(total8 < ncu ? total8 : ncu), 1, 1);
-            const size_t shm8 = 4 * P8_STAGE_BYTES;
-            static bool once8 = false;
-            if (!once8) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
-                once8 = true;
+            const size_t shm8 = 5 * P8_STAGE_BYTES;  // the whole 160 KB LDS of a CU
+            typedef void (*p8_fn)(GemmArgs);
+            const p8_fn fn8 = rowsum ? gemm_bf16_p8_kernel<false, false, true>
+                                     : a_kc ? (b_kc ? gemm_bf16_p8_kernel<true, true, false> : gemm_bf16_p8_kernel<true, false, false>)
+                                            : (b_kc ? gemm_bf16_p8_kernel<false, true, false> : gemm_bf16_p8_kernel<false, false, false>);
+            static p8_fn attr_done[16];
+            static int n_attr = 0;
+            bool seen = false;
+            for (int i = 0; i < n_attr; ++i) seen = seen || attr_done[i] == fn8;
+            if (!seen) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
+                if (n_attr < 16) attr_done[n_attr++] = fn8;
             }
             const bool prof8 = ecamp_prof_active();
             if (prof8) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream);
-            if (rowsum) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, true>), grid8, dim3(512), shm8, stream, g);
-            else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, true, false>), grid8, dim3(512), shm8, stream, g);
-            else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_p8_kernel<true, false, false>), grid8, dim3(512), shm8, stream, g);
-            else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, true, false>), grid8, dim3(512), shm8, stream, g);
-            else hipLaunchKernelGGL((gemm_bf16_p8_kernel<false, false, false>), grid8, dim3(512), shm8, stream, g);
+            hipLaunchKernelGGL(fn8, grid8, dim3(512), shm8, stream, g);
             if (split_k > 1) {
                 long n4 = M * N / 4;
                 int nb = (int)((n4 + 255) / 256);

@@ -1,9 +1,9 @@
 #!/bin/bash
-# development probe: where does the P8 GEMM spend its time? (dbg: 1 no in-loop DMA, 2 no reads/MFMA, 4 no epilogue, 8/16 DMA placement)
+# development probe: P8 GEMM variants (ECAMP_P8_DBG bits: 4 = no epilogue, 8 = no pre-epilogue DMA wait) vs the 128^2 kernel
 cd /root/repo
-for dbg in ${DBGS:-0 4}; do
-  echo "== ECAMP_P8_DBG=$dbg"
-  ECAMP_GEMM_P8=${P8MODE:-2} ECAMP_P8_DBG=$dbg timeout 200 python tools/gemm_bench.py $SHAPES 2>&1 | grep -v amdgpu.ids | tail -15
+for dbg in ${DBGS:-0}; do
+  echo "== P8 forced, ECAMP_P8_DBG=$dbg"
+  ECAMP_GEMM_P8=2 ECAMP_P8_DBG=$dbg timeout 200 python tools/gemm_bench.py $SHAPES 2>&1 | grep -v amdgpu.ids | tail -15
 done
-echo "== baseline (128^2 kernel)"
-timeout 200 python tools/gemm_bench.py $SHAPES 2>&1 | grep -v amdgpu.ids | tail -15
+echo "== 128^2 kernel only"
+ECAMP_GEMM_P8=0 timeout 200 python tools/gemm_bench.py $SHAPES 2>&1 | grep -v amdgpu.ids | tail -15
