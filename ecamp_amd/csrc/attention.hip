@@ -467,3 +467,73 @@ extern "C" int ecamp_attn_bwd(const void* q, const void* k, const void* v, const
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
+
+// =============================================================================================
+// Attention PROBABILITIES (evaluation / visualisation only): probs[b,h,i,:] = softmax_j(scale * q_i . k_j + mask_j), f32.
+// One wave per query row; lane owns keys lane, lane+64, ...  Not a training-path kernel: it exists because the reference's
+// Visualization model returns the fusion layer's cross-attention probabilities (Visualization/module/context_fusion.py:45-57).
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q, const T* __restrict__ k, const int32_t* __restrict__ key_mask,
+                                                         float* __restrict__ probs, int B, int H, int Tq, int Tk, int hd, long q_sb, long q_st,
+                                                         long q_sh, long k_sb, long k_st, long k_sh, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * H * Tq) return;
+    const int i = (int)(row % Tq), h = (int)((row / Tq) % H), b = (int)(row / ((long)Tq * H));
+    const T* qp = q + b * q_sb + i * q_st + h * q_sh;
+    const T* kb = k + b * k_sb + h * k_sh;
+    constexpr int MAXJ = 16;  // Tk <= 1024
+    float s[MAXJ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+        const int j = lane + 64 * jj;
+        s[jj] = -INFINITY;
+        if (j < Tk) {
+            const T* kp = kb + (long)j * k_st;
+            float acc = 0.f;
+            for (int d = 0; d < hd; ++d) acc += to_f<T>(qp[d]) * to_f<T>(kp[d]);
+            acc *= scale;
+            if (key_mask && key_mask[(long)b * Tk + j] == 0) acc += -3.4028234663852886e38f;  // + finfo(f32).min, as bert_modeling.py:92
+            s[jj] = acc;
+            mx = fmaxf(mx, acc);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+        const int j = lane + 64 * jj;
+        if (j < Tk) {
+            s[jj] = __expf(s[jj] - mx);
+            sum += s[jj];
+        }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float* out = probs + row * Tk;
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+        const int j = lane + 64 * jj;
+        if (j < Tk) out[j] = s[jj] * inv;
+    }
+}
+
+extern "C" int ecamp_attn_probs(const void* q, const void* k, const int32_t* key_mask, float* probs, int32_t B, int32_t H, int32_t Tq,
+                                int32_t Tk, int32_t hd, const int64_t* q_strides, const int64_t* k_strides, float scale, int32_t dtype,
+                                hipStream_t stream) {
+    ECAMP_CHECK_ARG(q && k && probs && q_strides && k_strides, "attn_probs: null pointer");
+    ECAMP_CHECK_ARG(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tk <= 1024 && hd > 0, "attn_probs: bad shape (Tk <= 1024)");
+    ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "attn_probs: bad dtype %d", dtype);
+    const long rows = (long)B * H * Tq;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == ECAMP_F32)
+        hipLaunchKernelGGL(attn_probs_kernel<float>, grid, block, 0, stream, (const float*)q, (const float*)k, key_mask, probs, B, H, Tq, Tk, hd,
+                           (long)q_strides[0], (long)q_strides[1], (long)q_strides[2], (long)k_strides[0], (long)k_strides[1], (long)k_strides[2], scale);
+    else
+        hipLaunchKernelGGL(attn_probs_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, key_mask, probs, B, H, Tq, Tk, hd,
+                           (long)q_strides[0], (long)q_strides[1], (long)q_strides[2], (long)k_strides[0], (long)k_strides[1], (long)k_strides[2], scale);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}

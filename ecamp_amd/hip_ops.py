@@ -138,6 +138,14 @@ def attn_fwd(q, k, v, B, H, Tq, Tk, hd, qs, ks, vs, scale, key_mask=None, drop_p
     return o, lse
 
 
+def attn_probs(q, k, B, H, Tq, Tk, hd, qs, ks, scale, key_mask=None):
+    """softmax(scale * q k^T [+ finfo.min on masked keys]) -> f32 [B, H, Tq, Tk]  (Visualization/module/context_fusion.py:45-57)."""
+    _chk(q, k)
+    probs = torch.empty((B, H, Tq, Tk), device=q.device, dtype=torch.float32)
+    call("ecamp_attn_probs", ptr(q), ptr(k), ptr(key_mask), ptr(probs), B, H, Tq, Tk, hd, _st(qs), _st(ks), float(scale), code(q.dtype), stream())
+    return probs
+
+
 def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, H, Tq, Tk, hd, qs, ks, vs, dqs, dks, dvs, scale, key_mask=None, drop_p=0.0,
              seed=0, offset=0):
     delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)

@@ -238,6 +238,48 @@ class ECAMP(nn.Module):
         return img_losses[0], img_losses[1], mlm_loss
 
 
+    @torch.no_grad()
+    def forward_visualization(self, imgs, text_ids, attention_mask, type_ids, mask_ratio=0, noise=None):
+        """The reference's Visualization model (Visualization/module/model_ecamp.py:308-319): encoder on the 224^2 image with
+        `mask_ratio` (0: every patch kept, in argsort(noise) order as the reference does), then the fusion layer's
+        cross-attention probabilities of the report tokens onto the image tokens (Visualization/module/context_fusion.py:45-57)
+        -> f32 [B, heads, S, L_keep].  Evaluation semantics (no dropout) whatever `self.training` is."""
+        import math
+
+        from .. import hip_ops as ops
+        from ..functions import BertEmbedFn, NormFn, ReportStemFn, StemFn, VitBlockFn, _self_attn_fwd
+        A = self.prepare()
+        dev = A.device
+        imgs = imgs.to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        if imgs.shape[1:] != (3, self.img_size, self.img_size):
+            raise ValueError("imgs must be [B,3,%d,%d], got %s" % (self.img_size, self.img_size, tuple(imgs.shape)))
+        mv = lambda t: t.to(dev, dtype=torch.int64, non_blocking=True).contiguous()
+        ids, attention_mask, type_ids = mv(text_ids), mv(attention_mask), mv(type_ids)
+        if ids.dim() == 1:
+            ids, attention_mask, type_ids = ids[None], attention_mask[None], type_ids[None]
+        B, S = ids.shape
+        if noise is not None:
+            noise = noise.to(dev, dtype=torch.float32).contiguous()
+        x, _, _, _, ids_keep = StemFn.apply(imgs, noise, self, mask_ratio, self.cls_token)
+        T = ids_keep.shape[1] + 1
+        for blk in self.blocks:
+            x = VitBlockFn.apply(x, blk, self, B, T, self.num_heads)
+        latent = NormFn.apply(x, self.norm, self)
+        lat, _ = ReportStemFn.apply(latent, self, B, T)
+        bert = self.bert_encoder.model.bert
+        e = BertEmbedFn.apply(ids, type_ids, bert.embeddings, self, 0.0, bert.embeddings.LayerNorm.weight)
+        fl = bert.context_fusion_layer
+        key_mask = attention_mask.to(torch.int32).contiguous()
+        a1 = _self_attn_fwd(self, fl.attention.self, fl.attention.output, e, B, S, key_mask, 0.0, 0.0, [])
+        ca = fl.cross_self_attention
+        H = a1.shape[1]
+        heads = self.bert_config.num_attention_heads
+        hd = H // heads
+        q = ops.linear_fwd(a1, A.w(ca.query.weight), ca.query.bias.data)
+        k = ops.linear_fwd(lat, A.w(ca.key.weight), ca.key.bias.data)   # [B*T, H]; the cls row is skipped by a pointer offset
+        return ops.attn_probs(q, k.view(-1)[H:], B, heads, S, T - 1, hd, (S * H, H, hd), (T * H, H, hd), 1.0 / math.sqrt(hd))
+
+
 def ecamp(**kwargs):
     """ViT-B/16 encoder + 512-d/4-block decoder + reference BERT -- model_ecamp.py:328-333."""
     return ECAMP(patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512, decoder_depth=4,

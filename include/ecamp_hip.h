@@ -67,6 +67,11 @@ int ecamp_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
                    const int64_t* dv_strides, float scale, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
                    ecampStream_t stream);
+/* Attention probabilities softmax(scale * q k^T + mask), f32 [B,H,Tq,Tk] (Tk <= 1024): the tensor the reference's Visualization
+ * model returns from the fusion layer's cross-attention (Visualization/module/context_fusion.py:45-57,
+ * Visualization/module/model_ecamp.py:308-319).  Evaluation only. */
+int ecamp_attn_probs(const void* q, const void* k, const int32_t* key_mask, float* probs, int32_t B, int32_t H, int32_t Tq, int32_t Tk,
+                     int32_t hd, const int64_t* q_strides, const int64_t* k_strides, float scale, int32_t dtype, ecampStream_t stream);
 
 /* ---- elementwise / reductions ---- */
 int ecamp_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, ecampStream_t stream);

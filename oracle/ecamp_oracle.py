@@ -406,6 +406,37 @@ def forward(P, cfg, batch, mask_ratio=0.75, noise=None, train=False, return_aux=
     return (mim, res, mlm), aux
 
 
+def forward_visualization(P, cfg, imgs, ids, attention_mask, type_ids, mask_ratio=0.0, noise=None):
+    """f4: the Visualization variant of ECAMP.forward (Visualization/module/model_ecamp.py:308-319): eval-mode encoder on the
+    224^2 image with `mask_ratio` (0 there: all 196 patches kept, but still SHUFFLED by argsort(noise) -- the reference hands
+    the fusion layer the tokens in `ids_keep` order), bert_mlp, embeddings, the fusion layer's text self-attention block, and
+    the cross-attention PROBABILITIES of the text onto the image tokens, which is what the Visualization fusion layer returns
+    (Visualization/module/context_fusion.py:45-57 `cross_self_outputs[1]`; bert_modeling.py:113-129).
+    -> [B, heads, S, L_keep] f32, plus ids_keep."""
+    b = cfg.bert
+    if noise is None:
+        noise = torch.rand(imgs.shape[0], cfg.num_patches)
+    latent, mask, ids_restore, ids_keep = image_encoder(P, cfg, imgs, mask_ratio, noise)
+    lat = _lin(P, "bert_mlp", latent)
+    img = lat[:, 1:, :]
+    B, S = ids.shape
+    pre = "bert_encoder.model.bert."
+    fmin = torch.finfo(torch.float32).min
+    text_mask = (1.0 - attention_mask[:, None, None, :].to(torch.float32)) * fmin
+    img_mask = torch.zeros(B, 1, 1, img.shape[1])
+    pos = torch.arange(S)
+    e = (F.embedding(ids, P[pre + "embeddings.word_embeddings.weight"], padding_idx=0)
+         + P[pre + "embeddings.token_type_embeddings.weight"][type_ids]
+         + P[pre + "embeddings.position_embeddings.weight"][pos][None])
+    e = _ln(P, pre + "embeddings.LayerNorm", e, b.layer_norm_eps)
+    fp = pre + "context_fusion_layer"
+    a = bert_self_attention(P, fp + ".attention.self", e, text_mask, b.num_attention_heads, 0.0, False)
+    a = bert_self_output(P, fp + ".attention.output", a, e, b.layer_norm_eps, 0.0, False)
+    _, probs = bert_self_attention(P, fp + ".cross_self_attention", a, img_mask, b.num_attention_heads, 0.0, False, kv=img,
+                                   return_probs=True)
+    return probs, ids_keep
+
+
 # ---------------------------------------------------------------------------------------------
 # engine-side host arithmetic (a1-a5)
 # ---------------------------------------------------------------------------------------------

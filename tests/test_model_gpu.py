@@ -244,3 +244,26 @@ def test_ragged_shapes_fp32_match_oracle(dev, B, S, mask_ratio):
         g, gr = dict(model.named_parameters())[n].grad.float().cpu(), P[n].grad
         err = (g - gr).norm().item() / (gr.norm().item() + 1e-12)
         assert err < 1e-3, (n, err)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_visualization_forward_matches_reference(dev, dtype, tol):
+    """ECAMP.forward_visualization (mask_ratio=0, fusion cross-attention probabilities [B,6,S,196]) against
+    the vectors captured from the reference's Visualization model (tests/golden/vis_base_b2_s128.npz)."""
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    from oracle.make_golden import digest
+    g = _load("vis_base_b2_s128")
+    B, S = int(g["meta/B"]), int(g["meta/S"])
+    model, cfg = _build("base_b2_s128", dtype, dev)
+    model.eval()
+    batch = recipe.recipe_batch(cfg, B, S, seed=0)
+    imgs = orc.bicubic_resize(batch["image"], cfg.img_size)
+    probs = model.forward_visualization(imgs, batch["ids"], batch["attention_mask"], batch["type_ids"], mask_ratio=0,
+                                        noise=recipe.recipe_noise(B, cfg.num_patches, seed=0))
+    assert probs.dtype == torch.float32 and tuple(probs.shape) == (B, cfg.bert.num_attention_heads, S, cfg.num_patches)
+    p = probs.cpu()
+    assert float((p.sum(-1) - 1).abs().max()) < 1e-4
+    nm, s = digest(p)
+    print("vis", dtype, "norm rel", rel(nm[0], g["probs/nm"][0]), "sample rel", rel(s, g["probs/s"]), "tok4 rel", rel(p[:, :, 4].numpy(), g["probs_tok4"]))
+    assert rel(nm[0], g["probs/nm"][0]) < tol and rel(s, g["probs/s"]) < tol and rel(p[:, :, 4].numpy(), g["probs_tok4"]) < tol

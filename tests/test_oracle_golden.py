@@ -63,3 +63,24 @@ def test_golden_generator_skips_cleanly_without_reference():
         pytest.skip("reference checkout present (authoring container)")
     with pytest.raises(RuntimeError):
         ref_shim.install()
+
+
+def test_oracle_visualization_forward_matches_reference_vectors():
+    """oracle.forward_visualization vs the cross-attention probabilities captured from the reference's
+    Visualization model (tests/golden/vis_base_b2_s128.npz, written by oracle/make_golden_vis.py)."""
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(GOLD, "vis_base_b2_s128.npz"))
+    cfg = orc.cfg_base()
+    B, S = int(g["meta/B"]), int(g["meta/S"])
+    P = orc.load_state(orc.new_params(cfg, requires_grad=False), recipe.recipe_state(cfg, seed=0))
+    batch = recipe.recipe_batch(cfg, B, S, seed=0)
+    imgs = orc.bicubic_resize(batch["image"], cfg.img_size)
+    with torch.no_grad():
+        probs, ids_keep = orc.forward_visualization(P, cfg, imgs, batch["ids"], batch["attention_mask"], batch["type_ids"], 0.0,
+                                                    recipe.recipe_noise(B, cfg.num_patches, seed=0))
+    assert tuple(probs.shape) == (B, cfg.bert.num_attention_heads, S, cfg.num_patches)
+    assert (ids_keep.numpy() == g["ids_keep"]).all()
+    nm, s = digest(probs)
+    assert rel(nm[0], g["probs/nm"][0]) < 1e-5 and rel(s, g["probs/s"]) < 1e-5
+    assert rel(probs[:, :, 4].numpy(), g["probs_tok4"]) < 1e-5  # the row main_visualization.py:153-154 plots
+    assert float((probs.sum(-1) - 1).abs().max()) < 1e-5
