@@ -4,13 +4,14 @@ unchanged), on the MI355X-native model / optimizer / data-parallel reducer.
     python -m torch.distributed.run --nproc_per_node=8 -m ecamp_amd.main_pretrain --batch_size 256 --accum_iter 8 ...
 
 Extra flags (all optional): --compute_dtype {bf16,fp32}, --max_caption_length, --synthetic_len, --print_freq.
-The MIMIC-CXR `ContextBertDataset` (pretrain_datasets.py) is outside this round's scope: when
-`--data_path` holds no dataset CSV the synthetic stand-in with the same batch schema is used.
+When `--data_path` holds the MIMIC-CXR CSVs the `ContextBertDataset` of module/pretrain_datasets.py is used (batched
+entity-aware masker, bit-exact against the reference loop); otherwise the synthetic stand-in with the same batch schema.
 """
 import argparse
 import datetime
 import json
 import os
+import random
 import shutil
 import time
 from pathlib import Path
@@ -83,9 +84,12 @@ def main(args):
     torch.manual_seed(seed)
     np.random.seed(seed)
 
-    if os.path.exists(os.path.join(args.data_path, "mimic-cxr-2.0.0-entity-llm.csv")):
-        raise SystemExit("the MIMIC-CXR ContextBertDataset pipeline is not part of this implementation yet (SURVEY.md 8f, f2)")
-    dataset_train = SyntheticContextBertDataset(args.synthetic_len, args.max_caption_length, args.input_size, seed=args.seed)
+    if os.path.exists(os.path.join(args.data_path, "mimic-cxr-2.0.0-entity-llm.csv")):   # main_pretrain.py:195
+        from .module.pretrain_datasets import ContextBertDataset
+        random.seed(seed)  # the item pipeline draws from Python's `random` (pretrain_datasets.py:98,121,123)
+        dataset_train = ContextBertDataset(os.path.join(args.data_path), max_caption_length=args.max_caption_length)
+    else:
+        dataset_train = SyntheticContextBertDataset(args.synthetic_len, args.max_caption_length, args.input_size, seed=args.seed)
     num_tasks, global_rank = misc.get_world_size(), misc.get_rank()
     sampler_train = DistributedSampler(dataset_train, num_replicas=num_tasks, rank=global_rank, shuffle=True)
     print("Sampler_train = %s" % str(sampler_train))

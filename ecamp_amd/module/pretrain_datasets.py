@@ -1,0 +1,262 @@
+"""ContextBertDataset -- the reference's data pipeline (ECAMP/Pre-training/module/pretrain_datasets.py:34-239), SURVEY.md 8(f) f2.
+
+What is different from the reference, and why:
+  * entity-aware masking (`_context_mask`, :60-110) and the template down-weighting / re-normalisation (:141-184) are
+    restated as BATCHED TENSOR code (`context_mask`, `template_weights`) that runs on the host or on the GPU, instead of a
+    Python loop over 256 positions per sample: at ~5 k pairs/s/GPU x 8 GPUs the per-token loop cannot feed the trainer.
+    Given the same sequential stream of uniforms (the reference consumes `random.random()` in position order) the result is
+    bit-identical to the reference loop -- checked against vectors captured from the reference (tests/golden/data_pipeline.npz).
+  * the reference's collate_fn `.squeeze()`s a batch of one down to 1-D (:218-225); ours keeps the batch dimension.
+Same constructor, same item tuple, same batch dict schema (:228-237).
+"""
+import os
+import random
+from typing import List, Tuple
+
+import torch
+from torch.utils.data import Dataset
+
+# pretrain_datasets.py:17-24 -- the 44 entities whose context is kept, and the token ids of the down-weighted templates
+entities = ['abnormality', 'abscess', 'aerate', 'aorta', 'atelectasis', 'bronchiectasis', 'calcification', 'cardiomediastinal',
+            'cardiomegaly', 'catheter', 'chf', 'collapse', 'congestion', 'consolidation', 'contour', 'COPD',
+            'deformity', 'dilation', 'distention', 'edema', 'effusion', 'embolism', 'emphysema', 'engorgement',
+            'fibrosis', 'fracture', 'granuloma', 'hernia', 'hilar', 'hyperinflate', 'hemidiaphragm', 'infiltrate',
+            'mass', 'nodule', 'obscure', 'opacity', 'perihilar', 'pneumonia', 'pneumothorax', 'sarcoidosis',
+            'silhouette', 'thickening', 'tuberculosis', 'vasculature']
+template1 = [219, 149, 152, 422, 158]  # "there is no evidence of"
+template2 = [219, 149, 152]            # "there is no"
+PAD, MASK, PERIOD = 0, 3, 16            # token ids the reference hard-codes (:74,77,93)
+
+
+class MaskVocab:
+    """Per-token-id flags the masker needs: `word in entities` (:68,86) and `word[0:2] == '##'` (:77,81)."""
+
+    def __init__(self, is_entity: torch.Tensor, is_subword: torch.Tensor):
+        self.is_entity, self.is_subword = is_entity.bool(), is_subword.bool()
+
+    @classmethod
+    def from_tokenizer(cls, tokenizer):
+        vocab = tokenizer.get_vocab()
+        n = max(vocab.values()) + 1
+        ent, sub = torch.zeros(n, dtype=torch.bool), torch.zeros(n, dtype=torch.bool)
+        es = set(entities)
+        for w, i in vocab.items():
+            ent[i] = w in es
+            sub[i] = w[0:2] == '##'
+        return cls(ent, sub)
+
+    def to(self, device):
+        return MaskVocab(self.is_entity.to(device), self.is_subword.to(device))
+
+
+def context_mask(tokens: torch.Tensor, vocab: MaskVocab, stream: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Batched `_context_mask` (pretrain_datasets.py:60-110).
+
+    tokens [B, L] int64; stream [B, >= 2L-2] float64 uniforms, consumed per row in the order the reference calls
+    `random.random()`: one per visited non-subword position (ascending), then one per entity position (ascending).
+    -> (masked_tokens [B, L], mask_pos [B, L] bool: the entity-context positions the reference returns as a list).
+    The loop's data dependencies, all resolved without a loop:
+      * it stops at the first PAD at or after position 1 and never visits position L-1 (:73-75);
+      * a subword token copies the masked state of the token before it -- by induction the pass-1 state of its word's first
+        token (the 75 % entity masking of the second loop happens later and is NOT propagated) (:77-82);
+      * `i not in mask_pos` (:104) is always true when position i is visited (an entity only registers positions before
+        itself), so context positions are protected from nothing; they only carry the expanded loss weight;
+      * the assignment at :95-96 is dead (it sits under `if word in entities` and tests `word not in entities`)."""
+    B, L = tokens.shape
+    dev = tokens.device
+    idx = torch.arange(L, device=dev)[None, :]
+    inner = (idx >= 1) & (idx <= L - 2)
+    is_pad = (tokens == PAD) & inner
+    first_pad = torch.where(is_pad.any(1), is_pad.to(torch.int64).argmax(1), torch.full((B,), L, device=dev, dtype=torch.int64))
+    valid = inner & (idx < first_pad[:, None])
+    sub = vocab.is_subword[tokens]
+    ent_tok = vocab.is_entity[tokens]
+    entity_exist = (ent_tok & inner).any(1)                       # :67-70 scans every position
+    head = valid & ~sub                                           # positions that draw a number in the first loop
+    ent = head & ent_tok                                          # entity_pos
+    k1 = head.to(torch.int64).cumsum(1) - 1
+    prob1 = stream.gather(1, k1.clamp_min(0))
+    m_head = head & torch.where(entity_exist[:, None], (prob1 < 0.7) & ~ent, prob1 < 0.75)    # :98-105
+    state = m_head | (tokens == MASK)                             # "masked_tokens[i-1] == 3" as seen by the next subword
+    h_idx = torch.where(~sub, idx.expand(B, L), torch.zeros_like(tokens)).cummax(1).values   # first token of the word at i
+    m_sub = valid & sub & state.gather(1, h_idx)                  # :77-79
+    n1 = head.to(torch.int64).sum(1)
+    k2 = n1[:, None] + ent.to(torch.int64).cumsum(1) - 1
+    prob2 = stream.gather(1, k2.clamp(0, stream.shape[1] - 1))
+    m_ent = ent & (prob2 < 0.75)                                  # :107-111
+    masked = torch.where(m_head | m_sub | m_ent, torch.full_like(tokens, MASK), tokens)
+    not_period = tokens != PERIOD
+    mask_pos = torch.zeros_like(valid)
+    mask_pos[:, 1:L - 1] |= ent[:, 2:L] & not_period[:, 1:L - 1]      # i-1 for an entity at i >= 2
+    mask_pos[:, 1:L - 2] |= ent[:, 3:L] & not_period[:, 1:L - 2]      # i-2 for an entity at i >= 3
+    return masked, mask_pos
+
+
+def template_weights(ids: torch.Tensor, mask_pos: torch.Tensor) -> torch.Tensor:
+    """Per-token loss weights (pretrain_datasets.py:141-184): 0.05 on "there is no [evidence of]" templates, the entity-context
+    positions scaled up so that the row's total weight is preserved, or every weight scaled when no context exists.
+    ids [B, L] ORIGINAL token ids, mask_pos [B, L] bool -> f32 [B, L].  The templates cannot overlap themselves or each other
+    (token 219 only opens them), so the reference's skip-ahead scan equals independent matching at every start i < L-4."""
+    B, L = ids.shape
+    dev = ids.device
+    n = L - 4
+
+    def match(t):
+        m = torch.ones((B, n), dtype=torch.bool, device=dev)
+        for k, v in enumerate(t):
+            m &= ids[:, k:k + n] == v
+        return m
+
+    m1 = match(template1)
+    m2 = match(template2) & ~m1
+    dim = torch.zeros((B, L), dtype=torch.bool, device=dev)
+    for k in range(5):
+        dim[:, k:k + n] |= m1
+    for k in range(3):
+        dim[:, k:k + n] |= m2
+    weights = torch.where(dim, torch.full((B, L), 0.05, device=dev), torch.ones((B, L), device=dev))
+    dcnt = dim.sum(1).to(torch.float64)
+    mcnt = mask_pos.sum(1).to(torch.float64)
+    ldm = (mask_pos & dim).sum(1).to(torch.float64)
+    case_a = (mcnt > 0) & (dcnt > 0)
+    case_b = ~case_a & (dcnt > 0)
+    one = torch.ones_like(dcnt)
+    exp_a = (0.95 * (dcnt - ldm) + mcnt) / torch.where(case_a, mcnt - 0.95 * ldm, one)           # :177-178
+    exp_b = float(L) / (float(L) - 0.95 * dcnt)                                                  # :182-183
+    sa = torch.where(case_a, exp_a, one).to(torch.float32)[:, None]
+    sb = torch.where(case_b, exp_b, one).to(torch.float32)[:, None]
+    weights = torch.where(mask_pos, weights * sa, weights)
+    return weights * sb
+
+
+def assemble_report(report: str, llm_output: str, rng) -> str:
+    """pretrain_datasets.py:116-132: with probability 0.8 splice the LLM summary between two sentences of the report."""
+    parts = report.split('.')
+    n = len(parts)
+    sent = ""
+    if rng.random() < 0.8:
+        location = rng.randint(0, n)
+        for i in range(0, location):
+            sent += parts[i]
+            sent += "."
+        sent += llm_output
+        for i in range(location, n):
+            sent += parts[i]
+            sent += "."
+    else:
+        sent = report
+    sent = sent.replace("..", ".")
+    return '[CLS] ' + sent
+
+
+def pil_loader(path: str):
+    from PIL import Image
+    with open(path, 'rb') as f:
+        img = Image.open(f)
+        return img.convert('RGB')
+
+
+def default_image_transform(size=448):
+    """pretrain_datasets.py:47-52 (RandomResizedCrop(448, scale=(0.2,1), bicubic) / flip / grayscale x3 / normalise) with PIL and
+    torch only (torchvision is not a dependency).  Draws from the torch RNG as torchvision's transforms do, so Python's `random`
+    stream -- which the text half of the item consumes -- is left exactly as in the reference."""
+    import math
+
+    import numpy as np
+    from PIL import Image
+
+    def uni(a, b):
+        return float(torch.empty(1).uniform_(a, b).item())
+
+    def tf(img):
+        w, h = img.size
+        area = w * h
+        box = None
+        for _ in range(10):  # torchvision RandomResizedCrop.get_params
+            target = area * uni(0.2, 1.0)
+            ar = math.exp(uni(math.log(3.0 / 4.0), math.log(4.0 / 3.0)))
+            cw, ch = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
+            if 0 < cw <= w and 0 < ch <= h:
+                top = int(torch.randint(0, h - ch + 1, (1,)).item())
+                left = int(torch.randint(0, w - cw + 1, (1,)).item())
+                box = (left, top, left + cw, top + ch)
+                break
+        if box is None:
+            s = min(w, h)
+            box = ((w - s) // 2, (h - s) // 2, (w - s) // 2 + s, (h - s) // 2 + s)
+        img = img.crop(box).resize((size, size), Image.BICUBIC)
+        if float(torch.rand(1).item()) < 0.5:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        g = np.asarray(img.convert('L'), dtype=np.float32) / 255.0
+        t = torch.from_numpy((g - 0.4721) / 0.3037)
+        return t[None].expand(3, size, size).contiguous()
+
+    return tf
+
+
+class ContextBertDataset(Dataset):
+    """Same constructor and item tuple as the reference class (pretrain_datasets.py:34-199).  `data_root` holds
+    `mimic_wordpiece.json`, `mimic-cxr-2.0.0-entity-llm.csv` (img_path, report, llm_output) and
+    `mimic-cxr-2.0.0-attn-label.csv` (label_i, label_j)."""
+
+    def __init__(self, data_root, max_caption_length: int = 256, transform=None):
+        import tokenizers
+        self.max_caption_length = max_caption_length
+        self.data_root = data_root
+        self.images_list, self.report_list, self.llm_out_list, self.attn_i_list, self.attn_j_list = self.read_csv()
+        self.tokenizer = tokenizers.Tokenizer.from_file(os.path.join(self.data_root, "mimic_wordpiece.json"))
+        self.tokenizer.enable_truncation(max_length=self.max_caption_length)
+        self.tokenizer.enable_padding(length=self.max_caption_length)
+        self.vocab = MaskVocab.from_tokenizer(self.tokenizer)
+        self.transform = transform if transform is not None else default_image_transform(448)
+
+    def __len__(self):
+        return len(self.images_list)
+
+    def read_csv(self):
+        import pandas as pd
+        df = pd.read_csv(os.path.join(self.data_root, 'mimic-cxr-2.0.0-entity-llm.csv'), sep=',')
+        df_attn = pd.read_csv(os.path.join(self.data_root, 'mimic-cxr-2.0.0-attn-label.csv'), sep=',')
+        return df["img_path"], df["report"], df["llm_output"], df_attn["label_i"], df_attn["label_j"]
+
+    def text_item(self, index, rng=random):
+        """Everything of __getitem__ but the image (:113-190): ids, attention_mask, type_ids, masked_ids, weights (all [1, L])."""
+        sent = assemble_report(self.report_list[index], self.llm_out_list[index], rng)
+        encoded = self.tokenizer.encode(sent)
+        ids = torch.tensor(encoded.ids).unsqueeze(0)
+        attention_mask = torch.tensor(encoded.attention_mask).unsqueeze(0)
+        type_ids = torch.tensor(encoded.type_ids).unsqueeze(0)
+        L = ids.shape[1]
+        stream = torch.tensor([[rng.random() for _ in range(2 * L)]], dtype=torch.float64)
+        masked_ids, mask_pos = context_mask(ids, self.vocab, stream)
+        weights = template_weights(ids, mask_pos)
+        return ids, attention_mask, type_ids, masked_ids, weights
+
+    def __getitem__(self, index):
+        image = self.transform(pil_loader(self.images_list[index]))
+        ids, attention_mask, type_ids, masked_ids, weights = self.text_item(index)
+        column = torch.tensor(self.attn_i_list[index]).unsqueeze(0)
+        row = torch.tensor(self.attn_j_list[index]).unsqueeze(0)
+        return image, ids, attention_mask, type_ids, masked_ids, weights, column, row
+
+    def collate_fn(self, instances: List[Tuple]):
+        cols = list(zip(*instances))
+        st = lambda i: torch.cat(cols[i], 0)   # items are [1, L] / [1]: concatenating keeps the batch dimension at B == 1
+        return {"image": torch.stack(cols[0]), "labels": st(1), "attention_mask": st(2), "type_ids": st(3), "ids": st(4),
+                "weights": st(5), "column": st(6), "row": st(7)}
+
+
+class DeviceMasker:
+    """Mask-on-device path for pre-tokenised reports: `ids` [B, L] (already on the GPU) -> (masked ids, weights) with one
+    batched call, uniforms from a torch generator.  Statistically the reference's masker; not the same random stream."""
+
+    def __init__(self, vocab: MaskVocab, device, seed=0):
+        self.vocab = vocab.to(device)
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed)
+
+    def __call__(self, ids):
+        B, L = ids.shape
+        stream = torch.rand((B, 2 * L), generator=self.gen, device=ids.device, dtype=torch.float64)
+        masked, mask_pos = context_mask(ids, self.vocab, stream)
+        return masked, template_weights(ids, mask_pos)
