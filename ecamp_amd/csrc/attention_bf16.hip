@@ -12,6 +12,7 @@
 // Softmax / lse / delta / dropout (Philox, regenerated in backward) are f32 in registers; P and dS are rounded to bf16 only as
 // MFMA operands, like the reference's autocast attention.
 #include "attention.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short v4s16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -27,6 +28,16 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* bas
 #pragma unroll
     for (int i = 0; i < (64 * CPR) / 256; ++i) {
         int idx = tid + 256 * i;
+        int row = idx / CPR, ch = idx % CPR;
+        uint4 v = (r0 + row < nrows) ? *reinterpret_cast<const uint4*>(base + (long)(r0 + row) * st + ch * 8) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(lds + row * PB + ch * 16) = v;
+    }
+}
+// same, for a workgroup whose idle waves have already returned (nthr = 64 * active waves)
+template <int HD>
+__device__ __forceinline__ void stage_tile_n(unsigned char* lds, const bf16_t* base, long st, int r0, int nrows, int tid, int nthr) {
+    constexpr int CPR = HD / 8, PB = TileCfg<HD>::PB;
+    for (int idx = tid; idx < 64 * CPR; idx += nthr) {
         int row = idx / CPR, ch = idx % CPR;
         uint4 v = (r0 + row < nrows) ? *reinterpret_cast<const uint4*>(base + (long)(r0 + row) * st + ch * 8) : make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(lds + row * PB + ch * 16) = v;
@@ -81,6 +92,44 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v, float mul) {
     u.x = pack_bf16x2(v[0] * mul, v[1] * mul);
     u.y = pack_bf16x2(v[2] * mul, v[3] * mul);
     *reinterpret_cast<uint2*>(p) = u;
+}
+
+// keep-mask scales of 4 consecutive attention probabilities (keys j0..j0+3 of query row `row`): element index e = row*Tk + j,
+// mask(e) = word (e & 3) of Philox(counter e >> 2) -- the convention of dropout_scale().  When Tk and j0 are multiples of 4 the
+// four elements share ONE Philox call (it was four, each using a single word: the dropout cost as much as the attention).
+__device__ __forceinline__ void attn_drop4(const AttnArgs& a, uint64_t row, int j0, float inv_keep, float (&m)[4]) {
+    const uint64_t e0 = row * (uint64_t)a.Tk + (uint64_t)j0;
+    if ((a.Tk & 3) == 0) {
+        dropout_scale4(a.seed, a.offset, e0 >> 2, a.drop_p, inv_keep, m);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = dropout_scale(a.seed, a.offset, e0 + r, a.drop_p, inv_keep);
+    }
+}
+
+// The dK/dV kernels hold the transposed tile: a lane owns ONE key kj and 4 consecutive query rows i0..i0+3, whose mask words
+// live in four different Philox outputs (one per row).  The 4 lanes of a quad own keys 4m..4m+3, i.e. exactly the 4 words of
+// each of those outputs: lane x of the quad computes the output of row i0+x, and the quad exchanges words with DPP quad
+// broadcasts -- one Philox call per lane instead of four.  Same mask(e) as everywhere else.
+__device__ __forceinline__ void attn_drop4_col(const AttnArgs& a, uint64_t row0, int kj, int li, float inv_keep, float (&m)[4]) {
+    if ((a.Tk & 3) == 0) {
+        const int x = li & 3;
+        const uint4 P = philox4x32(a.seed, a.offset, ((row0 + (uint64_t)x) * (uint64_t)a.Tk + (uint64_t)(kj & ~3)) >> 2);
+#define ECAMP_QUAD_WORD(R)                                                                                      \
+        do {                                                                                                    \
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)P.x, (R) * 0x55, 0xf, 0xf, false);       \
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)P.y, (R) * 0x55, 0xf, 0xf, false);       \
+            const uint32_t w2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)P.z, (R) * 0x55, 0xf, 0xf, false);       \
+            const uint32_t w3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)P.w, (R) * 0x55, 0xf, 0xf, false);       \
+            const uint32_t w = x == 0 ? w0 : x == 1 ? w1 : x == 2 ? w2 : w3;                                     \
+            m[(R)] = ((float)(w >> 8) * (1.0f / 16777216.0f)) >= a.drop_p ? inv_keep : 0.0f;                     \
+        } while (0)
+        ECAMP_QUAD_WORD(0); ECAMP_QUAD_WORD(1); ECAMP_QUAD_WORD(2); ECAMP_QUAD_WORD(3);
+#undef ECAMP_QUAD_WORD
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = dropout_scale(a.seed, a.offset, (row0 + (uint64_t)r) * (uint64_t)a.Tk + (uint64_t)kj, a.drop_p, inv_keep);
+    }
 }
 
 // =============================================================================================
@@ -153,12 +202,12 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(AttnArgs a) {
         for (int jt = 0; jt < 4; ++jt) {
             float p[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = s[c * 4 + jt][r] * inv;
-                if (a.drop_p > 0.f) {
-                    uint64_t e = ((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk + (c * 64 + jt * 16 + 4 * g + r);
-                    p[r] *= dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
-                }
+            for (int r = 0; r < 4; ++r) p[r] = s[c * 4 + jt][r] * inv;
+            if (a.drop_p > 0.f) {
+                float dm[4];
+                attn_drop4(a, (uint64_t)bh * a.Tq + qi, c * 64 + jt * 16 + 4 * g, inv_keep, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] *= dm[r];
             }
             ptile_write4(pt, li, jt * 16 + 4 * g, p);
         }
@@ -179,8 +228,8 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(AttnArgs a) {
 // =============================================================================================
 // Forward for ANY key length: keys streamed in chunks of 64 with the online-softmax recurrence (running max m, running
 // sum l, O rescaled by exp(m_old - m_new)).  Used when Tk > 256 (ViT-L/16 at 448^2: decoder sequence 785).
-template <int HD>
-__global__ __launch_bounds__(256) void attn16_fwd_long_kernel(AttnArgs a) {
+template <int HD, bool PART>
+__device__ __forceinline__ void attn16_fwd_long_body(const AttnArgs& a, int nthr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* KT = smem;
     unsigned char* VT = smem + TileCfg<HD>::BYTES;
@@ -206,8 +255,13 @@ __global__ __launch_bounds__(256) void attn16_fwd_long_kernel(AttnArgs a) {
 #pragma unroll 1
     for (int c = 0; c < nkc; ++c) {
         __syncthreads();
-        stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
-        stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
+        if (PART) {
+            stage_tile_n<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid, nthr);
+            stage_tile_n<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid, nthr);
+        } else {
+            stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
+            stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
+        }
         __syncthreads();
         f32x4 s[4];
         float cmx = NEG_BIG;
@@ -236,10 +290,12 @@ __global__ __launch_bounds__(256) void attn16_fwd_long_kernel(AttnArgs a) {
             for (int r = 0; r < 4; ++r) {
                 p[r] = s[jt][r] > 0.5f * NEG_BIG ? __expf(s[jt][r] - mn) : 0.f;
                 csum += p[r];
-                if (a.drop_p > 0.f) {
-                    uint64_t e = ((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk + (c * 64 + jt * 16 + 4 * g + r);
-                    p[r] *= dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
-                }
+            }
+            if (a.drop_p > 0.f) {
+                float dm[4];
+                attn_drop4(a, (uint64_t)bh * a.Tq + qi, c * 64 + jt * 16 + 4 * g, inv_keep, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] *= dm[r];
             }
             ptile_write4(pt, li, jt * 16 + 4 * g, p);
         }
@@ -266,10 +322,21 @@ __global__ __launch_bounds__(256) void attn16_fwd_long_kernel(AttnArgs a) {
     }
 }
 
+template <int HD>
+__global__ __launch_bounds__(256) void attn16_fwd_long_kernel(AttnArgs a) {
+    const int nact = min(4, (a.Tq - (int)blockIdx.x * 64 + 15) >> 4);   // see attn16_bwd_dq_kernel
+    if (nact < 4) {
+        if ((int)(threadIdx.x >> 6) >= nact) return;
+        attn16_fwd_long_body<HD, true>(a, nact * 64);
+    } else {
+        attn16_fwd_long_body<HD, false>(a, 256);
+    }
+}
+
 // =============================================================================================
 // dQ (+ delta).  D layouts: S/dP [j = 4g+r][i = li]; dQ [d = 4g+r][i = li]
-template <int HD, int KCH>
-__global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(AttnArgs a) {
+template <int HD, int KCH, bool PART>
+__device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& a, int nthr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* KT = smem;
     unsigned char* VT = smem + TileCfg<HD>::BYTES;
@@ -309,8 +376,13 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll 1
     for (int c = 0; c < nkc; ++c) {
         __syncthreads();
-        stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
-        stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
+        if (PART) {
+            stage_tile_n<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid, nthr);
+            stage_tile_n<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid, nthr);
+        } else {
+            stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
+            stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
+        }
         __syncthreads();
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
@@ -320,18 +392,14 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(AttnArgs a) {
                 s = MFMA(frag_rows<HD>(KT, jt * 16 + li, ks * 4 + g), qf[ks], s);
                 dp = MFMA(frag_rows<HD>(VT, jt * 16 + li, ks * 4 + g), gf[ks], dp);
             }
-            float ds[4];
+            float ds[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.drop_p > 0.f) attn_drop4(a, (uint64_t)bh * a.Tq + qi, c * 64 + jt * 16 + 4 * g, inv_keep, dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int j = c * 64 + jt * 16 + 4 * g + r;
                 bool ok = qok && j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
                 float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
-                float gg = dp[r];
-                if (a.drop_p > 0.f) {
-                    uint64_t e = ((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk + j;
-                    gg *= dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
-                }
-                ds[r] = p * (gg - dl);
+                ds[r] = p * (dp[r] * dm[r] - dl);
             }
             ptile_write4(st, li, jt * 16 + 4 * g, ds);
         }
@@ -350,10 +418,24 @@ __global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(AttnArgs a) {
     }
 }
 
+// The last 64-row workgroup of a sequence may own fewer than four 16-row tiles (T = 197: one): its idle waves return before the
+// first barrier (a barrier only waits for the waves still alive) and the staging loops run over the remaining threads.  Written
+// as two instantiations of one body so that the full workgroups keep exactly the code (and registers) they had.
+template <int HD, int KCH>
+__global__ __launch_bounds__(256) void attn16_bwd_dq_kernel(AttnArgs a) {
+    const int nact = min(4, (a.Tq - (int)blockIdx.x * 64 + 15) >> 4);
+    if (nact < 4) {
+        if ((int)(threadIdx.x >> 6) >= nact) return;
+        attn16_bwd_dq_body<HD, KCH, true>(a, nact * 64);
+    } else {
+        attn16_bwd_dq_body<HD, KCH, false>(a, 256);
+    }
+}
+
 // =============================================================================================
 // dK, dV.  D layouts: S/dP [i = 4g+r][j = li]; dK/dV [d = 4g+r][j = li]
-template <int HD>
-__global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(AttnArgs a) {
+template <int HD, bool PART>
+__device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& a, int nthr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* QT = smem;
     unsigned char* GT = smem + TileCfg<HD>::BYTES;
@@ -385,8 +467,13 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll 1
     for (int c = 0; c < nqc; ++c) {
         __syncthreads();
-        stage_tile<HD>(QT, qb, a.q_st, c * 64, a.Tq, tid);
-        stage_tile<HD>(GT, gb, a.do_st, c * 64, a.Tq, tid);
+        if (PART) {
+            stage_tile_n<HD>(QT, qb, a.q_st, c * 64, a.Tq, tid, nthr);
+            stage_tile_n<HD>(GT, gb, a.do_st, c * 64, a.Tq, tid, nthr);
+        } else {
+            stage_tile<HD>(QT, qb, a.q_st, c * 64, a.Tq, tid);
+            stage_tile<HD>(GT, gb, a.do_st, c * 64, a.Tq, tid);
+        }
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -396,7 +483,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(AttnArgs a) {
                 s = MFMA(frag_rows<HD>(QT, it * 16 + li, ks * 4 + g), kf[ks], s);
                 dp = MFMA(frag_rows<HD>(GT, it * 16 + li, ks * 4 + g), vf[ks], dp);
             }
-            float pd[4], ds[4];
+            float pd[4], ds[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.drop_p > 0.f) attn_drop4_col(a, (uint64_t)bh * a.Tq + (c * 64 + it * 16 + 4 * g), kj, li, inv_keep, dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int i = c * 64 + it * 16 + 4 * g + r;
@@ -404,13 +492,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(AttnArgs a) {
                 float lse = ok ? a.lse[bh * a.Tq + i] : 0.f;
                 float dl = ok ? a.delta[bh * a.Tq + i] : 0.f;
                 float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
-                float m = 1.0f;
-                if (a.drop_p > 0.f) {
-                    uint64_t e = ((uint64_t)bh * a.Tq + i) * (uint64_t)a.Tk + kj;
-                    m = dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
-                }
-                pd[r] = p * m;
-                ds[r] = p * (dp[r] * m - dl);
+                pd[r] = p * dm[r];
+                ds[r] = p * (dp[r] * dm[r] - dl);
             }
             ptile_write4(pt, li, it * 16 + 4 * g, pd);
             ptile_write4(st, li, it * 16 + 4 * g, ds);
@@ -433,6 +516,17 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(AttnArgs a) {
             store4(dkb + (long)kj * a.dk_st + dt * 16 + 4 * g, dk[dt], a.scale);
             store4(dvb + (long)kj * a.dv_st + dt * 16 + 4 * g, dv[dt], 1.0f);
         }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(AttnArgs a) {
+    const int nact = min(4, (a.Tk - (int)blockIdx.x * 64 + 15) >> 4);   // 16-key tiles of this workgroup that hold a key
+    if (nact < 4) {
+        if ((int)(threadIdx.x >> 6) >= nact) return;
+        attn16_bwd_dkv_body<HD, true>(a, nact * 64);
+    } else {
+        attn16_bwd_dkv_body<HD, false>(a, 256);
     }
 }
 
@@ -515,12 +609,12 @@ __global__ __launch_bounds__(256) void attn16r_fwd_kernel(AttnArgs a) {
             for (int jt = 0; jt < 4; ++jt) {
                 float p[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[r] = s[c * 4 + jt][r] * inv;
-                    if (a.drop_p > 0.f) {
-                        uint64_t e = ((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk + (c * 64 + jt * 16 + 4 * g + r);
-                        p[r] *= dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
-                    }
+                for (int r = 0; r < 4; ++r) p[r] = s[c * 4 + jt][r] * inv;
+                if (a.drop_p > 0.f) {
+                    float dm[4];
+                    attn_drop4(a, (uint64_t)bh * a.Tq + qi, c * 64 + jt * 16 + 4 * g, inv_keep, dm);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] *= dm[r];
                 }
                 ptile_write4(pt, li, jt * 16 + 4 * g, p);
             }
