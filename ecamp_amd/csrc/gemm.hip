@@ -17,6 +17,7 @@
 // f32 path (parity mode): same tiling with BK=16 on v_mfma_f32_16x16x4_f32 (exact f32 fma chain).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <stdint.h>
 
 struct GemmArgs {
@@ -826,17 +827,35 @@ static int p8_num_cu() {
     }
     return ncu;
 }
+// A persistent workgroup needs a whole CU (all 160 KB of LDS, all registers): when another kernel holds even one wave on a CU, the
+// workgroup assigned there starts late and the launch takes up to twice as long (tools/hog_probe.py: +11-17 % on the step with a
+// co-resident spinning kernel, against +1-5 % for the 128^2 kernel).  During the backward pass of a multi-GPU run RCCL's
+// all-reduce workgroups are such co-tenants.  Two process-wide switches (ecamp_set_option): "p8_wgrad" = 0 keeps the
+// weight-gradient form off the persistent kernel; "p8_wgrad_reserve_cus" = n launches it with n fewer workgroups than CUs, so
+// that a communication kernel that is already resident (or arrives between two GEMMs) finds CUs without displacing a
+// persistent workgroup.  The data-parallel wrapper sets the reserve; the forward pass has no communication beside it.
+static int g_p8_wgrad = 1;
+static int g_p8_wgrad_reserve = 0;
 static bool p8_selected(int64_t M, int64_t N, int a_kc, int b_kc, int dtype, int split_k) {
     const int env = p8_env();
     if (dtype != ECAMP_BF16 || env == 0) return false;
     if (env == 2) return true;
+    if (!a_kc && !b_kc && !g_p8_wgrad) return false;
     const long items = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
     return (a_kc != 0) == (b_kc != 0) && items >= (long)(0.75 * p8_num_cu());
 }
 
+extern "C" int ecamp_set_option(const char* name, int32_t value) {
+    ECAMP_CHECK_ARG(name != nullptr, "set_option: null name");
+    if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
+    if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
+    return ecamp_set_error(-1, "set_option: unknown option '%s'", name);
+}
+
 extern "C" int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype) {
     if (M <= 0 || N <= 0 || K <= 0) return 1;
-    const int ncu = p8_num_cu();
+    int ncu = p8_num_cu();
+    if (!a_kc && !b_kc && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;   // as the launch does
     // 128^2 kernel: about four resident workgroups per CU
     const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
     long s_old = 1024 / tiles;
@@ -915,7 +934,8 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
                      (!gmul || (ldg % 8 == 0 && al16(gmul))) && (!residual || (ldr % 8 == 0 && al16(residual))) && (!bias || al16(bias)) &&
                      (!g.partial || (N % 4 == 0 && al16(g.partial)));
             g.nsplit = split_k;
-            const int ncu = p8_num_cu();
+            int ncu = p8_num_cu();
+            if (!a_kc && !b_kc && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;
             const long total8 = (long)nbm8 * nbn8 * split_k;
             dim3 grid8((unsigned)(total8 < ncu ? total8 : ncu), 1, 1);
             const size_t shm8 = 5 * P8_STAGE_BYTES;  // the whole 160 KB LDS of a CU

@@ -71,6 +71,12 @@ def linear_dgrad(dy, w, gmul=None, alpha=1.0, alpha_dev=None, residual=None):
 _SPLIT_CACHE = {}
 
 
+def set_option(name, value):
+    """ecamp_set_option + invalidation of the split-count cache (the suggested split depends on the kernel selection)."""
+    call("ecamp_set_option", name.encode(), int(value))
+    _SPLIT_CACHE.clear()
+
+
 def _split_k(n_out, k_in, m, dtype=torch.bfloat16):
     """Split count of the weight-gradient GEMM (M=n_out, N=k_in, K=m): asked of the library, which knows which kernel runs."""
     key = (n_out, k_in, m, dtype)

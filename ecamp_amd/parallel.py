@@ -11,6 +11,7 @@ xGMI is point-to-point (7 links x ~153 GB/s): few large buckets (default 64 MiB)
 efficient; the whole exchange is ~1-8 ms against >= 25 ms of backward at B=256.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -112,6 +113,10 @@ class DistributedDataParallel(nn.Module):
         if dist.is_initialized() and dist.get_world_size(process_group) > 1:
             dist.broadcast(arena.flat_p, src=0, group=process_group)  # C1: parameters rank0 -> all (one 733 MB message)
             arena.sync_shadow()
+            # RCCL's all-reduce workgroups share the CUs with the backward pass, and a persistent one-workgroup-per-CU GEMM
+            # whose CU is taken starts that workgroup late (tools/hog_probe.py): leave 16 CUs to the communication kernels
+            from . import hip_ops
+            hip_ops.set_option("p8_wgrad_reserve_cus", int(os.environ.get("ECAMP_P8_RESERVE_CUS", "16")))
         self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group)
         arena.on_ready = self.reducer.mark_ready
 

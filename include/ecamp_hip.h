@@ -24,6 +24,9 @@ typedef struct ihipStream_t* ecampStream_t; /* == hipStream_t */
 #define ECAMP_BF16 1
 
 int ecamp_abi_version(void);
+/* development aid (tools/hog_probe.py): `blocks` workgroups spinning for `cycles` shader clocks on `stream` -- a stand-in for a
+ * communication kernel sharing the GPU with the training step; no reference counterpart */
+int ecamp_dev_spin(int32_t blocks, int32_t threads, int64_t cycles, ecampStream_t stream);
 const char* ecamp_last_error(void);
 
 /* ---- dense contractions -------------------------------------------------------------------------------------
@@ -44,6 +47,10 @@ int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int6
  * torch.autograd for nn.Linear, e.g. timm Mlp.fc1 at model_ecamp.py:233): it depends on which kernel the shape selects
  * (128^2 tiles, or the persistent 256^2 kernel whose work items should fill whole rounds of the chip).  Pure host arithmetic. */
 int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype);
+/* Process-wide switches with no reference counterpart.  "p8_wgrad" (default 1): 0 keeps weight-gradient GEMMs off the persistent
+ * one-workgroup-per-CU kernel.  "p8_wgrad_reserve_cus" (default 0): launch that kernel with this many fewer workgroups than CUs --
+ * set by the data-parallel wrapper, whose all-reduce kernels share the CUs during backward. */
+int ecamp_set_option(const char* name, int32_t value);
 
 /* ---- LayerNorm (nn.LayerNorm eps 1e-6: model_ecamp.py:69,84,235,256 + timm Block norms; HF LN eps 1e-12:
  * BertSelfOutput/BertOutput/BertEmbeddings/transform).  y = LN(z), z = dropout(x) + residual (both optional). */
