@@ -820,7 +820,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 // ---- kernel selection ------------------------------------------------------------------------------------------
 // ECAMP_GEMM_P8: unset = automatic, 0 = never, 2 = always (development).  Automatic: the persistent 256^2 kernel takes the
 // forward (both operands contraction-contiguous) and weight-gradient (both strided) forms when there are enough 256^2 work
-// items to give ~every CU one; the data-gradient form stays on the 128^2 kernel, which measured equal or better there.
+// items to give ~every CU one; the data-gradient form only when its output is at least as wide as its contraction (fc2, BERT
+// output dense), where it measured 3-15 % faster -- elsewhere the 128^2 kernel is equal or better.
 static int p8_env() {
     static const int v = getenv("ECAMP_GEMM_P8") ? atoi(getenv("ECAMP_GEMM_P8")) : -1;
     return v;
@@ -843,13 +844,15 @@ static int p8_num_cu() {
 // persistent workgroup.  The data-parallel wrapper sets the reserve; the forward pass has no communication beside it.
 static int g_p8_wgrad = 1;
 static int g_p8_wgrad_reserve = 0;
-static bool p8_selected(int64_t M, int64_t N, int a_kc, int b_kc, int dtype, int split_k) {
+static bool p8_selected(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype, int split_k) {
     const int env = p8_env();
     if (dtype != ECAMP_BF16 || env == 0) return false;
     if (env == 2) return true;
     if (!a_kc && !b_kc && !g_p8_wgrad) return false;
     const long items = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
-    return (a_kc != 0) == (b_kc != 0) && items >= (long)(0.75 * p8_num_cu());
+    if (items < (long)(0.75 * p8_num_cu())) return false;
+    if (a_kc && !b_kc) return N >= K;   // data gradient: measured faster only when the output is at least as wide as the contraction
+    return (a_kc != 0) == (b_kc != 0);
 }
 
 extern "C" int ecamp_set_option(const char* name, int32_t value) {
@@ -882,7 +885,7 @@ extern "C" int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_k
         const double score = (double)items / (double)(rounds * ncu) - 0.012 * (sp - 1);
         if (score > best_score + 1e-9) { best_score = score; best = sp; }
     }
-    if (!p8_selected(M, N, a_kc, b_kc, dtype, best)) return (int)s_old;
+    if (!p8_selected(M, N, K, a_kc, b_kc, dtype, best)) return (int)s_old;
     return best;
 }
 
@@ -928,7 +931,7 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     if (split_k > 1) { g.alpha = 1.0f; g.alpha_dev = nullptr; }
     g.nbm = ceil_div(M, BM); g.nbn = ceil_div(N, BN);
     dim3 grid(g.nbm * g.nbn, 1, split_k), block(256);
-    if (p8_selected(M, N, a_kc, b_kc, dtype, split_k)) {
+    if (p8_selected(M, N, K, a_kc, b_kc, dtype, split_k)) {
         const int nbm8 = ceil_div(M, 256), nbn8 = ceil_div(N, 256);
         {
             g.nbm = nbm8; g.nbn = nbn8;
