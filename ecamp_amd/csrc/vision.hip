@@ -5,6 +5,7 @@
 // Masks are never materialised as pixel tensors (the reference kron()s them, model_ecamp.py:196-215):
 // they are evaluated from mask[b, y/16, x/16] and the window bounds on the fly.
 #include "common.h"
+#include <stdint.h>
 
 // ---------------------------------------------------------------------------------------------
 // K1  bicubic resize (aten upsample_bicubic2d semantics: A=-0.75, align_corners=False, no antialias)
@@ -45,9 +46,51 @@ __global__ void bicubic_kernel(const float* __restrict__ src, float* __restrict_
         dst[i] = acc;
     }
 }
+// Exact 2x down-resize (the only ratio on the hot path: 448 -> 224, model_ecamp.py:318): every output pixel has the same tap phase
+// t = 0.5, rows 2y-1..2y+2, columns 2x-1..2x+2 (clamped).  A thread produces 4 consecutive outputs from 4 x 4 aligned float4 loads
+// (the generic kernel issues 64 scalar loads for the same work) in the generic kernel's order of operations -> identical bits.
+__global__ __launch_bounds__(256) void bicubic_half_kernel(const float* __restrict__ src, float* __restrict__ dst, long planes, int Hd, int Wd) {
+    const int Ws = 2 * Wd, Hs = 2 * Hd, W4 = Wd >> 2;
+    const long n = planes * Hd * W4;
+    float w[4];
+    cubic_coeffs(0.5f, w);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int tx = (int)(i % W4), y = (int)((i / W4) % Hd);
+        const long pl = i / ((long)W4 * Hd);
+        const float* p = src + pl * (long)Hs * Ws;
+        const int c0 = 8 * tx;                                  // source column of output 4*tx is 2*(4*tx) = c0; taps start at c0-1
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(2 * y - 1 + a, 0), Hs - 1);
+            const float* r = p + (long)yy * Ws;
+            const float4 v1 = *reinterpret_cast<const float4*>(r + c0);
+            const float4 v2 = *reinterpret_cast<const float4*>(r + c0 + 4);
+            const float left = c0 > 0 ? r[c0 - 1] : r[0];                          // column clamp at the left border
+            const float4 v3 = c0 + 8 < Ws ? *reinterpret_cast<const float4*>(r + c0 + 8) : make_float4(r[Ws - 1], r[Ws - 1], 0.f, 0.f);
+            const float v[11] = {left, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y};   // columns c0-1 .. c0+9
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float row = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) row += w[b] * v[2 * o + b];
+                acc[o] += w[a] * row;
+            }
+        }
+        *reinterpret_cast<float4*>(dst + (pl * Hd + y) * (long)Wd + 4 * tx) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
 extern "C" int ecamp_bicubic_resize(const float* src, float* dst, int64_t planes, int32_t Hs, int32_t Ws, int32_t Hd,
                                     int32_t Wd, hipStream_t stream) {
     ECAMP_CHECK_ARG(src && dst && planes > 0, "bicubic: bad args");
+    if (Hs == 2 * Hd && Ws == 2 * Wd && (Wd & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+        long n4 = planes * Hd * (Wd >> 2);
+        int nb4 = (int)((n4 + 255) / 256);
+        if (nb4 > 16384) nb4 = 16384;
+        hipLaunchKernelGGL(bicubic_half_kernel, dim3(nb4), dim3(256), 0, stream, src, dst, (long)planes, Hd, Wd);
+        ECAMP_LAUNCH_CHECK();
+        return 0;
+    }
     long n = planes * Hd * Wd;
     int nb = (int)((n + 255) / 256);
     if (nb > 8192) nb = 8192;
