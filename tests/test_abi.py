@@ -64,3 +64,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(d, f)
+
+
+def test_gemm_planning_helpers_are_pure_host_arithmetic(lib):
+    """ecamp_gemm_suggest_split / ecamp_set_option (no reference counterpart: they plan the persistent-kernel launches)."""
+    BF16 = 1
+    # weight gradient of timm Mlp.fc1 at configs[1] (dW[3072,768] += dY^T X over 12800 tokens): enough splits to fill whole
+    # rounds of the chip, never more than K/512
+    s = lib.ecamp_gemm_suggest_split(3072, 768, 12800, 0, 0, BF16)
+    assert 1 <= s <= 25
+    assert lib.ecamp_gemm_suggest_split(30000, 768, 32768, 0, 0, BF16) <= 8        # vocab projection: already hundreds of tiles
+    assert lib.ecamp_gemm_suggest_split(0, 0, 0, 0, 0, BF16) == 1                    # degenerate shapes do not crash
+    assert lib.ecamp_set_option(b"p8_wgrad_reserve_cus", 16) == 0
+    s16 = lib.ecamp_gemm_suggest_split(3072, 768, 12800, 0, 0, BF16)
+    assert 1 <= s16 <= 25
+    assert lib.ecamp_set_option(b"p8_wgrad_reserve_cus", 0) == 0
+    assert lib.ecamp_set_option(b"p8_wgrad", 0) == 0 and lib.ecamp_set_option(b"p8_wgrad", 1) == 0
+    assert lib.ecamp_set_option(b"no_such_option", 1) < 0 and b"unknown option" in lib.ecamp_last_error()
+    assert lib.ecamp_set_option(None, 1) < 0
