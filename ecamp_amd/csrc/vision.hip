@@ -5,6 +5,7 @@
 // Masks are never materialised as pixel tensors (the reference kron()s them, model_ecamp.py:196-215):
 // they are evaluated from mask[b, y/16, x/16] and the window bounds on the fly.
 #include "common.h"
+#include <stdlib.h>
 #include <stdint.h>
 
 // ---------------------------------------------------------------------------------------------
@@ -535,6 +536,131 @@ __global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restri
     if (threadIdx.x == 0) atomicAdd(loss_sum, part);
 }
 
+// ---- bf16 matrix-core variant of the SR head (compute_dtype = bf16) ---------------------------------------------------------
+// A 3 -> 3 channel 3x3 convolution is nine 4x4 (out-channel x in-channel, padded from 3) matrix products per pixel.
+// v_mfma_f32_4x4x4_16B_bf16 does sixteen independent 4x4x4 products per wave: block = lane/4, the lane (block, i) supplies row i of
+// A, column i of B and receives column i of D (probed on hardware: tools/probes/mfma4_probe.hip).  With A = the tap's weight matrix
+// (held in registers, the same in every block), B column = the 4 input channels of ONE pixel and D column = that pixel's 4 output
+// channels, a wave convolves 64 pixels with 9 MFMAs and 9 eight-byte LDS reads per lane -- the f32 VALU form above needs 81 FMAs
+// and 108 LDS reads per pixel and is LDS-issue-bound.  Tiles are kept channel-interleaved in LDS: [y][x][4] bf16 = 8 B per pixel.
+// f32 accumulation; u, c1 (and ds, dc1 in backward) are rounded to bf16, the skip connection and the loss stay f32.
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+#define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k((A), (B), (C), 0, 0, 0)
+
+__device__ __forceinline__ bf16x4_t sr_pack4(float a, float b, float c) {
+    uint2 u = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, 0.f));
+    return __builtin_bit_cast(bf16x4_t, u);
+}
+// A operand of tap (ky,kx): row i = lane&3 of M[i][k];  TRANS = false: M = W[oc=i][ic=k] (forward conv), true: M = W[oc=k][ic=i]
+template <bool TRANS>
+__device__ __forceinline__ void sr_load_taps(const float* __restrict__ w, int lane, bf16x4_t (&a)[9]) {
+    const int i = lane & 3;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v[3] = {0.f, 0.f, 0.f};
+        if (i < 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = TRANS ? w[(k * 3 + i) * 9 + t] : w[(i * 3 + k) * 9 + t];
+        }
+        a[t] = sr_pack4(v[0], v[1], v[2]);
+    }
+}
+// 3x3 stencil of one pixel per lane over a channel-interleaved tile of edge ES; FLIP reads (y+2-ky, x+2-kx) (transposed conv)
+template <int ES, bool FLIP>
+__device__ __forceinline__ f32x4_t sr_mfma_conv(const unsigned char* tile, int y, int x, const bf16x4_t (&a)[9]) {
+    f32x4_t acc[3];   // one accumulator per kernel row: three independent MFMA chains instead of one of nine
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        acc[ky] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = FLIP ? y + 2 - ky : y + ky, xx = FLIP ? x + 2 - kx : x + kx;
+            const bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(tile + (yy * ES + xx) * 8);
+            acc[ky] = MFMA4(a[ky * 3 + kx], b, acc[ky]);
+        }
+    }
+    return acc[0] + acc[1] + acc[2];
+}
+
+__global__ __launch_bounds__(256) void sr_mfma_fwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+                                                          const long* __restrict__ column, const long* __restrict__ row, SrP P,
+                                                          float* __restrict__ loss_sum, long B, int R, int win) {
+    __shared__ __attribute__((aligned(16))) unsigned char U16[36 * 36 * 8];   // u, halo 2
+    __shared__ __attribute__((aligned(16))) unsigned char C16[34 * 34 * 8];   // c1, halo 1
+    __shared__ float PP[3 * 20 * 20];                                          // pred_img patch (rows/cols Y0/2-2 .. Y0/2+17, clamped)
+    __shared__ float UC[3 * 32 * 32];                                          // u on the tile itself in f32 (skip connection)
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16x4_t a1[9], a2[9];
+    sr_load_taps<false>(P.w1, lane, a1);
+    sr_load_taps<false>(P.w2, lane, a2);
+    const float b1[3] = {P.b1[0], P.b1[1], P.b1[2]}, b2[3] = {P.b2[0], P.b2[1], P.b2[2]};
+    const int R2 = 2 * R, G = R2 / SRT;
+    float part = 0.f;
+    for (long t = blockIdx.x; t < B * G * G; t += gridDim.x) {
+        const long b = t / (G * G);
+        const int ty = (int)((t / G) % G), tx = (int)(t % G);
+        const int c0 = (int)column[b], r0 = (int)row[b];
+        if (ty < c0 || ty >= c0 + win || tx < r0 || tx >= r0 + win) continue;  // block-uniform
+        const int Y0 = ty * SRT, X0 = tx * SRT;
+        const int ylo = Y0 / 2 - 2, xlo = X0 / 2 - 2;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 3 * 400; idx += 256) {
+            int c = idx / 400, yy = (idx / 20) % 20, xx = idx % 20;
+            int y = min(max(ylo + yy, 0), R - 1), x = min(max(xlo + xx, 0), R - 1);
+            PP[idx] = pred_img[((b * 3 + c) * (long)R + y) * R + x];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 36 * 36; idx += 256) {       // u on halo 2 from the patch
+            const int y = idx / 36, x = idx % 36;
+            const int Y = Y0 - 2 + y, X = X0 - 2 + x;
+            float u[3] = {0.f, 0.f, 0.f};
+            if (Y >= 0 && Y < R2 && X >= 0 && X < R2) {
+                int y0, y1, x0, x1;
+                float wy0, wy1, wx0, wx1;
+                up2_taps(Y, R, y0, y1, wy0, wy1);
+                up2_taps(X, R, x0, x1, wx0, wx1);
+                y0 -= ylo; y1 -= ylo; x0 -= xlo; x1 -= xlo;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* pl = PP + c * 400;
+                    u[c] = wy0 * (wx0 * pl[y0 * 20 + x0] + wx1 * pl[y0 * 20 + x1]) + wy1 * (wx0 * pl[y1 * 20 + x0] + wx1 * pl[y1 * 20 + x1]);
+                }
+            }
+            *reinterpret_cast<bf16x4_t*>(U16 + idx * 8) = sr_pack4(u[0], u[1], u[2]);
+            if (y >= 2 && y < 34 && x >= 2 && x < 34) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) UC[(c * 32 + y - 2) * 32 + x - 2] = u[c];
+            }
+        }
+        __syncthreads();
+        for (int g = wave; g < (34 * 34 + 63) / 64; g += 4) {             // c1 = relu(conv1(u) + b1) on halo 1, 0 outside the image
+            const int p = g * 64 + lane, pc = min(p, 34 * 34 - 1);
+            const int y = pc / 34, x = pc % 34;
+            const f32x4_t acc = sr_mfma_conv<36, false>(U16, y, x, a1);
+            const int Y = Y0 - 1 + y, X = X0 - 1 + x;
+            const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+            if (p < 34 * 34)
+                *reinterpret_cast<bf16x4_t*>(C16 + p * 8) = in ? sr_pack4(fmaxf(acc[0] + b1[0], 0.f), fmaxf(acc[1] + b1[1], 0.f), fmaxf(acc[2] + b1[2], 0.f))
+                                                               : sr_pack4(0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        for (int g = wave; g < 16; g += 4) {                               // s = relu(conv2(c1) + b2 + u); loss
+            const int p = g * 64 + lane, y = p >> 5, x = p & 31;
+            const f32x4_t acc = sr_mfma_conv<34, false>(C16, y, x, a2);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                float sv = fmaxf(acc[o] + b2[o] + UC[(o * 32 + y) * 32 + x], 0.f);
+                float d = sv - big[((b * 3 + o) * (long)R2 + Y0 + y) * R2 + X0 + x];
+                part += d * d;
+            }
+        }
+    }
+    part = block_sum_256(part, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, part);
+}
+
 // block-level reduction of NV per-thread partials into global f32 (one atomic per value per block)
 template <int NV>
 __device__ __forceinline__ void reduce_to_global(float (&v)[NV], float* __restrict__ out, float* sh /* [4][NV] */) {
@@ -794,16 +920,320 @@ __global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __res
     }
 }
 
+// backward on the matrix cores: the four stencils (conv1, conv2, conv2^T, conv1^T) as in sr_mfma_fwd_kernel; the weight-gradient
+// stage keeps the tap-split f32 accumulation of sr_fused_bwd_kernel, reading the bf16 tiles.  ds / dc1 are rounded to bf16.
+__device__ __forceinline__ float sr_ch(const unsigned char* tile, int pix, int c) {   // channel c of interleaved pixel `pix` as f32
+    return __uint_as_float((uint32_t)(*reinterpret_cast<const unsigned short*>(tile + pix * 8 + c * 2)) << 16);
+}
+__global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+                                                             const long* __restrict__ column, const long* __restrict__ row, SrP P,
+                                                             float* __restrict__ dsr, float* __restrict__ gw, long B, int R, int win) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    unsigned char* U16 = smem8;                          // 42 x 42 x 8 B  (halo 5)
+    unsigned char* C16 = U16 + 42 * 42 * 8;              // 40 x 40 x 8 B  (halo 4)
+    unsigned char* DS16 = C16 + 40 * 40 * 8;             // 38 x 38 x 8 B  (halo 3)
+    unsigned char* DC16 = DS16 + 38 * 38 * 8;            // 36 x 36 x 8 B  (halo 2)
+    float* DU = reinterpret_cast<float*>(DC16 + 36 * 36 * 8);   // 3 x 34 x 34 f32 (halo 1); first holds the 3 x 24 x 24 pred_img patch
+    float* PP = DU;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the four tap sets (conv1, conv2, conv2^T, conv1^T) x 9 taps x 4 operand rows live in LDS and are fetched per stage: holding
+    // all of them in registers (72 VGPRs) next to the 42 weight-gradient accumulators spilled
+    __shared__ bf16x4_t TAPS[4][9][4];
+    if (threadIdx.x < 144) {
+        const int c = threadIdx.x / 36, t = (threadIdx.x / 4) % 9, i = threadIdx.x & 3;
+        const float* w = (c == 0 || c == 3) ? P.w1 : P.w2;
+        const bool trans = c >= 2;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (i < 3) {
+            for (int kk = 0; kk < 3; ++kk) v[kk] = trans ? w[(kk * 3 + i) * 9 + t] : w[(i * 3 + kk) * 9 + t];
+        }
+        TAPS[c][t][i] = sr_pack4(v[0], v[1], v[2]);
+    }
+#define SR_TAPS(NAME, C)                                                     \
+    bf16x4_t NAME[9];                                                        \
+    _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) NAME[t_] = TAPS[(C)][t_][lane & 3]
+    const float b1[3] = {P.b1[0], P.b1[1], P.b1[2]}, b2[3] = {P.b2[0], P.b2[1], P.b2[2]};
+    const int R2 = 2 * R, G = R2 / SRT, PT = SRT / 2;
+    const long T = B * G * G;
+    const int tap0 = wave * 7, ntap = wave == 3 ? 6 : 7;
+    int off1[7], off2[7];   // byte offsets of tap (i,ky,kx) in the interleaved U / C1 tiles
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        int tap = min(tap0 + t, 26);
+        int i = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+        off1[t] = (ky * 42 + kx) * 8 + i * 2;
+        off2[t] = (ky * 40 + kx) * 8 + i * 2;
+    }
+    float g1[7][3], g2[7][3], bb1[3], bb2[3];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) g1[t][o] = g2[t][o] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) bb1[o] = bb2[o] = 0.f;
+    const int py = threadIdx.x / PT, px = threadIdx.x % PT;  // this thread's pred_img pixel of a 16x16 tile
+
+    // Tiles are software-pipelined: the pred_img patch and the `big` values of the NEXT reachable tile are requested while the
+    // current one is computed (a tile is otherwise two dependent global round trips at 2 workgroups per CU: 0.9 of 3.2 ms).
+    // next reachable tile at or after t; tiles with no window pixel within reach get a zero gradient on the way
+    auto advance = [&](long t) {
+        for (; t < T; t += gridDim.x) {
+            const long b = t / (G * G);
+            const int ty = (int)((t / G) % G), tx = (int)(t % G);
+            const int c0 = (int)column[b], r0 = (int)row[b];
+            if (!(ty < c0 - 1 || ty > c0 + win || tx < r0 - 1 || tx > r0 + win)) break;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dsr[((b * 3 + c) * (long)R + ty * PT + py) * R + tx * PT + px] = 0.f;
+        }
+        return t;
+    };
+    float pp[7], bigv[6][3];
+    bool inw[6];
+    auto fetch_patch = [&](long t) {
+        const long b = t / (G * G);
+        const int ylo = (int)((t / G) % G) * (SRT / 2) - 4, xlo = (int)(t % G) * (SRT / 2) - 4;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            const int c = idx / 576, yy = (idx / 24) % 24, xx = idx % 24;
+            const int y = min(max(ylo + yy, 0), R - 1), x = min(max(xlo + xx, 0), R - 1);
+            pp[k] = idx < 3 * 576 ? pred_img[((b * 3 + c) * (long)R + y) * R + x] : 0.f;
+        }
+    };
+    auto fetch_big = [&](long t) {   // pixel (wave + 4j)*64 + lane of the 38 x 38 halo-3 region
+        const long b = t / (G * G);
+        const int Y0 = (int)((t / G) % G) * SRT, X0 = (int)(t % G) * SRT;
+        const int c0 = (int)column[b], r0 = (int)row[b];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int p = (wave + 4 * j) * 64 + lane;
+            const int y = p / 38, x = p % 38;
+            const int Y = Y0 - 3 + y, X = X0 - 3 + x;
+            bool in = p < 38 * 38 && Y >= 0 && Y < R2 && X >= 0 && X < R2;
+            if (in) {
+                int gy = Y / SRT, gx = X / SRT;
+                in = gy >= c0 && gy < c0 + win && gx >= r0 && gx < r0 + win;
+            }
+            inw[j] = in;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) bigv[j][o] = in ? big[((b * 3 + o) * (long)R2 + Y) * R2 + X] : 0.f;
+        }
+    };
+    long t = advance(blockIdx.x);
+    if (t < T) {
+        fetch_patch(t);
+        fetch_big(t);
+    }
+    while (t < T) {
+        const long b = t / (G * G);
+        const int ty = (int)((t / G) % G), tx = (int)(t % G);
+        const int Y0 = ty * SRT, X0 = tx * SRT;
+        const int ylo = Y0 / 2 - 4, xlo = X0 / 2 - 4;
+        __syncthreads();   // the previous tile's stage 8 is done with DU (= the patch buffer)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            if (idx < 3 * 576) PP[idx] = pp[k];
+        }
+        const long tn = advance(t + gridDim.x);
+        if (tn < T) fetch_patch(tn);          // in flight until the next iteration
+        __syncthreads();
+        // (2) u on halo 5
+        for (int idx = threadIdx.x; idx < 42 * 42; idx += 256) {
+            const int y = idx / 42, x = idx % 42;
+            const int Y = Y0 - 5 + y, X = X0 - 5 + x;
+            float u[3] = {0.f, 0.f, 0.f};
+            if (Y >= 0 && Y < R2 && X >= 0 && X < R2) {
+                int y0, y1, x0, x1;
+                float wy0, wy1, wx0, wx1;
+                up2_taps(Y, R, y0, y1, wy0, wy1);
+                up2_taps(X, R, x0, x1, wx0, wx1);
+                y0 -= ylo; y1 -= ylo; x0 -= xlo; x1 -= xlo;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* pl = PP + c * 576;
+                    u[c] = wy0 * (wx0 * pl[y0 * 24 + x0] + wx1 * pl[y0 * 24 + x1]) + wy1 * (wx0 * pl[y1 * 24 + x0] + wx1 * pl[y1 * 24 + x1]);
+                }
+            }
+            *reinterpret_cast<bf16x4_t*>(U16 + idx * 8) = sr_pack4(u[0], u[1], u[2]);
+        }
+        __syncthreads();
+        // (3) c1 on halo 4
+        {
+            SR_TAPS(a1, 0);
+            for (int g = wave; g < (40 * 40 + 63) / 64; g += 4) {
+                const int p = g * 64 + lane, pc = min(p, 40 * 40 - 1);
+                const int y = pc / 40, x = pc % 40;
+                const f32x4_t acc = sr_mfma_conv<42, false>(U16, y, x, a1);
+                const int Y = Y0 - 4 + y, X = X0 - 4 + x;
+                const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+                if (p < 40 * 40)
+                    *reinterpret_cast<bf16x4_t*>(C16 + p * 8) = in ? sr_pack4(fmaxf(acc[0] + b1[0], 0.f), fmaxf(acc[1] + b1[1], 0.f), fmaxf(acc[2] + b1[2], 0.f))
+                                                                   : sr_pack4(0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        // (4) ds on halo 3: [pixel in window] * (s - big) * [s > 0]
+        {
+            SR_TAPS(a2, 1);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int g = wave + 4 * j;
+                if (g < (38 * 38 + 63) / 64) {   // wave-uniform
+                    const int p = g * 64 + lane, pc = min(p, 38 * 38 - 1);
+                    const int y = pc / 38, x = pc % 38;
+                    const f32x4_t acc = sr_mfma_conv<40, false>(C16, y, x, a2);
+                    float d[3] = {0.f, 0.f, 0.f};
+                    if (inw[j]) {
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) {
+                            float sv = fmaxf(acc[o] + b2[o] + sr_ch(U16, (y + 2) * 42 + x + 2, o), 0.f);
+                            d[o] = sv > 0.f ? sv - bigv[j][o] : 0.f;
+                        }
+                    }
+                    if (p < 38 * 38) *reinterpret_cast<bf16x4_t*>(DS16 + p * 8) = sr_pack4(d[0], d[1], d[2]);
+                }
+            }
+        }
+        if (tn < T) fetch_big(tn);            // bigv / inw are free again: request the next tile's targets
+        __syncthreads();
+        // (5) dc1 on halo 2 = [c1 > 0] * conv2^T(ds)
+        {
+            SR_TAPS(a2t, 2);
+            for (int g = wave; g < (36 * 36 + 63) / 64; g += 4) {
+                const int p = g * 64 + lane, pc = min(p, 36 * 36 - 1);
+                const int y = pc / 36, x = pc % 36;
+                const f32x4_t acc = sr_mfma_conv<38, true>(DS16, y, x, a2t);
+                const int Y = Y0 - 2 + y, X = X0 - 2 + x;
+                const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+                float d[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) d[i] = (in && sr_ch(C16, (y + 2) * 40 + x + 2, i) > 0.f) ? acc[i] : 0.f;
+                if (p < 36 * 36) *reinterpret_cast<bf16x4_t*>(DC16 + p * 8) = sr_pack4(d[0], d[1], d[2]);
+            }
+        }
+        __syncthreads();
+        // (6) weight gradients over the 32x32 centre: conv2 from (ds, c1), conv1 from (dc1, u)
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int idx = lane + 64 * j;
+            const int y = idx >> 5, x = idx & 31;
+            const int pd2 = (y + 3) * 38 + x + 3, pd1 = (y + 2) * 36 + x + 2;
+            const float d2[3] = {sr_ch(DS16, pd2, 0), sr_ch(DS16, pd2, 1), sr_ch(DS16, pd2, 2)};
+            const float d1[3] = {sr_ch(DC16, pd1, 0), sr_ch(DC16, pd1, 1), sr_ch(DC16, pd1, 2)};
+            const unsigned char* c1p = C16 + ((y + 3) * 40 + x + 3) * 8;   // tap (ky,kx) reads centre + (ky-1, kx-1)
+            const unsigned char* up = U16 + ((y + 4) * 42 + x + 4) * 8;
+#pragma unroll
+            for (int tt = 0; tt < 7; ++tt) {
+                if (tt < ntap) {
+                    const float v2 = __uint_as_float((uint32_t)(*reinterpret_cast<const unsigned short*>(c1p + off2[tt])) << 16);
+                    const float v1 = __uint_as_float((uint32_t)(*reinterpret_cast<const unsigned short*>(up + off1[tt])) << 16);
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        g2[tt][o] += d2[o] * v2;
+                        g1[tt][o] += d1[o] * v1;
+                    }
+                }
+            }
+            if (wave == 3) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    bb2[o] += d2[o];
+                    bb1[o] += d1[o];
+                }
+            }
+        }
+        __syncthreads();
+        // (7) du on halo 1 (f32, planar) = ds + conv1^T(dc1)
+        {
+            SR_TAPS(a1t, 3);
+            for (int g = wave; g < (34 * 34 + 63) / 64; g += 4) {
+                const int p = g * 64 + lane, pc = min(p, 34 * 34 - 1);
+                const int y = pc / 34, x = pc % 34;
+                const f32x4_t acc = sr_mfma_conv<36, true>(DC16, y, x, a1t);
+                const int Y = Y0 - 1 + y, X = X0 - 1 + x;
+                const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+                if (p < 34 * 34) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) DU[(i * 34 + y) * 34 + x] = in ? acc[i] + sr_ch(DS16, (y + 2) * 38 + x + 2, i) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // (8) transpose of the bilinear x2: each pred_img pixel gathers the <= 4x4 du values whose footprint touches it; the
+        // 4 + 4 row / column weights do not depend on the channel
+        {
+            const int y = ty * PT + py, x = tx * PT + px;
+            float wyv[4], wxv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int Y = 2 * y - 1 + k, X = 2 * x - 1 + k;
+                int q0, q1;
+                float w0, w1;
+                wyv[k] = 0.f;
+                wxv[k] = 0.f;
+                if (Y >= 0 && Y < R2) {
+                    up2_taps(Y, R, q0, q1, w0, w1);
+                    wyv[k] = (q0 == y ? w0 : 0.f) + (q1 == y ? w1 : 0.f);
+                }
+                if (X >= 0 && X < R2) {
+                    up2_taps(X, R, q0, q1, w0, w1);
+                    wxv[k] = (q0 == x ? w0 : 0.f) + (q1 == x ? w1 : 0.f);
+                }
+            }
+            const int yb = 2 * py, xb = 2 * px;   // DU coordinates of (2y-1, 2x-1): (Y - Y0 + 1, X - X0 + 1)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    float rowv = 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) rowv += wxv[kx] * DU[(c * 34 + yb + ky) * 34 + xb + kx];
+                    acc += wyv[ky] * rowv;
+                }
+                dsr[((b * 3 + c) * (long)R + y) * R + x] = acc;
+            }
+        }
+        t = tn;
+    }
+#undef SR_TAPS
+    // one cross-lane reduction per kernel: gw layout {dW1[81], db1[3], dW2[81], db2[3]}, dW[o][i][ky][kx] = index o*27 + tap
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float s1 = wave_sum(g1[tt][o]), s2 = wave_sum(g2[tt][o]);
+            if (lane == 0 && tt < ntap) {
+                atomicAdd(gw + o * 27 + tap0 + tt, s1);
+                atomicAdd(gw + 84 + o * 27 + tap0 + tt, s2);
+            }
+        }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float s1 = wave_sum(bb1[o]), s2 = wave_sum(bb2[o]);
+        if (lane == 0 && wave == 3) {
+            atomicAdd(gw + 81 + o, s1);
+            atomicAdd(gw + 84 + 81 + o, s2);
+        }
+    }
+}
+
 extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B, int32_t R,
-                            int32_t super_patch, int32_t window, hipStream_t stream) {
+                            int32_t super_patch, int32_t window, int32_t mode, hipStream_t stream) {
     ECAMP_CHECK_ARG(pred_img && big && column && row && w1 && b1 && w2 && b2 && loss_sum, "sr_fwd: null pointer");
     ECAMP_CHECK_ARG(super_patch == SRT && (2 * R) % SRT == 0, "sr_fwd: the fused SR head is built for 32-px super-patches (patch 16)");
+    ECAMP_CHECK_ARG(mode == 0 || mode == 1, "sr_fwd: mode must be 0 (f32 VALU) or 1 (bf16 matrix cores)");
     SrP W = {w1, b1, w2, b2};
     long tiles = B * (2 * R / SRT) * (2 * R / SRT);
     int nb = (int)(tiles < 2048 ? tiles : 2048);
-    hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
-                       (long)B, R, window);
+    if (mode == 1)
+        hipLaunchKernelGGL(sr_mfma_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
+                           (long)B, R, window);
+    else
+        hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
+                           (long)B, R, window);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
@@ -812,9 +1242,10 @@ extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64
 // folds g_res*2/N in when adding into the .grad views).
 extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* dsr, float* gw_ws, int64_t B, int32_t R,
-                            int32_t super_patch, int32_t window, hipStream_t stream) {
+                            int32_t super_patch, int32_t window, int32_t mode, hipStream_t stream) {
     ECAMP_CHECK_ARG(pred_img && big && column && row && w1 && b1 && w2 && b2 && dsr && gw_ws, "sr_bwd: null pointer");
     ECAMP_CHECK_ARG(super_patch == SRT && (2 * R) % SRT == 0, "sr_bwd: the fused SR head is built for 32-px super-patches (patch 16)");
+    ECAMP_CHECK_ARG(mode == 0 || mode == 1, "sr_bwd: mode must be 0 (f32 VALU) or 1 (bf16 matrix cores)");
     SrP W = {w1, b1, w2, b2};
     long tiles = B * (2 * R / SRT) * (2 * R / SRT);
     int nb = (int)(tiles < 1024 ? tiles : 1024);
@@ -823,6 +1254,18 @@ extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sr_fused_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         once = true;
+    }
+    if (mode == 1) {
+        const size_t shm8 = (size_t)(42 * 42 + 40 * 40 + 38 * 38 + 36 * 36) * 8 + (size_t)3 * 34 * 34 * sizeof(float);
+        static bool once8 = false;
+        if (!once8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sr_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
+            once8 = true;
+        }
+        hipLaunchKernelGGL(sr_mfma_bwd_kernel, dim3(nb), dim3(256), shm8, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr, gw_ws,
+                           (long)B, R, window);
+        ECAMP_LAUNCH_CHECK();
+        return 0;
     }
     hipLaunchKernelGGL(sr_fused_bwd_kernel, dim3(nb), dim3(256), shm, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr, gw_ws,
                        (long)B, R, window);

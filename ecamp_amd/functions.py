@@ -175,8 +175,10 @@ class ImgLossFn(torch.autograd.Function):
         sums = ops.zeros((2,), xd.device)
         pred_img = ops.unpatchify_mim(pred, imgs, mask, sums[0:], B, R, p)
         sr = m.super_res
+        # bf16 mode: the SR stencils run on the matrix cores (u / c1 / ds / dc1 rounded to bf16); f32 mode keeps the exact f32 stencils
+        sr_mode = 0 if cd == torch.float32 else 1
         ops.sr_fwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data, sr.conv2.bias.data,
-                   sums[1:], 2 * p, m.sr_window)
+                   sums[1:], 2 * p, m.sr_window, sr_mode)
         n1, n2 = B * 3 * R * R, B * 3 * 4 * R * R
         ctx.s = (xd, mean, rstd, h, pred_img, imgs, mask, big, column, row, m, B, n1, n2)
         m._aux = dict(pred=pred, pred_img=pred_img) if m.keep_aux else None
@@ -193,7 +195,7 @@ class ImgLossFn(torch.autograd.Function):
         sr = m.super_res
         ws = ops.zeros((168,), xd.device)
         dsr = ops.sr_bwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data,
-                         sr.conv2.bias.data, ws, 2 * p, m.sr_window)
+                         sr.conv2.bias.data, ws, 2 * p, m.sr_window, 0 if cd == torch.float32 else 1)
         ops.scaled_accum(ws[0:81], G(sr.conv1.weight), gm_gs, 1)
         ops.scaled_accum(ws[81:84], G(sr.conv1.bias), gm_gs, 1)
         ops.scaled_accum(ws[84:165], G(sr.conv2.weight), gm_gs, 1)

@@ -278,17 +278,18 @@ def img_loss_bwd(pred_img, imgs, mask, dsr, gm_gs, B, R, p, dtype):
     return dpred
 
 
-def sr_fwd(pred_img, big, column, row, w1, b1, w2, b2, loss_sum, super_patch, window):
+def sr_fwd(pred_img, big, column, row, w1, b1, w2, b2, loss_sum, super_patch, window, mode=0):
+    """mode 0: f32 stencils (parity); 1: bf16 matrix cores."""
     B, _, R, _ = pred_img.shape
     call("ecamp_sr_fwd", ptr(pred_img), ptr(big), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(loss_sum), B, R,
-         super_patch, window, stream())
+         super_patch, window, int(mode), stream())
 
 
-def sr_bwd(pred_img, big, column, row, w1, b1, w2, b2, gw_ws, super_patch, window):
+def sr_bwd(pred_img, big, column, row, w1, b1, w2, b2, gw_ws, super_patch, window, mode=0):
     B, _, R, _ = pred_img.shape
     dsr = torch.empty((B, 3, R, R), device=pred_img.device, dtype=torch.float32)
     call("ecamp_sr_bwd", ptr(pred_img), ptr(big), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dsr), ptr(gw_ws), B, R,
-         super_patch, window, stream())
+         super_patch, window, int(mode), stream())
     return dsr
 
 

@@ -116,10 +116,11 @@ int ecamp_img_loss_bwd(const float* pred_img, const float* imgs, const float* ma
                        void* dpred, int64_t B, int32_t R, int32_t p, int32_t dtype, ecampStream_t stream);
 int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
                  const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B, int32_t R, int32_t super_patch,
-                 int32_t window, ecampStream_t stream); /* model_ecamp.py:28-46,196-215,291-299; fused, LDS-resident */
+                 int32_t window, int32_t mode, ecampStream_t stream); /* model_ecamp.py:28-46,196-215,291-299; fused, LDS-resident.
+                 mode 0: f32 VALU stencils (parity); mode 1: bf16 matrix cores (4x4x4 MFMA per tap), f32 accumulate / skip / loss */
 int ecamp_sr_bwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
                  const float* b1, const float* w2, const float* b2, float* dsr, float* gw_ws, int64_t B, int32_t R,
-                 int32_t super_patch, int32_t window, ecampStream_t stream);
+                 int32_t super_patch, int32_t window, int32_t mode, ecampStream_t stream);
 int ecamp_scaled_accum(const float* ws, float* grad, const float* scale_dev, int32_t idx, int32_t n, ecampStream_t stream);
 
 /* ---- report side ---- */

@@ -322,6 +322,44 @@ def test_unshuffle(dev, dtype):
     check("unshuffle dmask_token", gm, mr.grad.view(-1), 1e-5)
 
 
+@pytest.mark.parametrize("R,win", [(64, 3), (32, 2), (96, 4)])
+def test_sr_head_matrix_core_mode(dev, R, win):
+    """mode 1 of ecamp_sr_fwd/bwd (bf16 4x4x4 MFMA stencils, used when compute_dtype is bf16) against torch autograd of the reference
+    SR head (model_ecamp.py:28-46,291-299).  u, c1, ds, dc1 are rounded to bf16: loss within 2e-3, gradients within a few 1e-2 of
+    their scale on average; single pixels whose ReLU gate sits within rounding of zero may flip (that is what bf16 activations do)."""
+    o = ops()
+    B = 3
+    pimg, big = gen(B, 3, R, R, seed=2), gen(B, 3, 2 * R, 2 * R, seed=3)
+    column, row = torch.tensor([0, 1, 1]), torch.tensor([1, 0, 1])
+    ws = [gen(3, 3, 3, 3, seed=5, scale=0.3), gen(3, seed=6, scale=0.1), gen(3, 3, 3, 3, seed=7, scale=0.3), gen(3, seed=8, scale=0.1)]
+    pr = pimg.clone().requires_grad_(True)
+    wr = [t.clone().requires_grad_(True) for t in ws]
+    u = F.interpolate(pr, scale_factor=2, mode="bilinear", align_corners=False)
+    sr = F.relu(F.conv2d(F.relu(F.conv2d(u, wr[0], wr[1], padding=1)), wr[2], wr[3], padding=1) + u)
+    G = 2 * R // 32
+    sm = torch.zeros(B, G, G)
+    for i in range(B):
+        sm[i, column[i]:column[i] + win, row[i]:row[i] + win] = 1
+    spm = torch.kron(sm, torch.ones(32, 32))[:, None].expand(-1, 3, -1, -1)
+    loss = 0.5 * ((sr * spm - big * spm) ** 2).sum()
+    loss.backward()
+    wd = [t.to(dev).contiguous() for t in ws]
+    s = torch.zeros(1, device=dev)
+    o.sr_fwd(pimg.to(dev), big.to(dev), column.to(dev), row.to(dev), *wd, s, 32, win, 1)
+    assert abs(s.item() - 2 * loss.item()) / (2 * loss.item()) < 2e-3
+    gw = torch.zeros(168, device=dev)
+    dsr = o.sr_bwd(pimg.to(dev), big.to(dev), column.to(dev), row.to(dev), *wd, gw, 32, win, 1).cpu()
+    err = (dsr - pr.grad).abs()
+    print("sr mfma R=%d: mean |err| / mean |grad| = %.3e, grad-norm rel %.3e" % (R, err.mean() / pr.grad.abs().mean(), abs(dsr.norm() - pr.grad.norm()) / pr.grad.norm()))
+    assert err.mean() / pr.grad.abs().mean() < 3e-2
+    assert abs(dsr.norm() - pr.grad.norm()) / pr.grad.norm() < 2e-2
+    assert (err > 0.25 * pr.grad.abs().max()).float().mean() < 1e-3          # gate flips are rare
+    check("d conv1.weight (mfma)", gw[0:81], wr[0].grad.view(-1), 2e-2)
+    check("d conv1.bias (mfma)", gw[81:84], wr[1].grad, 2e-2)
+    check("d conv2.weight (mfma)", gw[84:165], wr[2].grad.view(-1), 2e-2)
+    check("d conv2.bias (mfma)", gw[165:168], wr[3].grad, 2e-2)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("R,win", [(64, 3), (32, 2)])
 def test_image_losses_and_sr_head(dev, dtype, R, win):
