@@ -51,6 +51,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise EcampHipError("libecamp_hip.so not found at %s -- run `python -m ecamp_amd.build` (there is no CPU fallback)" % LIB_PATH)
+    # torch first: it brings its own HIP runtime, and a process that loads /opt/rocm's runtime (through this library) before
+    # torch's ends up with two runtimes of which the second sees no device ("no ROCm-capable device is detected")
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (ret, args) in _protos.items():
