@@ -19,12 +19,13 @@ import torch.nn as nn
 
 
 class GradReducer:
-    def __init__(self, flat_g, offsets, sizes, unused=(), bucket_mb=64.0, group=None):
+    def __init__(self, flat_g, offsets, sizes, unused=(), bucket_mb=64.0, group=None, force_comm=False):
         self.flat_g, self.offsets, self.sizes = flat_g, list(offsets), list(sizes)
         self.unused = set(unused)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.enabled = True
+        self.force_comm = force_comm  # run the collectives even in a 1-rank group (exercises the RCCL / stream plumbing in tests)
         cap = int(bucket_mb * 1024 * 1024) // flat_g.element_size()
         n = len(self.offsets)
         ends = [self.offsets[i + 1] if i + 1 < n else flat_g.numel() for i in range(n)]
@@ -49,7 +50,7 @@ class GradReducer:
         self._cb_queued = False
 
     def _launch(self, b):
-        if self.launched[b] or self.world == 1:
+        if self.launched[b] or (self.world == 1 and not self.force_comm):
             self.launched[b] = True
             return
         self.launched[b] = True
@@ -106,7 +107,8 @@ class GradReducer:
 class DistributedDataParallel(nn.Module):
     """Minimal DDP surface used by main_pretrain.py (`.module`, forward passthrough, `no_sync`)."""
 
-    def __init__(self, module, device_ids=None, find_unused_parameters=False, bucket_cap_mb=64.0, process_group=None, **_ignored):
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, bucket_cap_mb=64.0, process_group=None, force_comm=False,
+                 **_ignored):
         super().__init__()
         self.module = module
         arena = module.prepare()
@@ -117,7 +119,7 @@ class DistributedDataParallel(nn.Module):
             # whose CU is taken starts that workgroup late (tools/hog_probe.py): leave 16 CUs to the communication kernels
             from . import hip_ops
             hip_ops.set_option("p8_wgrad_reserve_cus", int(os.environ.get("ECAMP_P8_RESERVE_CUS", "16")))
-        self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group)
+        self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group, force_comm)
         arena.on_ready = self.reducer.mark_ready
 
     def forward(self, *args, **kwargs):

@@ -87,3 +87,39 @@ def test_checkpoint_round_trip_and_torch_adamw_compat(dev, tmp_path):
     m3.prepare()
     misc.load_model(args=argparse.Namespace(resume=os.path.join(tmp_path, "mae.pth")), model_without_ddp=m3, optimizer=None, loss_scaler=None)
     assert torch.equal(m3.blocks[0].norm1.weight.cpu(), ck["model"]["blocks.0.norm1.weight"])
+
+
+def test_ddp_wrapper_runs_rccl_on_the_side_stream(dev):
+    """One-rank RCCL group with the collectives forced on: the bucketed all-reduce (AVG over one rank = identity) runs on the side
+    HIP stream behind the backward stages, and the gradients equal those of the unwrapped model."""
+    import os
+
+    import torch.distributed as dist
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.parallel import DistributedDataParallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        batch = synthetic_batch(2, 32, 448, seed=3, device=dev)
+        noise = torch.rand(2, 196, generator=torch.Generator().manual_seed(0))
+        grads = []
+        for wrap in (False, True):
+            torch.manual_seed(0)
+            model = me.ecamp_tiny(compute_dtype=torch.float32).to(dev)
+            model.eval()
+            net = DistributedDataParallel(model, bucket_cap_mb=8.0, force_comm=True) if wrap else model
+            out = net(batch, noise=noise)
+            sum(out).backward()
+            torch.cuda.synchronize()
+            if wrap:
+                assert len(net.reducer.buckets) > 4 and net.reducer.use_avg
+            grads.append(model.arena.flat_g.clone())
+        assert torch.isfinite(grads[1]).all()
+        assert float((grads[0] - grads[1]).abs().max()) <= 1e-6 * float(grads[0].abs().max())
+    finally:
+        if created:
+            dist.destroy_process_group()
