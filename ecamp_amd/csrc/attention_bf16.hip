@@ -234,6 +234,7 @@ __device__ __forceinline__ void attn16_fwd_long_body(const AttnArgs& a, int nthr
     unsigned char* KT = smem;
     unsigned char* VT = smem + TileCfg<HD>::BYTES;
     unsigned char* PT = smem + 2 * TileCfg<HD>::BYTES;
+    int* KM = reinterpret_cast<int*>(PT + 4 * 2048);    // attend-flags of the 64 keys of the staged chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
     const int q0 = blockIdx.x * 64 + wave * 16;
@@ -262,6 +263,10 @@ __device__ __forceinline__ void attn16_fwd_long_body(const AttnArgs& a, int nthr
             stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
             stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
         }
+        if (tid < 64) {
+            const int j = c * 64 + tid;
+            KM[tid] = (j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0)) ? 1 : 0;
+        }
         __syncthreads();
         f32x4 s[4];
         float cmx = NEG_BIG;
@@ -270,11 +275,11 @@ __device__ __forceinline__ void attn16_fwd_long_body(const AttnArgs& a, int nthr
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks) acc = MFMA(frag_rows<HD>(KT, jt * 16 + li, ks * 4 + g), qf[ks], acc);
+            const int4 km = *reinterpret_cast<const int4*>(KM + jt * 16 + 4 * g);
+            const int kmv[4] = {km.x, km.y, km.z, km.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int j = c * 64 + jt * 16 + 4 * g + r;
-                bool ok = j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
-                acc[r] = ok ? acc[r] * a.scale : NEG_BIG;
+                acc[r] = kmv[r] != 0 ? acc[r] * a.scale : NEG_BIG;
                 cmx = fmaxf(cmx, acc[r]);
             }
             s[jt] = acc;
@@ -341,6 +346,7 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& a, int nthr) 
     unsigned char* KT = smem;
     unsigned char* VT = smem + TileCfg<HD>::BYTES;
     unsigned char* ST = smem + 2 * TileCfg<HD>::BYTES;  // 4 per-wave dS tiles
+    int* KM = reinterpret_cast<int*>(ST + 4 * 2048);    // attend-flags of the 64 keys of the staged chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
     const int q0 = blockIdx.x * 64 + wave * 16;
@@ -383,6 +389,10 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& a, int nthr) 
             stage_tile<HD>(KT, kb, a.k_st, c * 64, a.Tk, tid);
             stage_tile<HD>(VT, vb, a.v_st, c * 64, a.Tk, tid);
         }
+        if (tid < 64) {   // key validity once per chunk (it was a global load per score inside the tile loop)
+            const int j = c * 64 + tid;
+            KM[tid] = (j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0)) ? 1 : 0;
+        }
         __syncthreads();
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
@@ -392,12 +402,13 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& a, int nthr) 
                 s = MFMA(frag_rows<HD>(KT, jt * 16 + li, ks * 4 + g), qf[ks], s);
                 dp = MFMA(frag_rows<HD>(VT, jt * 16 + li, ks * 4 + g), gf[ks], dp);
             }
+            const int4 km = *reinterpret_cast<const int4*>(KM + jt * 16 + 4 * g);
+            const int kmv[4] = {km.x, km.y, km.z, km.w};
             float ds[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
             if (a.drop_p > 0.f) attn_drop4(a, (uint64_t)bh * a.Tq + qi, c * 64 + jt * 16 + 4 * g, inv_keep, dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int j = c * 64 + jt * 16 + 4 * g + r;
-                bool ok = qok && j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
+                const bool ok = qok && kmv[r] != 0;
                 float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
                 ds[r] = p * (dp[r] * dm[r] - dl);
             }
@@ -441,6 +452,7 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& a, int nthr)
     unsigned char* GT = smem + TileCfg<HD>::BYTES;
     unsigned char* PT = smem + 2 * TileCfg<HD>::BYTES;  // 4 per-wave P_dropped^T tiles [j][i]
     unsigned char* ST = PT + 4 * 2048;                  // 4 per-wave dS^T tiles
+    float* LS = reinterpret_cast<float*>(ST + 4 * 2048);  // lse and delta of the 64 query rows of the staged chunk (2 x 64 floats)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
     const int j0 = blockIdx.x * 64 + wave * 16;
@@ -474,6 +486,11 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& a, int nthr)
             stage_tile<HD>(QT, qb, a.q_st, c * 64, a.Tq, tid);
             stage_tile<HD>(GT, gb, a.do_st, c * 64, a.Tq, tid);
         }
+        if (tid < 64) {   // per-row statistics once per chunk (they were 32 global loads per lane and chunk inside the tile loop)
+            const int i = c * 64 + tid;
+            LS[tid] = i < a.Tq ? a.lse[bh * a.Tq + i] : 0.f;
+            LS[64 + tid] = i < a.Tq ? a.delta[bh * a.Tq + i] : 0.f;
+        }
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -485,15 +502,15 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& a, int nthr)
             }
             float pd[4], ds[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
             if (a.drop_p > 0.f) attn_drop4_col(a, (uint64_t)bh * a.Tq + (c * 64 + it * 16 + 4 * g), kj, li, inv_keep, dm);
+            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(LS + it * 16 + 4 * g);
+            const f32x4 dl4 = *reinterpret_cast<const f32x4*>(LS + 64 + it * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int i = c * 64 + it * 16 + 4 * g + r;
                 bool ok = jok && i < a.Tq;
-                float lse = ok ? a.lse[bh * a.Tq + i] : 0.f;
-                float dl = ok ? a.delta[bh * a.Tq + i] : 0.f;
-                float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+                float p = ok ? __expf(s[r] * a.scale - lse4[r]) : 0.f;
                 pd[r] = p * dm[r];
-                ds[r] = p * (dp[r] * dm[r] - dl);
+                ds[r] = p * (dp[r] * dm[r] - dl4[r]);
             }
             ptile_write4(pt, li, it * 16 + 4 * g, pd);
             ptile_write4(st, li, it * 16 + 4 * g, ds);
@@ -829,7 +846,7 @@ static void fwd16(const AttnArgs& a, hipStream_t st) {
     // the online-softmax kernel keeps one chunk of scores live and is faster from 129 keys up (decoder T=197, S=256, ViT-L T=785)
     if (a.Tk > 128) {
         dim3 grid(ceil_div(a.Tq, 64), a.B * a.H);
-        hipLaunchKernelGGL((attn16_fwd_long_kernel<HD>), grid, dim3(256), (size_t)2 * TileCfg<HD>::BYTES + 4 * 2048, st, a);
+        hipLaunchKernelGGL((attn16_fwd_long_kernel<HD>), grid, dim3(256), (size_t)2 * TileCfg<HD>::BYTES + 4 * 2048 + 64 * sizeof(int), st, a);
         return;
     }
     {
@@ -863,7 +880,7 @@ static void bwd16(const AttnArgs& a, hipStream_t st) {
         else LAUNCH_R((attn16r_bwd_dq_kernel<HD, 4>), gridr, shr, st, a);
     } else {
         dim3 grid(ceil_div(a.Tq, 64), a.B * a.H);
-        size_t shm = 2 * TileCfg<HD>::BYTES + 4 * 2048;
+        size_t shm = 2 * TileCfg<HD>::BYTES + 4 * 2048 + 64 * sizeof(int);
         if (a.Tk <= 64) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 1>), grid, block, shm, st, a);
         else if (a.Tk <= 128) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 2>), grid, block, shm, st, a);
         else if (a.Tk <= 256) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 4>), grid, block, shm, st, a);
@@ -877,7 +894,7 @@ static void bwd16(const AttnArgs& a, hipStream_t st) {
         else LAUNCH_R((attn16r_bwd_dkv_kernel<HD, 4>), gridr, shq, st, a);
     } else {
         dim3 grid2(ceil_div(a.Tk, 64), a.B * a.H);
-        size_t shm2 = 2 * TileCfg<HD>::BYTES + 8 * 2048;
+        size_t shm2 = 2 * TileCfg<HD>::BYTES + 8 * 2048 + 128 * sizeof(float);
         hipLaunchKernelGGL((attn16_bwd_dkv_kernel<HD>), grid2, block, shm2, st, a);
     }
 }
