@@ -865,7 +865,7 @@ extern "C" int ecamp_set_option(const char* name, int32_t value) {
 extern "C" int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype) {
     if (M <= 0 || N <= 0 || K <= 0) return 1;
     int ncu = p8_num_cu();
-    if (!a_kc && !b_kc && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;   // as the launch does
+    if (!(a_kc && b_kc) && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;   // as the launch does
     // 128^2 kernel: about four resident workgroups per CU
     const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
     long s_old = 1024 / tiles;
@@ -945,7 +945,8 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
                      (!g.partial || (N % 4 == 0 && al16(g.partial)));
             g.nsplit = split_k;
             int ncu = p8_num_cu();
-            if (!a_kc && !b_kc && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;
+            // the reserve applies to the backward-only forms (weight gradient, data gradient): RCCL runs beside the backward pass
+            if (!(a_kc && b_kc) && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;
             const long total8 = (long)nbm8 * nbn8 * split_k;
             dim3 grid8((unsigned)(total8 < ncu ? total8 : ncu), 1, 1);
             const size_t shm8 = 5 * P8_STAGE_BYTES;  // the whole 160 KB LDS of a CU
