@@ -822,9 +822,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 // forward (both operands contraction-contiguous) and weight-gradient (both strided) forms when there are enough 256^2 work
 // items to give ~every CU one; the data-gradient form only when its output is at least as wide as its contraction (fc2, BERT
 // output dense), where it measured 3-15 % faster -- elsewhere the 128^2 kernel is equal or better.
+static int g_p8_mode = -2;   // -2: not set by ecamp_set_option("p8_mode", ...) -> the environment decides
 static int p8_env() {
     static const int v = getenv("ECAMP_GEMM_P8") ? atoi(getenv("ECAMP_GEMM_P8")) : -1;
-    return v;
+    return g_p8_mode != -2 ? g_p8_mode : v;
 }
 static int p8_num_cu() {
     static int ncu = 0;
@@ -857,6 +858,7 @@ static bool p8_selected(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int
 
 extern "C" int ecamp_set_option(const char* name, int32_t value) {
     ECAMP_CHECK_ARG(name != nullptr, "set_option: null name");
+    if (strcmp(name, "p8_mode") == 0) { g_p8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 always
     if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
     return ecamp_set_error(-1, "set_option: unknown option '%s'", name);

@@ -47,7 +47,8 @@ int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int6
  * torch.autograd for nn.Linear, e.g. timm Mlp.fc1 at model_ecamp.py:233): it depends on which kernel the shape selects
  * (128^2 tiles, or the persistent 256^2 kernel whose work items should fill whole rounds of the chip).  Pure host arithmetic. */
 int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype);
-/* Process-wide switches with no reference counterpart.  "p8_wgrad" (default 1): 0 keeps weight-gradient GEMMs off the persistent
+/* Process-wide switches with no reference counterpart.  "p8_mode": -1 automatic kernel selection (default), 0 never / 2 always the
+ * persistent 256^2 kernel (overrides ECAMP_GEMM_P8; used by the tests to exercise both kernels on every shape).  "p8_wgrad" (default 1): 0 keeps weight-gradient GEMMs off the persistent
  * one-workgroup-per-CU kernel.  "p8_wgrad_reserve_cus" (default 0): launch that kernel with this many fewer workgroups than CUs --
  * set by the data-parallel wrapper, whose all-reduce kernels share the CUs during backward. */
 int ecamp_set_option(const char* name, int32_t value);

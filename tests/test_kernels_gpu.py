@@ -539,3 +539,57 @@ def test_attention_long_sequence_bf16(dev, B, H, Tq, Tk, hd, masked):
     check("long attn dq", dq, qr.grad, 4e-2)
     check("long attn dk", dk, kr.grad, 4e-2)
     check("long attn dv", dv, vr.grad, 4e-2)
+
+
+# ------------------------------------------------------------------------------------------------ persistent 256^2 GEMM kernel
+@pytest.fixture
+def p8_always():
+    """Force the persistent 256x256-tile kernel for every bf16 GEMM (the automatic rule only picks it from ~192 tiles up)."""
+    o = ops()
+    o.set_option("p8_mode", 2)
+    yield o
+    o.set_option("p8_mode", -1)
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 2304, 768), (512, 128, 3072), (256, 30000, 768), (37 * 4, 512, 64), (1000, 1004, 40)])
+def test_gemm_persistent_kernel_fwd_epilogues_ragged(dev, p8_always, M, N, K):
+    """Same checks as test_gemm_fwd_epilogues, on the persistent kernel: ragged M (not a multiple of 256), N not a multiple of 8
+    (4-column epilogue path), K not a multiple of the 32-wide K tile, one or many tiles per workgroup."""
+    test_gemm_fwd_epilogues(dev, torch.bfloat16, M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 3072, 768), (256, 30000, 768), (1000, 520, 264)])
+def test_gemm_persistent_kernel_dgrad_wgrad_ragged(dev, p8_always, M, N, K):
+    test_gemm_dgrad_wgrad(dev, torch.bfloat16, M, N, K)
+
+
+def test_gemm_full_size_kernels_agree(dev):
+    """BASELINE configs[1] sizes (timm Mlp.fc1 of the encoder at B=256: 12800 x 3072 x 768): forward with bias + GELU + saved
+    pre-activation, data gradient through GELU', weight + bias gradient -- the persistent kernel against the 128^2 kernel on the
+    same inputs (both accumulate in f32; only the summation order differs), and both against a float64 sample of rows."""
+    o = ops()
+    M, N, K = 12800, 3072, 768
+    x = (torch.randn(M, K, generator=torch.Generator().manual_seed(1))).to(dev, torch.bfloat16)
+    w = (torch.randn(N, K, generator=torch.Generator().manual_seed(2)) * K ** -0.5).to(dev, torch.bfloat16)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
+    dy = torch.randn(M, N, generator=torch.Generator().manual_seed(4)).to(dev, torch.bfloat16)
+    res = {}
+    for mode in (0, 2):
+        o.set_option("p8_mode", mode)
+        y, pre = o.linear_fwd(x, w, b, act=1, save_pre=True)
+        dx = o.linear_dgrad(dy, w)
+        gw, gb = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        o.linear_wgrad(dy, x, gw, gb=gb)
+        res[mode] = (y.float(), pre.float(), dx.float(), gw, gb)
+    o.set_option("p8_mode", -1)
+    for name, a, c, tol in zip(("y", "pre", "dx", "gw", "gb"), res[0], res[2], (1e-2, 1e-2, 1e-2, 2e-3, 2e-3)):
+        err = float((a - c).abs().max() / c.abs().max())
+        print("  full-size %-3s 128^2 vs persistent rel %.3e" % (name, err))
+        assert err < tol, name
+    rows = torch.arange(0, M, 997, device=dev)
+    ref_pre = x[rows].double() @ w.double().t() + b.double()
+    assert float((res[2][1][rows].double() - ref_pre).abs().max() / ref_pre.abs().max()) < 1e-2
+    cols = torch.arange(0, N, 211, device=dev)
+    ref_gw = dy[:, cols].double().t() @ x.double()
+    assert float((res[2][3][cols].double() - ref_gw).abs().max() / ref_gw.abs().max()) < 2e-3
+    assert float((res[2][4].double() - dy.double().sum(0)).abs().max() / dy.double().sum(0).abs().max()) < 2e-3
