@@ -267,3 +267,59 @@ def test_visualization_forward_matches_reference(dev, dtype, tol):
     nm, s = digest(p)
     print("vis", dtype, "norm rel", rel(nm[0], g["probs/nm"][0]), "sample rel", rel(s, g["probs/s"]), "tok4 rel", rel(p[:, :, 4].numpy(), g["probs_tok4"]))
     assert rel(nm[0], g["probs/nm"][0]) < tol and rel(s, g["probs/s"]) < tol and rel(p[:, :, 4].numpy(), g["probs_tok4"]) < tol
+
+
+def test_full_size_batch_consistency_bf16(dev):
+    """BASELINE.json configs[1] at full size (B=256, S=128, 448^2 images, bf16): all three losses are batch means, so the loss of the
+    whole batch must equal the mean of the losses of its 8 sub-batches of 32 -- the full-size step runs the persistent 256^2 GEMMs,
+    split-K plans and kernel variants that the small parity cases never select.  Also: a second evaluation reproduces the first."""
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    torch.manual_seed(0)
+    model = me.ecamp(compute_dtype=torch.bfloat16).to(dev)
+    model.eval()
+    B, S = 256, 128
+    batch = synthetic_batch(B, S, 448, seed=11, device=dev)
+    noise = torch.rand(B, 196, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        full = torch.stack(model(batch, noise=noise)).double().cpu()
+        again = torch.stack(model(batch, noise=noise)).double().cpu()
+        parts = []
+        for i in range(0, B, 32):
+            sub = {k: v[i:i + 32] for k, v in batch.items()}
+            parts.append(torch.stack(model(sub, noise=noise[i:i + 32])).double().cpu())
+    parts = torch.stack(parts).mean(0)
+    print("full", full.tolist(), "mean of sub-batches", parts.tolist())
+    assert torch.isfinite(full).all()
+    assert float(((full - again).abs() / full.abs()).max()) < 1e-5
+    assert float(((full - parts).abs() / parts.abs()).max()) < 2e-3
+
+
+def test_full_size_gradient_is_the_mean_of_sub_batch_gradients_bf16(dev):
+    """Same full-size configuration, backward: the three losses are batch means, so the gradient of the whole batch of 256 equals the
+    mean of the gradients of its 8 sub-batches of 32 (accumulated into the arena).  Exercises the full-size weight-/data-gradient
+    GEMM plans (persistent kernel, split-K slabs, fused bias gradients) against the small-batch plans."""
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    torch.manual_seed(0)
+    model = me.ecamp(compute_dtype=torch.bfloat16).to(dev)
+    model.eval()   # dropout off: the two computations must see the same function
+    B, S = 256, 128
+    batch = synthetic_batch(B, S, 448, seed=12, device=dev)
+    noise = torch.rand(B, 196, generator=torch.Generator().manual_seed(6)).to(dev)
+    arena = model.prepare()
+    arena.flat_g.zero_()
+    sum(model(batch, noise=noise)).backward()
+    torch.cuda.synchronize()
+    g_full = arena.flat_g.clone()
+    arena.flat_g.zero_()
+    for i in range(0, B, 32):
+        sub = {k: v[i:i + 32] for k, v in batch.items()}
+        sum(model(sub, noise=noise[i:i + 32])).backward()
+    torch.cuda.synchronize()
+    g_parts = arena.flat_g / 8.0
+    assert torch.isfinite(g_full).all() and float(g_full.abs().max()) > 0
+    num = float((g_full - g_parts).double().norm())
+    den = float(g_parts.double().norm())
+    print("grad full vs mean of parts: rel l2 %.3e, norm %.4e" % (num / den, den))
+    assert num / den < 2e-2   # bf16 activations; identical in exact arithmetic
