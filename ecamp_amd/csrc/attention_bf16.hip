@@ -19,6 +19,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0)
 
+// softmax in base 2: scores are scaled by scale*log2(e) once, exp(x) becomes the native v_exp_f32 (2^x) with no extra multiply, and
+// a masked score (-1e30) needs no select: 2^(-1e30 - max(m, -1e29)) is 0.  lse is still stored in natural-log units.
+#define ATTN_LOG2E 1.4426950408889634f
+#define ATTN_LN2 0.6931471805599453f
+__device__ __forceinline__ float attn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <int HD> struct TileCfg { static constexpr int PB = HD * 2 + 32; static constexpr int BYTES = 64 * PB; };
 
 // rows [r0, r0+64) x HD of a (b,h) slice -> LDS (zeros past nrows)
@@ -247,6 +253,7 @@ __device__ __forceinline__ void attn16_fwd_long_body(const AttnArgs& a, int nthr
     load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
     const int qi = q0 + li;
     const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const float sc2 = a.scale * ATTN_LOG2E;
     float m = NEG_BIG, l = 0.f;
     f32x4 o[HD / 16];
 #pragma unroll
@@ -279,21 +286,22 @@ __device__ __forceinline__ void attn16_fwd_long_body(const AttnArgs& a, int nthr
             const int kmv[4] = {km.x, km.y, km.z, km.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc[r] = kmv[r] != 0 ? acc[r] * a.scale : NEG_BIG;
+                acc[r] = kmv[r] != 0 ? acc[r] * sc2 : NEG_BIG;
                 cmx = fmaxf(cmx, acc[r]);
             }
             s[jt] = acc;
         }
         cmx = red4_max(cmx);
         const float mn = fmaxf(m, cmx);
-        const float alpha = __expf(m - mn);  // first chunk: exp(-1e30 - finite) = 0, and l = o = 0 anyway
+        const float alpha = attn_exp2(m - mn);  // first chunk: 2^(-1e30 - finite) = 0, and l = o = 0 anyway
+        const float mns = fmaxf(mn, -1e29f);    // a row with no valid key so far keeps every p at 0
         float csum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
             float p[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[r] = s[jt][r] > 0.5f * NEG_BIG ? __expf(s[jt][r] - mn) : 0.f;
+                p[r] = attn_exp2(s[jt][r] - mns);
                 csum += p[r];
             }
             if (a.drop_p > 0.f) {
@@ -320,7 +328,7 @@ __device__ __forceinline__ void attn16_fwd_long_body(const AttnArgs& a, int nthr
         }
     }
     if (qi < a.Tq) {
-        if (g == 0) a.lse[bh * a.Tq + qi] = m + __logf(l);
+        if (g == 0) a.lse[bh * a.Tq + qi] = (m + __log2f(l)) * ATTN_LN2;
         const float inv = 1.0f / l;
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) store4(ob + (long)qi * a.o_st + dt * 16 + 4 * g, o[dt], inv);
@@ -371,7 +379,7 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& a, int nthr) 
     const int qi = q0 + li;
     const bool qok = qi < a.Tq;
     if (g == 0 && qok) a.delta[bh * a.Tq + qi] = dl;
-    const float lse = qok ? a.lse[bh * a.Tq + qi] : 0.f;
+    const float lse2 = (qok ? a.lse[bh * a.Tq + qi] : 0.f) * ATTN_LOG2E, sc2 = a.scale * ATTN_LOG2E;
     const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
 
     f32x4 dq[HD / 16];
@@ -409,7 +417,7 @@ __device__ __forceinline__ void attn16_bwd_dq_body(const AttnArgs& a, int nthr) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = qok && kmv[r] != 0;
-                float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+                float p = ok ? attn_exp2(fmaf(s[r], sc2, -lse2)) : 0.f;
                 ds[r] = p * (dp[r] * dm[r] - dl);
             }
             ptile_write4(st, li, jt * 16 + 4 * g, ds);
@@ -469,7 +477,7 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& a, int nthr)
     load_row_frags<HD>(vf, vb, a.v_st, j0, a.Tk, lane);
     const int kj = j0 + li;
     const bool jok = kj < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + kj] != 0);
-    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f, sc2 = a.scale * ATTN_LOG2E;
     f32x4 dk[HD / 16], dv[HD / 16];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -488,7 +496,7 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& a, int nthr)
         }
         if (tid < 64) {   // per-row statistics once per chunk (they were 32 global loads per lane and chunk inside the tile loop)
             const int i = c * 64 + tid;
-            LS[tid] = i < a.Tq ? a.lse[bh * a.Tq + i] : 0.f;
+            LS[tid] = i < a.Tq ? a.lse[bh * a.Tq + i] * ATTN_LOG2E : 0.f;   // base-2 units
             LS[64 + tid] = i < a.Tq ? a.delta[bh * a.Tq + i] : 0.f;
         }
         __syncthreads();
@@ -508,7 +516,7 @@ __device__ __forceinline__ void attn16_bwd_dkv_body(const AttnArgs& a, int nthr)
             for (int r = 0; r < 4; ++r) {
                 int i = c * 64 + it * 16 + 4 * g + r;
                 bool ok = jok && i < a.Tq;
-                float p = ok ? __expf(s[r] * a.scale - lse4[r]) : 0.f;
+                float p = ok ? attn_exp2(fmaf(s[r], sc2, -lse4[r])) : 0.f;
                 pd[r] = p * dm[r];
                 ds[r] = p * (dp[r] * dm[r] - dl4[r]);
             }
@@ -600,22 +608,23 @@ __global__ __launch_bounds__(256) void attn16r_fwd_kernel(AttnArgs a) {
         for (int t = 0; t < KCH * 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[t][r] = ((kok >> (t * 4 + r)) & 1ull) ? s[t][r] * a.scale : NEG_BIG;
+                s[t][r] = ((kok >> (t * 4 + r)) & 1ull) ? s[t][r] * (a.scale * ATTN_LOG2E) : NEG_BIG;
                 mx = fmaxf(mx, s[t][r]);
             }
         mx = red4_max(mx);
+        const float mxs = fmaxf(mx, -1e29f);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < KCH * 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = s[t][r] > 0.5f * NEG_BIG ? __expf(s[t][r] - mx) : 0.f;
+                float p = attn_exp2(s[t][r] - mxs);
                 s[t][r] = p;
                 sum += p;
             }
         sum = red4_sum(sum);
         const int qi = q0 + li;
-        if (g == 0 && qi < a.Tq) a.lse[bh * a.Tq + qi] = mx + __logf(sum);
+        if (g == 0 && qi < a.Tq) a.lse[bh * a.Tq + qi] = (mx + __log2f(sum)) * ATTN_LN2;
         const float inv = 1.0f / sum;
         f32x4 o[HD / 16];
 #pragma unroll
