@@ -160,55 +160,110 @@ class DecStemFn(torch.autograd.Function):
 
 
 # =============================================================================================
+def _dec_head_fwd(m, xd):
+    """decoder_norm -> decoder_pred on [B*(L+1), Dd] (model_ecamp.py:256-259); the cls row is still in the output."""
+    ln = m.decoder_norm
+    h, _, mean, rstd = ops.layernorm_fwd(xd, ln.weight.data, ln.bias.data, ln.eps)
+    pred = ops.linear_fwd(h, m.arena.w(m.decoder_pred.weight), m.decoder_pred.bias.data)
+    return pred, (xd, mean, rstd, h)
+
+
+def _dec_head_bwd(m, rec, dpred):
+    xd, mean, rstd, h = rec
+    A = m.arena
+    G = A.grad
+    dp, ln = m.decoder_pred, m.decoder_norm
+    ops.linear_wgrad_async(dpred, h, G(dp.weight), gb=G(dp.bias))
+    dh = ops.linear_dgrad(dpred, A.w(dp.weight))
+    dxd = ops.layernorm_bwd(dh, xd, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
+    A.ready(dp.weight, dp.bias, ln.weight, ln.bias)
+    return dxd
+
+
+def _pixel_loss_fwd(m, pred, imgs, big, mask, column, row, B):
+    """unpatchify -> masked MSE  +  SR head -> windowed MSE (model_ecamp.py:276-300) on pred [B*(L+1), p*p*3] (cls row ignored).
+    -> ([mim_loss, res_loss] f32, record for the backward)."""
+    cd = m.compute_dtype
+    R, p = m.img_size, m.patch_size
+    sums = ops.zeros((2,), pred.device)
+    pred_img = ops.unpatchify_mim(pred, imgs, mask, sums[0:], B, R, p)
+    sr = m.super_res
+    # bf16 mode: the SR stencils run on the matrix cores (u / c1 / ds / dc1 rounded to bf16); f32 mode keeps the exact f32 stencils
+    sr_mode = 0 if cd == torch.float32 else 1
+    ops.sr_fwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data, sr.conv2.bias.data,
+               sums[1:], 2 * p, m.sr_window, sr_mode)
+    n1, n2 = B * 3 * R * R, B * 3 * 4 * R * R
+    m._aux = dict(pred=pred, pred_img=pred_img) if m.keep_aux else None
+    return sums * m._loss_norm(n1, n2, pred.device), (pred_img, imgs, mask, big, column, row, B, n1, n2, pred.dtype)
+
+
+def _pixel_loss_bwd(m, rec, g):
+    pred_img, imgs, mask, big, column, row, B, n1, n2, pdt = rec
+    G = m.arena.grad
+    cd = m.compute_dtype
+    R, p = m.img_size, m.patch_size
+    gm_gs = (g * (2.0 * m._loss_norm(n1, n2, g.device))).contiguous()  # [g_mim*2/N1, g_res*2/N2] (2 floats, on device)
+    sr = m.super_res
+    ws = ops.zeros((168,), pred_img.device)
+    dsr = ops.sr_bwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data,
+                     sr.conv2.bias.data, ws, 2 * p, m.sr_window, 0 if cd == torch.float32 else 1)
+    ops.scaled_accum(ws[0:81], G(sr.conv1.weight), gm_gs, 1)
+    ops.scaled_accum(ws[81:84], G(sr.conv1.bias), gm_gs, 1)
+    ops.scaled_accum(ws[84:165], G(sr.conv2.weight), gm_gs, 1)
+    ops.scaled_accum(ws[165:168], G(sr.conv2.bias), gm_gs, 1)
+    m.arena.ready(sr.conv1.weight, sr.conv1.bias, sr.conv2.weight, sr.conv2.bias)
+    return ops.img_loss_bwd(pred_img, imgs, mask, dsr, gm_gs, B, R, p, pdt)
+
+
 class ImgLossFn(torch.autograd.Function):
     """decoder_norm -> decoder_pred -> unpatchify -> masked MSE  +  SR head -> windowed MSE.
     Returns one 2-element f32 tensor [mim_loss, res_loss]."""
 
     @staticmethod
     def forward(ctx, xd, imgs, big, mask, column, row, m, B):
-        A = m.arena
-        cd = m.compute_dtype
-        R, p = m.img_size, m.patch_size
-        ln = m.decoder_norm
-        h, _, mean, rstd = ops.layernorm_fwd(xd, ln.weight.data, ln.bias.data, ln.eps)
-        pred = ops.linear_fwd(h, A.w(m.decoder_pred.weight), m.decoder_pred.bias.data)
-        sums = ops.zeros((2,), xd.device)
-        pred_img = ops.unpatchify_mim(pred, imgs, mask, sums[0:], B, R, p)
-        sr = m.super_res
-        # bf16 mode: the SR stencils run on the matrix cores (u / c1 / ds / dc1 rounded to bf16); f32 mode keeps the exact f32 stencils
-        sr_mode = 0 if cd == torch.float32 else 1
-        ops.sr_fwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data, sr.conv2.bias.data,
-                   sums[1:], 2 * p, m.sr_window, sr_mode)
-        n1, n2 = B * 3 * R * R, B * 3 * 4 * R * R
-        ctx.s = (xd, mean, rstd, h, pred_img, imgs, mask, big, column, row, m, B, n1, n2)
-        m._aux = dict(pred=pred, pred_img=pred_img) if m.keep_aux else None
-        return sums * m._loss_norm(n1, n2, xd.device)
+        pred, head = _dec_head_fwd(m, xd)
+        out, tail = _pixel_loss_fwd(m, pred, imgs, big, mask, column, row, B)
+        ctx.s = (m, head, tail)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        xd, mean, rstd, h, pred_img, imgs, mask, big, column, row, m, B, n1, n2 = ctx.s
-        A = m.arena
-        G = A.grad
-        cd = m.compute_dtype
-        R, p = m.img_size, m.patch_size
-        gm_gs = (g * (2.0 * m._loss_norm(n1, n2, g.device))).contiguous()  # [g_mim*2/N1, g_res*2/N2] (2 floats, on device)
-        sr = m.super_res
-        ws = ops.zeros((168,), xd.device)
-        dsr = ops.sr_bwd(pred_img, big, column, row, sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data,
-                         sr.conv2.bias.data, ws, 2 * p, m.sr_window, 0 if cd == torch.float32 else 1)
-        ops.scaled_accum(ws[0:81], G(sr.conv1.weight), gm_gs, 1)
-        ops.scaled_accum(ws[81:84], G(sr.conv1.bias), gm_gs, 1)
-        ops.scaled_accum(ws[84:165], G(sr.conv2.weight), gm_gs, 1)
-        ops.scaled_accum(ws[165:168], G(sr.conv2.bias), gm_gs, 1)
-        dpred = ops.img_loss_bwd(pred_img, imgs, mask, dsr, gm_gs, B, R, p, cd)
-        dp = m.decoder_pred
-        ops.linear_wgrad_async(dpred, h, G(dp.weight), gb=G(dp.bias))
-        dh = ops.linear_dgrad(dpred, A.w(dp.weight))
-        ln = m.decoder_norm
-        dxd = ops.layernorm_bwd(dh, xd, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
-        A.ready(sr.conv1.weight, sr.conv1.bias, sr.conv2.weight, sr.conv2.bias, dp.weight, dp.bias, ln.weight, ln.bias)
+        m, head, tail = ctx.s
+        dxd = _dec_head_bwd(m, head, _pixel_loss_bwd(m, tail, g))
         ctx.s = None
         return (dxd,) + _none(7)
+
+
+class DecHeadFn(torch.autograd.Function):
+    """The tail of `image_decoder` alone (model_ecamp.py:256-259) for the stage-wise public API."""
+
+    @staticmethod
+    def forward(ctx, xd, m):
+        pred, head = _dec_head_fwd(m, xd)
+        ctx.s = (m, head)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        m, head = ctx.s
+        ctx.s = None
+        return _dec_head_bwd(m, head, dpred.contiguous()), None
+
+
+class PixelLossFn(torch.autograd.Function):
+    """`forward_loss` alone (model_ecamp.py:276-300) on a prediction that still carries its cls row."""
+
+    @staticmethod
+    def forward(ctx, pred, imgs, big, mask, column, row, m, B):
+        out, tail = _pixel_loss_fwd(m, pred, imgs, big, mask, column, row, B)
+        ctx.s = (m, tail)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m, tail = ctx.s
+        ctx.s = None
+        return (_pixel_loss_bwd(m, tail, g),) + _none(7)
 
 
 # =============================================================================================

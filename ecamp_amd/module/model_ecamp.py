@@ -195,9 +195,102 @@ class ECAMP(nn.Module):
         return self._norm_cache[key]
 
     # ---------------------------------------------------------------------------------------------
+    # --- the reference's stage-wise public methods (model_ecamp.py:138-300).  `forward` below runs the same kernels with the
+    # stages fused across these boundaries (no materialised masks, no unpatchified copy); these exist so that code written
+    # against the reference's methods keeps working, and they are differentiable through the same hand-written backwards.
+    def patchify(self, imgs):
+        """imgs (N, 3, H, W) -> (N, L, (2p)**2 * 3): the reference patchifies with the SUPER-resolution patch (model_ecamp.py:138-150)."""
+        p = self.patch_size * 2
+        if imgs.shape[2] != imgs.shape[3] or imgs.shape[2] % p != 0:
+            raise AssertionError("patchify: square image with a side divisible by %d expected, got %s" % (p, tuple(imgs.shape)))
+        h = imgs.shape[2] // p
+        return imgs.reshape(imgs.shape[0], 3, h, p, h, p).permute(0, 2, 4, 3, 5, 1).reshape(imgs.shape[0], h * h, p * p * 3)
+
+    def unpatchify(self, x):
+        """x (N, L, p*p*3) -> (N, 3, H, W)  (model_ecamp.py:153-165)."""
+        p = self.patch_size
+        h = int(x.shape[1] ** .5)
+        if h * h != x.shape[1]:
+            raise AssertionError("unpatchify: L=%d is not a square" % x.shape[1])
+        return x.reshape(x.shape[0], h, h, p, p, 3).permute(0, 5, 1, 3, 2, 4).reshape(x.shape[0], 3, h * p, h * p)
+
+    def random_masking(self, x, mask_ratio, noise=None):
+        """x [N, L, D] -> (x_masked [N, len_keep, D], mask [N, L] (0 keep / 1 remove), ids_restore, ids_keep)  (model_ecamp.py:168-193).
+        The noise comes from the model's Philox stream (or `noise`), the index sort from the `mask_indices` kernel."""
+        from .. import hip_ops as ops
+        self.prepare()
+        N, L, D = x.shape
+        len_keep = int(L * (1 - mask_ratio))
+        if noise is None:
+            seed, off = self.next_rng()
+            noise = ops.uniform((N, L), x.device, seed, off)
+        ids_restore, ids_keep, mask = ops.mask_indices(noise.to(x.device, torch.float32).contiguous(), len_keep)
+        ids_restore, ids_keep = ids_restore.long(), ids_keep.long()        # the kernels keep int32; the reference's API is int64
+        return torch.gather(x, 1, ids_keep.unsqueeze(-1).expand(-1, -1, D)), mask, ids_restore, ids_keep
+
+    def mask_2_pixel(self, mask, column, row):
+        """mask [N, L] -> (pixel_mask [N,3,R,R], super_pixel_mask [N,3,2R,2R])  (model_ecamp.py:196-215; the first grid axis is
+        the one the reference calls `column`).  Only for callers that want the masks: `forward_loss` never materialises them."""
+        p, g, w = self.patch_size, int(mask.shape[1] ** .5), self.sr_window
+        m2 = mask.reshape(mask.shape[0], g, g)
+        idx = torch.arange(g, device=mask.device)
+        c, r = column.view(-1, 1).to(mask.device), row.view(-1, 1).to(mask.device)
+        sup = (((idx >= c) & (idx < c + w))[:, :, None] & ((idx >= r) & (idx < r + w))[:, None, :]).to(torch.float32)
+        up = lambda t, k: t.repeat_interleave(k, 1).repeat_interleave(k, 2).unsqueeze(1).repeat(1, 3, 1, 1)
+        return up(m2, p), up(sup, 2 * p)
+
+    def image_encoder(self, x, mask_ratio, noise=None):
+        """x [N,3,R,R] -> (latent [N, 1+len_keep, D], mask, ids_restore, ids_keep)  (model_ecamp.py:218-237)."""
+        from ..functions import NormFn, StemFn, VitBlockFn
+        A = self.prepare()
+        x = x.to(A.device, dtype=torch.float32).contiguous()
+        if x.shape[1:] != (3, self.img_size, self.img_size):
+            raise ValueError("image_encoder expects [N,3,%d,%d], got %s" % (self.img_size, self.img_size, tuple(x.shape)))
+        if noise is not None:
+            noise = noise.to(A.device, dtype=torch.float32).contiguous()
+        B = x.shape[0]
+        t, _, mask, ids_restore, ids_keep = StemFn.apply(x, noise, self, mask_ratio, self.cls_token)
+        T = ids_keep.shape[1] + 1
+        for blk in self.blocks:
+            t = VitBlockFn.apply(t, blk, self, B, T, self.num_heads)
+        return NormFn.apply(t, self.norm, self).view(B, T, -1), mask, ids_restore.long(), ids_keep.long()   # int64 as in the reference
+
+    def image_decoder(self, x, ids_restore):
+        """latent [N, 1+len_keep, D], ids_restore [N, L] -> pred [N, L, p*p*3] (a view without the cls row)  (model_ecamp.py:240-264)."""
+        from ..functions import DecHeadFn, DecStemFn, VitBlockFn
+        A = self.prepare()
+        B, T, D = x.shape
+        L = self.num_patches
+        ids_keep = torch.argsort(ids_restore.to(A.device), dim=1)[:, :T - 1].to(torch.int32).contiguous()   # ids_shuffle = inverse permutation
+        ids_restore = ids_restore.to(A.device, torch.int32).contiguous()       # the index kernels read int32
+        xd = DecStemFn.apply(x.to(self.compute_dtype).reshape(B * T, D), ids_restore, ids_keep, self, B)
+        for blk in self.decoder_blocks:
+            xd = VitBlockFn.apply(xd, blk, self, B, L + 1, self.decoder_num_heads)
+        return DecHeadFn.apply(xd, self).view(B, L + 1, -1)[:, 1:, :]
+
+    def forward_loss(self, imgs, big_imgs, pred, mask, column, row):
+        """imgs [N,3,R,R], big_imgs [N,3,2R,2R], pred [N,L,p*p*3], mask [N,L] (1 = removed), column/row [N] -> (mim_loss, res_loss)
+        (model_ecamp.py:276-300): unpatchify + masked MSE and SR head + windowed MSE in two fused kernels."""
+        from ..functions import PixelLossFn
+        A = self.prepare()
+        dev = A.device
+        B, L, PD = pred.shape
+        full = torch.cat([pred.new_zeros(B, 1, PD), pred], 1).to(self.compute_dtype).reshape(B * (L + 1), PD)   # the kernels skip row 0
+        f32 = lambda t: t.to(dev, dtype=torch.float32).contiguous()
+        i64 = lambda t: t.to(dev, dtype=torch.int64).contiguous().view(-1)
+        out = PixelLossFn.apply(full, f32(imgs), f32(big_imgs), f32(mask), i64(column), i64(row), self, B)
+        return out[0], out[1]
+
     def forward_report_decoder(self, latent, ids_keep, caption_ids, labels, attention_mask, token_type_ids, weights, B=None, T=None):
-        """model_ecamp.py:267-273 (`ids_keep` is unused there too).  `latent` is [B*T, D] here."""
+        """model_ecamp.py:267-273 (`ids_keep` is unused there too).  `latent` is [B, T, D] as in the reference, or [B*T, D] with B, T."""
         from ..functions import ReportStemFn
+        if latent.dim() == 3:
+            B, T = latent.shape[:2]
+            latent = latent.reshape(B * T, -1)
+            dev = latent.device
+            mv = lambda t, dt: t.to(dev, dtype=dt).contiguous()
+            caption_ids, labels, attention_mask, token_type_ids = (mv(t, torch.int64) for t in (caption_ids, labels, attention_mask, token_type_ids))
+            weights = mv(weights, torch.float32)
         lat, gap = ReportStemFn.apply(latent, self, B, T)
         out = self.bert_encoder(lat, gap, caption_ids, labels, attention_mask, token_type_ids, weights, self, B, T)
         return out.loss

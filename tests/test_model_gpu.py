@@ -323,3 +323,97 @@ def test_full_size_gradient_is_the_mean_of_sub_batch_gradients_bf16(dev):
     den = float(g_parts.double().norm())
     print("grad full vs mean of parts: rel l2 %.3e, norm %.4e" % (num / den, den))
     assert num / den < 2e-2   # bf16 activations; identical in exact arithmetic
+
+
+def test_stagewise_public_methods_match_oracle_and_fused_forward_fp32(dev):
+    """The reference's stage-wise methods (model_ecamp.py:138-300: image_encoder, image_decoder, forward_loss,
+    forward_report_decoder, random_masking, mask_2_pixel, patchify, unpatchify) called one by one the way model_ecamp.py:320-325
+    does: every intermediate matches the oracle's function of the same name, and losses + gradients equal the fused forward()."""
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    name = "tiny_b4_s128"
+    B, S = 4, 128
+    model, cfg = _build(name, torch.float32, dev)
+    model.eval()
+    P = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+    batch = recipe.recipe_batch(cfg, B, S, seed=0)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=0)
+    big = batch["image"]
+    imgs = orc.bicubic_resize(big, cfg.img_size)
+
+    lat, mask, ids_restore, ids_keep = model.image_encoder(imgs, 0.75, noise=noise)
+    o_lat, o_mask, o_restore, o_keep = orc.image_encoder(P, cfg, imgs, 0.75, noise)
+    assert lat.shape == o_lat.shape
+    assert (ids_restore.cpu() == o_restore).all() and (ids_keep.cpu() == o_keep).all() and (mask.cpu() == o_mask).all()
+    assert rel(lat.detach().cpu(), o_lat) < 2e-4
+    pred = model.image_decoder(lat, ids_restore)
+    o_pred = orc.image_decoder(P, cfg, o_lat, o_restore)
+    assert pred.shape == o_pred.shape and rel(pred.detach().cpu(), o_pred) < 2e-4
+    mim, res = model.forward_loss(imgs, big, pred, mask, batch["column"], batch["row"])
+    o_mim, o_res, o_img, _ = orc.forward_loss(P, cfg, imgs, big, o_pred, o_mask, batch["column"], batch["row"])
+    assert rel(mim.item(), o_mim.item()) < 2e-4 and rel(res.item(), o_res.item()) < 2e-4
+    mlm = model.forward_report_decoder(lat, ids_keep, batch["ids"], batch["labels"], batch["attention_mask"], batch["type_ids"],
+                                       batch["weights"])
+    (mim + res + mlm).backward()
+    stage = np.array([mim.item(), res.item(), mlm.item()])
+    g_stage = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    f = model(batch, mask_ratio=0.75, noise=noise)
+    (f[0] + f[1] + f[2]).backward()
+    fused = np.array([t.item() for t in f])
+    print("stage-wise", stage, "fused", fused)
+    assert rel(stage, fused) < 2e-5
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        if p.grad.abs().max() < 1e-7:      # key biases: mathematically zero gradient (softmax shift invariance), only rounding noise
+            continue
+        worst = max(worst, rel(g_stage[n].cpu(), p.grad.cpu()))
+    print("  worst stage-wise vs fused gradient rel err %.2e" % worst)
+    assert worst < 5e-4
+
+    # the small helpers
+    x = torch.randn(B, cfg.num_patches, 24, device=dev)
+    xm, m2, r2, k2 = model.random_masking(x, 0.75, noise=noise)
+    o = orc.random_masking(x.cpu(), 0.75, noise)
+    assert (xm.cpu() == o[0]).all() and (m2.cpu() == o[1]).all() and (r2.cpu() == o[2]).all() and (k2.cpu() == o[3]).all()
+    pm, spm = model.mask_2_pixel(mask, batch["column"].to(dev), batch["row"].to(dev))
+    o_pm, o_spm = orc.mask_2_pixel(cfg, o_mask, batch["column"], batch["row"])
+    assert (pm.cpu() == o_pm).all() and (spm.cpu() == o_spm).all()
+    assert (model.unpatchify(pred.detach()).cpu() == orc.unpatchify(cfg, pred.detach().cpu())).all()
+    assert rel(model.unpatchify(pred.detach()).cpu(), o_img) < 2e-4
+    pf = model.patchify(big.to(dev))
+    p2 = 2 * cfg.patch_size
+    h = big.shape[2] // p2
+    ref = torch.einsum("nchpwq->nhwpqc", big.reshape(B, 3, h, p2, h, p2)).reshape(B, h * h, p2 * p2 * 3)
+    assert (pf.cpu() == ref).all()
+    with pytest.raises(AssertionError):
+        model.patchify(torch.zeros(1, 3, 30, 30, device=dev))
+
+
+def test_stagewise_public_methods_bf16(dev):
+    """Same composition in the production dtype: stage-wise losses equal the fused forward's (same kernels, same order)."""
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    B, S = 2, 128
+    model, cfg = _build("base_b2_s128", torch.bfloat16, dev)
+    model.eval()
+    batch = recipe.recipe_batch(cfg, B, S, seed=0)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=0)
+    big = batch["image"]
+    imgs = orc.bicubic_resize(big, cfg.img_size)
+    lat, mask, ids_restore, ids_keep = model.image_encoder(imgs, 0.75, noise=noise)
+    assert lat.dtype == torch.bfloat16 and lat.shape == (B, 50, 768)
+    pred = model.image_decoder(lat, ids_restore)
+    assert pred.shape == (B, 196, 768)
+    mim, res = model.forward_loss(imgs, big, pred, mask, batch["column"], batch["row"])
+    mlm = model.forward_report_decoder(lat, ids_keep, batch["ids"], batch["labels"], batch["attention_mask"], batch["type_ids"],
+                                       batch["weights"])
+    f = model(batch, mask_ratio=0.75, noise=noise)
+    a, b = np.array([mim.item(), res.item(), mlm.item()]), np.array([t.item() for t in f])
+    print("bf16 stage-wise", a, "fused", b)
+    # the only difference: forward() resizes on the GPU (bicubic kernel) while this test resized with the oracle on the host
+    assert (np.abs(a - b) / b).max() < 5e-3
