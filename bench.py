@@ -197,7 +197,7 @@ def main():
             # whole-step view with SURVEY.md 8(d)'s algorithmic FLOPs per pair
             gflop_pair = 88.99 if args.seq == 128 else 136.64
             res["roofline"]["whole_step_tflops"] = round(gflop_pair * 1e9 * args.batch / (dt / args.steps) / 1e12, 2)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N=1 only; at N>1 the other ranks would sit waiting for it
             try:
                 res["cpu_baseline"] = cpu_baseline(args.seq)
             except Exception as e:  # the baseline is reporting only; never lose the GPU number over it
