@@ -62,6 +62,8 @@ class ParamArena:
             self.index[id(p)] = i
         self.unused = [i for i, p in enumerate(self.params) if getattr(p, "_ecamp_unused", False)]
         self.on_ready = None  # callback(list of slot ids) set by the data-parallel reducer
+        self.version = 0      # bumped whenever the values the kernels read change (optimizer step, sync_shadow)
+        self._w8 = {}         # slot -> (version, e4m3 copy, scale): the fp8-forward mode's weights, re-quantised once per step
         self.sync_shadow()
 
     # -- views ---------------------------------------------------------------------------------
@@ -77,6 +79,17 @@ class ParamArena:
         i = self.index[id(p)]
         o, n = self.offsets[i], self.sizes[i]
         return self.flat_p16[o:o + n].view(p.shape)
+
+    def w8(self, p):
+        """(uint8 e4m3 copy of parameter p, f32[1] scale) for the fp8 forward GEMMs (configs[4]); quantised from the bf16 shadow
+        the first time it is asked for after the values changed."""
+        i = self.index[id(p)]
+        hit = self._w8.get(i)
+        if hit is None or hit[0] != self.version:
+            q, s = ops.quantize_fp8(self.w(p).contiguous())
+            hit = (self.version, q, s)
+            self._w8[i] = hit
+        return hit[1], hit[2]
 
     def _span(self, ps):
         idx = [self.index[id(p)] for p in ps]
@@ -103,6 +116,7 @@ class ParamArena:
         """Refresh the bf16 shadow from the f32 masters (after load_state_dict / manual edits; AdamW does it itself)."""
         if self.flat_p16 is not None:
             ops.cast(self.flat_p, self.flat_p16)
+        self.version += 1
 
     def zero_grad(self):
         ops.zero_(self.flat_g)

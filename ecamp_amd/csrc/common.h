@@ -139,5 +139,6 @@ void ecamp_prof_end(hipStream_t s);
 #define ECAMP_PROF_GEMM_BF16 0
 #define ECAMP_PROF_GEMM_F32 1
 #define ECAMP_PROF_ATTN 2
+#define ECAMP_PROF_GEMM_FP8 3
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

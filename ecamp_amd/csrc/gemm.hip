@@ -815,6 +815,176 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 }
 
 // =============================================================================================
+// fp8 forward GEMM (BASELINE.json configs[4]: fp8 MFMA forward, bf16 gradients): Y = act((A8 . B8^T) * sa * sb + bias) (+ residual)
+// with A8 [M,K], B8 [N,K] in OCP e4m3 (one byte per element, contraction-contiguous) and per-tensor scales sa, sb on the device.
+// The tile, LDS image and fragment reads are those of the 128^2 bf16 kernel with K counted in BYTES (128 per step): a lane's two
+// 16-B fragment reads (chunks lk and lk+4 of a row) are the 32 k-values it feeds to ONE v_mfma_scale_f32_16x16x128_f8f6f4 (block
+// scales 2^0) -- twice the contraction depth of the bf16 kernel per LDS byte and per matrix-pipe cycle.  Which 32 k a lane holds
+// does not matter as long as both operands use the same split (tools/probes/fp8_mfma_probe.hip checks the instruction's row /
+// k-group / output mapping and the converter's encodings on hardware).
+// =============================================================================================
+typedef __attribute__((ext_vector_type(8))) int v8i32;
+
+__device__ __forceinline__ void g2r_kc8(const unsigned char* P, long ld, int row0, int nrows, int k0, int kend, int tid, uint4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + 256 * i;
+        int row = c >> 3, kc = c & 7;
+        int gr = row0 + row, gk = k0 + kc * 16;
+        r[i] = (gr < nrows && gk < kend) ? *reinterpret_cast<const uint4*>(P + (long)gr * ld + gk) : make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ v8i32 frag_kc8(const unsigned char* lds, int row, int lk) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(lds + row * 128 + ((lk ^ swz(row)) << 4));
+    const uint4 hi = *reinterpret_cast<const uint4*>(lds + row * 128 + (((lk + 4) ^ swz(row)) << 4));
+    return (v8i32){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+}
+
+__global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmArgs g0, const float* __restrict__ sa, const float* __restrict__ sb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
+    unsigned char* ldsA = lds;
+    unsigned char* ldsB = lds + 128 * 128;
+    GemmArgs g = g0;
+    g.alpha = g0.alpha * sa[0] * sb[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = xcd_remap(blockIdx.x, g.nbm * g.nbn);
+    const int mblk = wg / g.nbn, nblk = wg % g.nbn;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+    const unsigned char* A = reinterpret_cast<const unsigned char*>(g.A);
+    const unsigned char* B = reinterpret_cast<const unsigned char*>(g.B);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 ra[4], rb[4];
+    g2r_kc8(A, g.lda, m0, g.M, 0, g.K, tid, ra);
+    g2r_kc8(B, g.ldb, n0, g.N, 0, g.K, tid, rb);
+    r2s_kc(ldsA, tid, ra);
+    r2s_kc(ldsB, tid, rb);
+    __syncthreads();
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lrow = lane & 15, lk = lane >> 4;
+    for (int k0 = 0; k0 < g.K; k0 += 128) {
+        const bool has_next = (k0 + 128) < g.K;
+        if (has_next) {
+            g2r_kc8(A, g.lda, m0, g.M, k0 + 128, g.K, tid, ra);
+            g2r_kc8(B, g.ldb, n0, g.N, k0 + 128, g.K, tid, rb);
+        }
+        v8i32 fm[4], fn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fm[t] = frag_kc8(ldsA, wm + t * 16 + lrow, lk);
+            fn[t] = frag_kc8(ldsB, wn + t * 16 + lrow, lk);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fn[tn], fm[tm], acc[tm][tn], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        __syncthreads();
+        if (has_next) {
+            r2s_kc(ldsA, tid, ra);
+            r2s_kc(ldsB, tid, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+            epilogue4<bf16_t>(g, m0 + wm + tm * 16 + lrow, n0 + wn + tn * 16 + 4 * lk, acc[tm][tn], 0);
+}
+
+// |x|_max of a tensor into out[0] (which the caller zeroes): non-negative floats order like their bit patterns
+template <typename T>
+__global__ void amax_kernel(const T* __restrict__ x, float* __restrict__ out, long n4) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float v[4];
+        ld4<T>(x + i * 4, v);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+    }
+}
+// q = e4m3(x / scale), scale = max(amax, tiny) / 448 written to scale_out[0]; values are clamped first (the converter maps
+// anything above 448 + half an ulp to NaN, it does not saturate)
+template <typename T>
+__global__ void quant_fp8_kernel(const T* __restrict__ x, const float* __restrict__ amax, unsigned int* __restrict__ q,
+                                 float* __restrict__ scale_out, long n4) {
+    const float sc = fmaxf(amax[0], 1e-20f) * (1.0f / 448.0f);
+    const float inv = 1.0f / sc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = sc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float v[4];
+        ld4<T>(x + i * 4, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * inv, -448.f), 448.f);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+        q[i] = (unsigned int)w;
+    }
+}
+
+extern "C" int ecamp_amax(const void* x, float* out, int64_t n, int32_t dtype, hipStream_t stream) {
+    ECAMP_CHECK_ARG(x && out && n > 0 && n % 4 == 0, "amax: bad args");
+    ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "amax: bad dtype %d", dtype);
+    const long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    if (dtype == ECAMP_F32) hipLaunchKernelGGL(amax_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)x, out, n4);
+    else hipLaunchKernelGGL(amax_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)x, out, n4);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ecamp_quant_fp8(const void* x, const float* amax, void* q, float* scale_out, int64_t n, int32_t dtype, hipStream_t stream) {
+    ECAMP_CHECK_ARG(x && amax && q && scale_out && n > 0 && n % 4 == 0, "quant_fp8: bad args");
+    ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "quant_fp8: bad dtype %d", dtype);
+    const long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    if (dtype == ECAMP_F32) hipLaunchKernelGGL(quant_fp8_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)x, amax, (unsigned int*)q, scale_out, n4);
+    else hipLaunchKernelGGL(quant_fp8_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)x, amax, (unsigned int*)q, scale_out, n4);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                              int64_t ldc, const float* scale_a, const float* scale_b, const float* bias, const void* residual,
+                              int64_t ldr, void* pre_out, int64_t ldp, int act, hipStream_t stream) {
+    ECAMP_CHECK_ARG(A8 && B8 && C && scale_a && scale_b, "ecamp_gemm_fp8: null operand");
+    ECAMP_CHECK_ARG(M > 0 && N > 0 && K > 0, "ecamp_gemm_fp8: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
+    ECAMP_CHECK_ARG(K % 16 == 0 && lda % 16 == 0 && ldb % 16 == 0 && N % 4 == 0, "ecamp_gemm_fp8: K, lda, ldb must be multiples of 16 and N of 4");
+    GemmArgs g;
+    g.dbg = 0; g.wide = 0; g.nsplit = 1;
+    g.A = A8; g.B = B8; g.C = C;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.bias = bias; g.residual = residual; g.ldr = ldr; g.pre_out = pre_out; g.ldp = ldp; g.gmul = nullptr; g.ldg = 0;
+    g.alpha = 1.0f; g.alpha_dev = nullptr; g.alpha_out = 1.0f; g.alpha_dev_out = nullptr;
+    g.rowsum = nullptr;
+    g.act = act; g.out_f32 = 0; g.accumulate = 0;
+    g.k_per_split = (int)K;
+    g.partial = nullptr;
+    g.nbm = ceil_div(M, BM); g.nbn = ceil_div(N, BN);
+    const bool prof = ecamp_prof_active();
+    if (prof) ecamp_prof_begin(ECAMP_PROF_GEMM_FP8, 2.0 * (double)M * (double)N * (double)K, stream);
+    hipLaunchKernelGGL(gemm_fp8_kernel, dim3(g.nbm * g.nbn), dim3(256), 0, stream, g, scale_a, scale_b);
+    if (prof) ecamp_prof_end(stream);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
 // host entry
 // =============================================================================================
 // ---- kernel selection ------------------------------------------------------------------------------------------

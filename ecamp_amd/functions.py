@@ -26,6 +26,16 @@ def _none(n):
     return (None,) * n
 
 
+def _vit_linear(m, x, lin, **kw):
+    """Forward of a timm Attention.qkv / proj or Mlp.fc1 / fc2 layer: bf16 GEMM, or -- model.fp8_forward, BASELINE configs[4] --
+    the e4m3 GEMM on per-tensor-quantised copies of x and the weight.  The backward is the bf16 one either way."""
+    A = m.arena
+    if m.fp8_forward and x.dtype == torch.bfloat16:
+        w8, ws = A.w8(lin.weight)
+        return ops.linear_fwd_fp8(x, w8, ws, lin.bias.data, **kw)
+    return ops.linear_fwd(x, A.w(lin.weight), lin.bias.data, **kw)
+
+
 # =============================================================================================
 class StemFn(torch.autograd.Function):
     @staticmethod
@@ -70,15 +80,15 @@ class VitBlockFn(torch.autograd.Function):
         hd = D // heads
         eps = blk.norm1.eps
         h, _, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight.data, blk.norm1.bias.data, eps)
-        qkv = ops.linear_fwd(h, A.w(blk.attn.qkv.weight), blk.attn.qkv.bias.data)
+        qkv = _vit_linear(m, h, blk.attn.qkv)
         st = (T * 3 * D, 3 * D, hd)
         flat = qkv.view(-1)
         a, lse = ops.attn_fwd(flat, flat[D:], flat[2 * D:], B, heads, T, T, hd, st, st, st, hd ** -0.5)
         a = a.view(B * T, D)
-        x1 = ops.linear_fwd(a, A.w(blk.attn.proj.weight), blk.attn.proj.bias.data, residual=x)
+        x1 = _vit_linear(m, a, blk.attn.proj, residual=x)
         h2, _, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight.data, blk.norm2.bias.data, eps)
-        u, pre = ops.linear_fwd(h2, A.w(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, act=1, save_pre=True)
-        x2 = ops.linear_fwd(u, A.w(blk.mlp.fc2.weight), blk.mlp.fc2.bias.data, residual=x1)
+        u, pre = _vit_linear(m, h2, blk.mlp.fc1, act=1, save_pre=True)
+        x2 = _vit_linear(m, u, blk.mlp.fc2, residual=x1)
         ctx.s = (x, mean1, rstd1, h, qkv, a, lse, x1, mean2, rstd2, h2, pre, u)
         ctx.cfg = (blk, m, B, T, heads)
         return x2

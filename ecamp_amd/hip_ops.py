@@ -58,6 +58,35 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, save_pre=False, out_dtype=
     return (y, pre) if save_pre else y
 
 
+# --------------------------------------------------------------------------------------------- fp8 forward (configs[4])
+def quantize_fp8(x):
+    """Per-tensor e4m3 quantisation of a contiguous f32/bf16 tensor (numel % 4 == 0): -> (q uint8 same shape, scale f32[1]);
+    x ~= q * scale, scale = max|x| / 448 taken from THIS tensor (current scaling: two passes, no history)."""
+    _chk(x)
+    assert x.is_contiguous()
+    amax = torch.empty((1,), device=x.device, dtype=torch.float32)
+    zero_(amax)
+    call("ecamp_amax", ptr(x), ptr(amax), x.numel(), code(x.dtype), stream())
+    q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    scale = torch.empty((1,), device=x.device, dtype=torch.float32)
+    call("ecamp_quant_fp8", ptr(x), ptr(amax), ptr(q), ptr(scale), x.numel(), code(x.dtype), stream())
+    return q, scale
+
+
+def linear_fwd_fp8(x, w8, w_scale, bias=None, act=0, residual=None, save_pre=False):
+    """y (bf16) = act(dequant(q(x)) @ dequant(w8).T + bias) (+ residual): x [M,K] bf16 is quantised here, w8 [N,K] uint8 + scale
+    come from `quantize_fp8(weight)` (once per optimizer step).  The backward of the layer keeps using the bf16 x and w."""
+    M, K = x.shape
+    N = w8.shape[0]
+    assert w8.shape[1] == K and w8.dtype == torch.uint8 and x.dtype == torch.bfloat16 and x.is_contiguous() and w8.is_contiguous()
+    x8, xs = quantize_fp8(x)
+    y = torch.empty((M, N), device=x.device, dtype=torch.bfloat16)
+    pre = torch.empty((M, N), device=x.device, dtype=torch.bfloat16) if save_pre else None
+    call("ecamp_gemm_fp8", ptr(x8), ptr(w8), ptr(y), M, N, K, K, K, N, ptr(xs), ptr(w_scale), ptr(bias), ptr(residual),
+         residual.stride(0) if residual is not None else 0, ptr(pre), N, int(act), stream())
+    return (y, pre) if save_pre else y
+
+
 def linear_dgrad(dy, w, gmul=None, alpha=1.0, alpha_dev=None, residual=None):
     """dx = alpha * (dy @ w) [* gelu'(gmul)] [+ residual];  dy [M,N], w [N,K]."""
     M, N = dy.shape

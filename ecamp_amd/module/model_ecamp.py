@@ -74,7 +74,7 @@ class InterpolateConvSuperResolution(nn.Module):
 class ECAMP(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=768,
                  decoder_depth=4, decoder_num_heads=6, mlp_ratio=4.0, norm_layer=nn.LayerNorm, norm_pix_loss=False,
-                 bert_config=None, compute_dtype=torch.bfloat16, sr_window=None):
+                 bert_config=None, compute_dtype=torch.bfloat16, sr_window=None, fp8_forward=False):
         super().__init__()
         if in_chans != 3 or patch_size % 4 != 0:
             raise ValueError("in_chans must be 3 and patch_size a multiple of 4")
@@ -86,6 +86,11 @@ class ECAMP(nn.Module):
         self.img_size, self.patch_size, self.embed_dim = img_size, patch_size, embed_dim
         self.num_heads, self.decoder_embed_dim, self.decoder_num_heads = num_heads, decoder_embed_dim, decoder_num_heads
         self.compute_dtype = compute_dtype
+        # BASELINE.json configs[4]: the forward GEMMs of the ViT blocks (qkv, proj, fc1, fc2; encoder and decoder) on e4m3 copies of
+        # activations and weights (per-tensor scales), gradients through the bf16 path.  bf16 compute dtype only.
+        if fp8_forward and compute_dtype != torch.bfloat16:
+            raise ValueError("fp8_forward needs compute_dtype=torch.bfloat16")
+        self.fp8_forward = bool(fp8_forward)
         self.bert_config = bert_config if bert_config is not None else BertConfig()
         # image encoder (model_ecamp.py:58-69)
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)

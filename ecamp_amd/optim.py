@@ -75,6 +75,7 @@ class FusedAdamW(torch.optim.Optimizer):
         ops.adamw_grouped(A.flat_p, A.flat_g, self._m, self._v, A.flat_p16, self._table, [g["lr"] for g in self.param_groups],
                           [g["weight_decay"] for g in self.param_groups], g0["betas"][0], g0["betas"][1], g0["eps"], self._step,
                           self.grad_scale)
+        A.version += 1   # the bf16 shadows changed: the fp8-forward mode re-quantises its weight copies on next use
         return loss
 
     def zero_grad(self, set_to_none=False):

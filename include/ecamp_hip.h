@@ -53,6 +53,20 @@ int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc
  * set by the data-parallel wrapper, whose all-reduce kernels share the CUs during backward. */
 int ecamp_set_option(const char* name, int32_t value);
 
+/* ---- fp8 forward (BASELINE.json configs[4]: "fp8 MFMA forward (bf16 grads) for QKV/MLP GEMMs"; no reference counterpart -- the
+ * reference runs these nn.Linear layers under torch.cuda.amp, main_pretrain.py:138).  Per-tensor scaling, OCP e4m3:
+ *   ecamp_amax      out[0] = max(out[0], max|x|)               (caller zeroes out[0]; n % 4 == 0)
+ *   ecamp_quant_fp8 scale_out[0] = max(amax[0], tiny) / 448;  q[i] = e4m3(clamp(x[i] / scale, +-448))   (one byte per element)
+ *   ecamp_gemm_fp8  C[M,N] (bf16) = act((A8[M,K] . B8[N,K]^T) * scale_a[0] * scale_b[0] + bias) (+ residual); act 0 none, 1 exact GELU
+ *                   with the bf16 pre-activation saved to pre_out -- the forward of timm Attention.qkv / proj and Mlp.fc1 / fc2
+ *                   (call sites model_ecamp.py:233-234, 254-255).  K, lda, ldb multiples of 16 bytes.  f32 accumulation on
+ *                   v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales. */
+int ecamp_amax(const void* x, float* out, int64_t n, int32_t dtype, ecampStream_t stream);
+int ecamp_quant_fp8(const void* x, const float* amax, void* q, float* scale_out, int64_t n, int32_t dtype, ecampStream_t stream);
+int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                   const float* scale_a, const float* scale_b, const float* bias, const void* residual, int64_t ldr, void* pre_out,
+                   int64_t ldp, int act, ecampStream_t stream);
+
 /* ---- LayerNorm (nn.LayerNorm eps 1e-6: model_ecamp.py:69,84,235,256 + timm Block norms; HF LN eps 1e-12:
  * BertSelfOutput/BertOutput/BertEmbeddings/transform).  y = LN(z), z = dropout(x) + residual (both optional). */
 int ecamp_layernorm_fwd(const void* x, const void* residual, void* z_out, const float* gamma, const float* beta, void* y,

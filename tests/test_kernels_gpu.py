@@ -593,3 +593,52 @@ def test_gemm_full_size_kernels_agree(dev):
     ref_gw = dy[:, cols].double().t() @ x.double()
     assert float((res[2][3][cols].double() - ref_gw).abs().max() / ref_gw.abs().max()) < 2e-3
     assert float((res[2][4].double() - dy.double().sum(0)).abs().max() / dy.double().sum(0).abs().max()) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ fp8 forward (BASELINE configs[4])
+def _e4m3_ref(x):
+    """Host restatement of per-tensor e4m3 quantisation: (dequantised values, scale) via torch.float8_e4m3fn (OCP, RNE)."""
+    amax = x.abs().max().clamp_min(1e-20)
+    scale = amax.float() * (1.0 / 448.0)
+    q = (x.float() / scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_quantize_fp8_is_bit_exact(dev, dtype):
+    o = ops()
+    x = rnd(gen(300, 512, seed=11, scale=3.0), dtype)
+    x[0, 0] = 0.0
+    q, s = o.quantize_fp8(x.to(dev, dtype).contiguous())
+    qr, sr = _e4m3_ref(x)
+    assert abs(s.item() - sr.item()) <= 1e-6 * sr.item()
+    same = (q.cpu().view(torch.uint8) == qr.view(torch.uint8))
+    # the only admissible differences: x/scale on the device is x * (1/scale) -- a tie can round the other way by one code
+    assert same.float().mean().item() > 0.999
+    d = (q.cpu().view(torch.float8_e4m3fn).float() - qr.float()).abs() / qr.float().abs().clamp_min(2 ** -6)
+    assert d.max().item() <= 0.126
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 256), (100, 2304, 768), (512, 132, 3072), (130, 512, 48)])
+def test_gemm_fp8_forward_epilogues(dev, M, N, K):
+    """fp8 forward GEMM == f32 matmul of the DEQUANTISED operands (the only rounding left is the bf16 output / f32 summation
+    order), for every forward epilogue; and within the e4m3 quantisation noise of the unquantised product."""
+    o = ops()
+    dtype = torch.bfloat16
+    x, w, b, r = rnd(gen(M, K, seed=1), dtype), rnd(gen(N, K, seed=2, scale=K ** -0.5), dtype), gen(N, seed=3), rnd(gen(M, N, seed=4), dtype)
+    xd, wd, bd, rd = x.to(dev, dtype), w.to(dev, dtype), b.to(dev), r.to(dev, dtype)
+    w8, ws = o.quantize_fp8(wd)
+    xq, xs = o.quantize_fp8(xd)
+    xdq = xq.cpu().view(torch.float8_e4m3fn).float() * xs.item()
+    wdq = w8.cpu().view(torch.float8_e4m3fn).float() * ws.item()
+    ref = xdq @ wdq.T
+    tol = TOL[dtype]
+    check("fp8 linear", o.linear_fwd_fp8(xd, w8, ws, bd), ref + b, tol)
+    check("fp8 linear+residual", o.linear_fwd_fp8(xd, w8, ws, None, residual=rd), ref + r, tol)
+    y, pre = o.linear_fwd_fp8(xd, w8, ws, bd, act=1, save_pre=True)
+    check("fp8 linear pre", pre, ref + b, tol)
+    check("fp8 linear gelu", y, F.gelu(rnd(ref + b, dtype)), tol)
+    exact = x @ w.T + b
+    e = ((o.linear_fwd_fp8(xd, w8, ws, bd).float().cpu() - exact).norm() / exact.norm()).item()
+    print("  fp8 vs unquantised product: relative Frobenius error %.3e" % e)
+    assert e < 6e-2
