@@ -116,9 +116,9 @@ class DistributedDataParallel(nn.Module):
             dist.broadcast(arena.flat_p, src=0, group=process_group)  # C1: parameters rank0 -> all (one 733 MB message)
             arena.sync_shadow()
             # RCCL's all-reduce workgroups share the CUs with the backward pass, and a persistent one-workgroup-per-CU GEMM
-            # whose CU is taken starts that workgroup late (tools/hog_probe.py): leave 16 CUs to the communication kernels
+            # whose CU is taken starts that workgroup late (tools/hog_probe.py): leave 32 CUs to the communication kernels
             from . import hip_ops
-            hip_ops.set_option("p8_wgrad_reserve_cus", int(os.environ.get("ECAMP_P8_RESERVE_CUS", "16")))
+            hip_ops.set_option("p8_wgrad_reserve_cus", int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")))
         self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group, force_comm)
         arena.on_ready = self.reducer.mark_ready
 
