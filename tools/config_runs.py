@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""One-GPU step times of the BASELINE.json configs that are not the bench line: configs[3] ViT-L/16 at 448^2 (B=64) and configs[4]
+ViT-B/16 at B=512 in bf16 and with the fp8 forward.  python tools/config_runs.py [--steps 8]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ecamp_amd import optim
+from ecamp_amd.data import synthetic_batch
+from ecamp_amd.module import model_ecamp
+from ecamp_amd.util.misc import NativeScalerWithGradNormCount
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=8); args = ap.parse_args()
+dev = torch.device("cuda:0")
+def run(name, ctor, B, big, **kw):
+    torch.manual_seed(0)
+    model = ctor(compute_dtype=torch.bfloat16, **kw).to(dev); model.prepare(); model.train()
+    opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
+    scaler = NativeScalerWithGradNormCount()
+    batch = synthetic_batch(B, 128, big, seed=0, device=dev)
+    def step():
+        mim, res, mlm = model(batch)
+        scaler(mim + res + mlm, opt, parameters=model.parameters(), update_grad=True)
+        opt.zero_grad()
+        return mim, res, mlm
+    for _ in range(6): out = step()   # allocator and weight-quantisation caches settle within a few steps
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps): out = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    r = {"config": name, "pairs_per_gpu": B, "ms_per_step": round(1e3 * dt, 2), "pairs_per_s": round(B / dt, 1),
+         "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses": [round(float(t), 4) for t in out]}
+    print(json.dumps(r), flush=True)
+    del model, opt, batch
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+run("configs[3] ViT-L/16 448^2 (784 visible tokens), bf16", model_ecamp.ecamp_large_448, 64, 896)
+run("configs[4] ViT-B/16 bf16 reference point, B=512", model_ecamp.ecamp, 512, 448)
+run("configs[4] ViT-B/16 fp8 forward (bf16 grads), B=512", model_ecamp.ecamp, 512, 448, fp8_forward=True)
