@@ -123,3 +123,29 @@ def test_ddp_wrapper_runs_rccl_on_the_side_stream(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_bench_prints_one_contract_line(dev):
+    """bench.py's output contract: exactly ONE JSON line on stdout with the driver's keys, the `roofline` object measured from
+    HIP events, and `cpu_baseline` only when asked for (skipped here to keep the test short)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in r, k
+    assert r["unit"] == "pairs/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "bf16" and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - 8 * 1e3 / r["ms_per_step"]) < 1e-2 * r["value"]
+    rf = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "cpu_baseline" not in r

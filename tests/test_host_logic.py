@@ -148,3 +148,17 @@ def test_grad_norm_reference_formula_on_cpu_tensors():
         p.grad = torch.randn_like(p)
     n = misc.get_grad_norm_(ps)
     assert n.item() == pytest.approx(torch.cat([p.grad.flatten() for p in ps]).norm().item(), rel=1e-6)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """The product path has no CPU fallback: on a box without an MI355X bench.py stops with a message instead of timing anything."""
+    import os, subprocess, sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "no CPU fallback" in (p.stderr + p.stdout)
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
