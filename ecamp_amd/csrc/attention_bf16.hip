@@ -556,9 +556,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // =============================================================================================
-// "Resident" variants: one workgroup per (batch, head); ALL keys/values (fwd, dQ) or ALL queries/dO (dK/dV) are staged into
-// LDS once, then each wave walks 16-row tiles with no further workgroup barrier.  Used whenever the operands fit in the 160 KiB
-// LDS (every shape of the ECAMP configs except dK/dV at hd=128, S>192, which streams chunks with the kernels above).
+// "Resident" forward: one workgroup per (batch, head); ALL keys/values are staged into LDS once, then each wave walks 16-row
+// query tiles with no further workgroup barrier.  Used for Tk <= 128 (the encoder and the report side).
 template <int HD, int KCH>
 __global__ __launch_bounds__(256) void attn16r_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -662,180 +661,6 @@ __global__ __launch_bounds__(256) void attn16r_fwd_kernel(AttnArgs a) {
     }
 }
 
-template <int HD, int KCH>
-__global__ __launch_bounds__(256) void attn16r_bwd_dq_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TB = TileCfg<HD>::BYTES;
-    unsigned char* KT = smem;
-    unsigned char* VT = smem + KCH * TB;
-    unsigned char* ST = smem + 2 * KCH * TB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const long bh = blockIdx.x;
-    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
-    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
-    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
-    const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_sb + h * a.o_sh;
-    const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_sb + h * a.do_sh;
-    bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_sb + h * a.dq_sh;
-#pragma unroll
-    for (int c = 0; c < KCH; ++c) {
-        stage_tile<HD>(KT + c * TB, kb, a.k_st, c * 64, a.Tk, tid);
-        stage_tile<HD>(VT + c * TB, vb, a.v_st, c * 64, a.Tk, tid);
-    }
-    __syncthreads();
-    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    unsigned char* st = ST + wave * 2048;
-    for (int q0 = wave * 16; q0 < a.Tq; q0 += 64) {
-        bf16x8 qf[HD / 32], gf[HD / 32], of[HD / 32];
-        load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
-        load_row_frags<HD>(gf, gb, a.do_st, q0, a.Tq, lane);
-        load_row_frags<HD>(of, ob, a.o_st, q0, a.Tq, lane);
-        float dl = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < HD / 32; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)gf[ks][e]) * bf2f((bf16_t)of[ks][e]);
-        dl = red4_sum(dl);
-        const int qi = q0 + li;
-        const bool qok = qi < a.Tq;
-        if (g == 0 && qok) a.delta[bh * a.Tq + qi] = dl;
-        const float lse = qok ? a.lse[bh * a.Tq + qi] : 0.f;
-        f32x4 dq[HD / 16];
-#pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int c = 0; c < KCH; ++c) {
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) {
-                    s = MFMA(frag_rows<HD>(KT + c * TB, jt * 16 + li, ks * 4 + g), qf[ks], s);
-                    dp = MFMA(frag_rows<HD>(VT + c * TB, jt * 16 + li, ks * 4 + g), gf[ks], dp);
-                }
-                float ds[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int j = c * 64 + jt * 16 + 4 * g + r;
-                    bool ok = qok && j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
-                    float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
-                    float gg = dp[r];
-                    if (a.drop_p > 0.f) {
-                        uint64_t e = ((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk + j;
-                        gg *= dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
-                    }
-                    ds[r] = p * (gg - dl);
-                }
-                ptile_write4(st, li, jt * 16 + 4 * g, ds);
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 sf = ptile_frag(st, li, kk * 4 + g);
-#pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = MFMA(frag_tr<HD>(KT + c * TB, dt * 16, kk * 32, lane), sf, dq[dt]);
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (qok) {
-#pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt) store4(dqb + (long)qi * a.dq_st + dt * 16 + 4 * g, dq[dt], a.scale);
-        }
-    }
-}
-
-template <int HD, int QCH>
-__global__ __launch_bounds__(256) void attn16r_bwd_dkv_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TB = TileCfg<HD>::BYTES;
-    unsigned char* QT = smem;
-    unsigned char* GT = smem + QCH * TB;
-    unsigned char* PT = smem + 2 * QCH * TB;
-    unsigned char* ST = PT + 4 * 2048;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const long bh = blockIdx.x;
-    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
-    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
-    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
-    const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_sb + h * a.do_sh;
-    bf16_t* dkb = reinterpret_cast<bf16_t*>(a.dk) + b * a.dk_sb + h * a.dk_sh;
-    bf16_t* dvb = reinterpret_cast<bf16_t*>(a.dv) + b * a.dv_sb + h * a.dv_sh;
-#pragma unroll
-    for (int c = 0; c < QCH; ++c) {
-        stage_tile<HD>(QT + c * TB, qb, a.q_st, c * 64, a.Tq, tid);
-        stage_tile<HD>(GT + c * TB, gb, a.do_st, c * 64, a.Tq, tid);
-    }
-    __syncthreads();
-    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    unsigned char* pt = PT + wave * 2048;
-    unsigned char* st = ST + wave * 2048;
-    for (int j0 = wave * 16; j0 < a.Tk; j0 += 64) {
-        bf16x8 kf[HD / 32], vf[HD / 32];
-        load_row_frags<HD>(kf, kb, a.k_st, j0, a.Tk, lane);
-        load_row_frags<HD>(vf, vb, a.v_st, j0, a.Tk, lane);
-        const int kj = j0 + li;
-        const bool jok = kj < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + kj] != 0);
-        f32x4 dk[HD / 16], dv[HD / 16];
-#pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int c = 0; c < QCH; ++c) {
-            if (c * 64 >= a.Tq) break;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) {
-                    s = MFMA(frag_rows<HD>(QT + c * TB, it * 16 + li, ks * 4 + g), kf[ks], s);
-                    dp = MFMA(frag_rows<HD>(GT + c * TB, it * 16 + li, ks * 4 + g), vf[ks], dp);
-                }
-                float pd[4], ds[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int i = c * 64 + it * 16 + 4 * g + r;
-                    bool ok = jok && i < a.Tq;
-                    float lse = ok ? a.lse[bh * a.Tq + i] : 0.f;
-                    float dl = ok ? a.delta[bh * a.Tq + i] : 0.f;
-                    float p = ok ? __expf(s[r] * a.scale - lse) : 0.f;
-                    float m = 1.0f;
-                    if (a.drop_p > 0.f) {
-                        uint64_t e = ((uint64_t)bh * a.Tq + i) * (uint64_t)a.Tk + kj;
-                        m = dropout_scale(a.seed, a.offset, e, a.drop_p, inv_keep);
-                    }
-                    pd[r] = p * m;
-                    ds[r] = p * (dp[r] * m - dl);
-                }
-                ptile_write4(pt, li, it * 16 + 4 * g, pd);
-                ptile_write4(st, li, it * 16 + 4 * g, ds);
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 pf = ptile_frag(pt, li, kk * 4 + g), sf = ptile_frag(st, li, kk * 4 + g);
-#pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt) {
-                    dv[dt] = MFMA(frag_tr<HD>(GT + c * TB, dt * 16, kk * 32, lane), pf, dv[dt]);
-                    dk[dt] = MFMA(frag_tr<HD>(QT + c * TB, dt * 16, kk * 32, lane), sf, dk[dt]);
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (kj < a.Tk) {
-#pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt) {
-                store4(dkb + (long)kj * a.dk_st + dt * 16 + 4 * g, dk[dt], a.scale);
-                store4(dvb + (long)kj * a.dv_st + dt * 16 + 4 * g, dv[dt], 1.0f);
-            }
-        }
-    }
-}
-
 template <typename K>
 static void lds_optin(K kern, size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -877,35 +702,19 @@ static void fwd16(const AttnArgs& a, hipStream_t st) {
 }
 template <int HD>
 static void bwd16(const AttnArgs& a, hipStream_t st) {
-    dim3 block(256), gridr(a.B * a.H);
-    const int kch = a.Tk <= 64 ? 1 : a.Tk <= 128 ? 2 : 4;
-    const size_t shr = (size_t)2 * kch * TileCfg<HD>::BYTES + 4 * 2048;
-    // measured on MI355X: staging everything once wins for the forward (fewer barriers), but the backward kernels run faster
-    // as 64-row workgroups streaming chunks (4x more workgroups, 2-3x smaller LDS footprint -> higher occupancy)
-    constexpr bool RESIDENT_BWD = false;
-    if (RESIDENT_BWD && shr <= LDS_MAX) {
-        if (kch == 1) LAUNCH_R((attn16r_bwd_dq_kernel<HD, 1>), gridr, shr, st, a);
-        else if (kch == 2) LAUNCH_R((attn16r_bwd_dq_kernel<HD, 2>), gridr, shr, st, a);
-        else LAUNCH_R((attn16r_bwd_dq_kernel<HD, 4>), gridr, shr, st, a);
-    } else {
-        dim3 grid(ceil_div(a.Tq, 64), a.B * a.H);
-        size_t shm = 2 * TileCfg<HD>::BYTES + 4 * 2048 + 64 * sizeof(int);
-        if (a.Tk <= 64) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 1>), grid, block, shm, st, a);
-        else if (a.Tk <= 128) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 2>), grid, block, shm, st, a);
-        else if (a.Tk <= 256) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 4>), grid, block, shm, st, a);
-        else hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 0>), grid, block, shm, st, a);
-    }
-    const int qch = a.Tq <= 64 ? 1 : a.Tq <= 128 ? 2 : 4;
-    const size_t shq = (size_t)2 * qch * TileCfg<HD>::BYTES + 8 * 2048;
-    if (RESIDENT_BWD && a.Tq <= 256 && shq <= LDS_MAX) {
-        if (qch == 1) LAUNCH_R((attn16r_bwd_dkv_kernel<HD, 1>), gridr, shq, st, a);
-        else if (qch == 2) LAUNCH_R((attn16r_bwd_dkv_kernel<HD, 2>), gridr, shq, st, a);
-        else LAUNCH_R((attn16r_bwd_dkv_kernel<HD, 4>), gridr, shq, st, a);
-    } else {
-        dim3 grid2(ceil_div(a.Tk, 64), a.B * a.H);
-        size_t shm2 = 2 * TileCfg<HD>::BYTES + 8 * 2048 + 128 * sizeof(float);
-        hipLaunchKernelGGL((attn16_bwd_dkv_kernel<HD>), grid2, block, shm2, st, a);
-    }
+    // The backward kernels run as 64-row workgroups streaming 64-key (dQ) / 64-query (dK, dV) chunks.  "Resident" variants that
+    // stage all of K/V (or Q/dO) once per (batch, head), like the forward above, were built and measured slower on MI355X: a quarter
+    // of the workgroups and 2-3x the LDS footprint cost more occupancy than the saved barriers return (rejected).
+    dim3 block(256);
+    dim3 grid(ceil_div(a.Tq, 64), a.B * a.H);
+    size_t shm = 2 * TileCfg<HD>::BYTES + 4 * 2048 + 64 * sizeof(int);
+    if (a.Tk <= 64) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 1>), grid, block, shm, st, a);
+    else if (a.Tk <= 128) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 2>), grid, block, shm, st, a);
+    else if (a.Tk <= 256) hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 4>), grid, block, shm, st, a);
+    else hipLaunchKernelGGL((attn16_bwd_dq_kernel<HD, 0>), grid, block, shm, st, a);
+    dim3 grid2(ceil_div(a.Tk, 64), a.B * a.H);
+    size_t shm2 = 2 * TileCfg<HD>::BYTES + 8 * 2048 + 128 * sizeof(float);
+    hipLaunchKernelGGL((attn16_bwd_dkv_kernel<HD>), grid2, block, shm2, st, a);
 }
 void attn_bf16_fwd(const AttnArgs& a, int hd, hipStream_t st) {
     if (hd == 32) fwd16<32>(a, st); else if (hd == 64) fwd16<64>(a, st); else fwd16<128>(a, st);

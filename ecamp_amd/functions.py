@@ -75,7 +75,6 @@ class StemFn(torch.autograd.Function):
 class VitBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blk, m, B, T, heads):
-        A = m.arena
         D = x.shape[1]
         hd = D // heads
         eps = blk.norm1.eps
