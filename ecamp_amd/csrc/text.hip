@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const T* __restrict
         if (c < nv) ld4<float>(gamma + c * 4, gm[i]);
         else gm[i][0] = gm[i][1] = gm[i][2] = gm[i][3] = 0.f;
     }
-    for (long b = wave; b < B; b += 4) {
+    for (long b = (long)blockIdx.y * 4 + wave; b < B; b += 4 * (long)gridDim.y) {   // gridDim.y workgroups share a position
         const long row = b * S + s;
         const long id = ids[row], ty = type_ids[row];
         const float mu = mean[row], rs = rstd[row];
@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const T* __restrict
             float t = sh[c] + sh[cols + c] + sh[2 * cols + c] + sh[3 * cols + c];
             if (k == 0) atomicAdd(dgamma + c, t);
             else if (k == 1) atomicAdd(dbeta + c, t);
-            else if (k == 2) gpos[(long)s * cols + c] += t;  // this workgroup owns position row s
+            else if (k == 2) {
+                if (gridDim.y == 1) gpos[(long)s * cols + c] += t;  // this workgroup owns position row s
+                else atomicAdd(gpos + (long)s * cols + c, t);
+            }
             else if (k == 3) atomicAdd(gtype + c, t);
             else if (k == 4) { if (t != 0.f) atomicAdd(gtype + cols + c, t); }
             else if (k == 5) { if (hot0 != pad_id && t != 0.f) atomicAdd(gword + (long)hot0 * cols + c, t); }
@@ -211,7 +214,11 @@ extern "C" int ecamp_bert_embed_bwd(const void* de, const void* z, const float* 
                                     hipStream_t stream) {
     ECAMP_CHECK_ARG(de && z && mean && rstd && gamma && ids && type_ids && gword && gpos && gtype && dgamma && dbeta, "bert_embed_bwd: null pointer");
     ECAMP_CHECK_ARG(cols % 4 == 0 && cols <= 1024, "bert_embed_bwd: cols=%d must be a multiple of 4 and <= 1024", cols);
-    dim3 grid(S), block(256);
+    // S workgroups alone leave half of the 256 CUs idle at S = 128: split the batch over gridDim.y workgroups per position
+    int gy = (int)(B / 32);
+    if (gy < 1) gy = 1;
+    if (gy > 8) gy = 8;
+    dim3 grid(S, gy), block(256);
     size_t shm = (size_t)4 * cols * sizeof(float);
     const int it = ceil_div(cols / 4, 64);
 #define L(T_, IT_) hipLaunchKernelGGL((bert_embed_bwd_kernel<T_, IT_>), grid, block, shm, stream, (const T_*)de, (const T_*)z, mean, rstd, gamma, (const long*)ids, (const long*)type_ids, gword, gpos, gtype, dgamma, dbeta, (long)B, S, cols, pad_id, hot0, hot1, drop_p, seed, offset)

@@ -28,3 +28,14 @@ dsr = torch.randn(B, 3, R, R, device=dev)
 gm = torch.tensor([1e-3, 1e-3], device=dev)
 t = timeit(lambda: o.img_loss_bwd(pred_img, imgs, mask, dsr, gm, B, R, p, torch.bfloat16))
 print("image-loss backward         %7.1f us  %6.0f GB/s" % (t, (imgs.numel() * 12 + pred.numel() * 2) / t / 1e3))
+# report-side embedding backward (LayerNorm backward + scatter into word / position / type rows)
+Bt, S, H = 256, 128, 768
+de = torch.randn(Bt * S, H, device=dev).bfloat16(); z = torch.randn(Bt * S, H, device=dev).bfloat16()
+mean = torch.zeros(Bt * S, device=dev); rstd = torch.ones(Bt * S, device=dev); gamma = torch.ones(H, device=dev)
+lens = torch.randint(32, 129, (Bt,), device=dev)
+ids = torch.randint(5, 30000, (Bt, S), device=dev); ids[torch.arange(S, device=dev)[None] >= lens[:, None]] = 0
+ids[:, 0] = 2; ids[torch.rand(Bt, S, device=dev) < 0.3] = 3
+ty = torch.zeros(Bt, S, dtype=torch.int64, device=dev)
+gw = torch.zeros(30000, H, device=dev); gp = torch.zeros(512, H, device=dev); gt = torch.zeros(2, H, device=dev); gg = torch.zeros(H, device=dev); gb = torch.zeros(H, device=dev)
+t = timeit(lambda: o.bert_embed_bwd(de, z, mean, rstd, gamma, ids, ty, gw, gp, gt, gg, gb, Bt, S, H))
+print("report embedding backward   %7.1f us  %6.0f GB/s" % (t, (de.numel() * 4 + de.numel() * 4) / t / 1e3))
