@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void adamw_grouped_kernel(float* __restrict__ 
                                                             float* __restrict__ m, float* __restrict__ v,
                                                             bf16_t* __restrict__ p16, const unsigned char* __restrict__ grp,
                                                             long n4, GroupHyper hp, float b1, float b2, float eps, float bc1,
-                                                            float rsqrt_bc2, float gscale) {
+                                                            float rsqrt_bc2, float gscale, float* __restrict__ sumsq) {
+    __shared__ float ss_sh[4];
+    float ss = 0.f;   // sum of squares of the (unscaled) gradients this thread consumed: the global grad-norm for free
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const unsigned gi = grp[i >> 4];  // 16 float4 per 64-element block
         if (gi >= 8) continue;
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(256) void adamw_grouped_kernel(float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float gr = gg[r] * gscale;
+            ss += gr * gr;
             pp[r] *= 1.0f - lr * wd;
             mm[r] = b1 * mm[r] + (1.0f - b1) * gr;
             vv[r] = b2 * vv[r] + (1.0f - b2) * gr * gr;
@@ -100,10 +103,14 @@ __global__ __launch_bounds__(256) void adamw_grouped_kernel(float* __restrict__ 
         st4<float>(v + i * 4, vv);
         if (p16) st4<bf16_t>(p16 + i * 4, pp);
     }
+    if (sumsq) {
+        ss = block_sum_256(ss, ss_sh);
+        if (threadIdx.x == 0) atomicAdd(sumsq, ss);
+    }
 }
 extern "C" int ecamp_adamw_grouped(float* p, const float* g, float* m, float* v, void* p_bf16, const uint8_t* block_group,
                                    int64_t n, int32_t ngroups, const float* lr_host, const float* wd_host, float beta1,
-                                   float beta2, float eps, int64_t step, float grad_scale, hipStream_t stream) {
+                                   float beta2, float eps, int64_t step, float grad_scale, float* grad_sumsq, hipStream_t stream) {
     ECAMP_CHECK_ARG(p && g && m && v && block_group && lr_host && wd_host, "ecamp_adamw_grouped: null pointer");
     ECAMP_CHECK_ARG(n % 64 == 0 && ngroups >= 1 && ngroups <= 8 && step >= 1, "ecamp_adamw_grouped: bad args (n=%ld, groups=%d)", (long)n, ngroups);
     GroupHyper hp;
@@ -116,7 +123,7 @@ extern "C" int ecamp_adamw_grouped(float* p, const float* g, float* m, float* v,
     if (nb > 8192) nb = 8192;
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adamw_grouped_kernel, dim3(nb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, block_group, n4, hp, beta1,
-                       beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+                       beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, grad_sumsq);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }

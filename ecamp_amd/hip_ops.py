@@ -365,11 +365,12 @@ def adamw(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
          float(wd), int(step), float(grad_scale), stream())
 
 
-def adamw_grouped(p, g, m, v, p16, block_group, lrs, wds, beta1, beta2, eps, step, grad_scale=1.0):
+def adamw_grouped(p, g, m, v, p16, block_group, lrs, wds, beta1, beta2, eps, step, grad_scale=1.0, grad_sumsq=None):
+    """grad_sumsq: optional zeroed f32[1]; receives sum((g * grad_scale)^2) over the updated elements (global grad-norm, fused)."""
     n = len(lrs)
     arr = ctypes.c_float * n
     call("ecamp_adamw_grouped", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), ptr(block_group), p.numel(), n, arr(*lrs), arr(*wds),
-         float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream())
+         float(beta1), float(beta2), float(eps), int(step), float(grad_scale), ptr(grad_sumsq), stream())
 
 
 # --------------------------------------------------------------------------------------------- side-stream weight gradients

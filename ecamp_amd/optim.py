@@ -67,16 +67,32 @@ class FusedAdamW(torch.optim.Optimizer):
         return arena
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_sumsq=None):
         loss = closure() if closure is not None else None
         A = self._bind()
         self._step += 1
         g0 = self.param_groups[0]
         ops.adamw_grouped(A.flat_p, A.flat_g, self._m, self._v, A.flat_p16, self._table, [g["lr"] for g in self.param_groups],
                           [g["weight_decay"] for g in self.param_groups], g0["betas"][0], g0["betas"][1], g0["eps"], self._step,
-                          self.grad_scale)
+                          self.grad_scale, grad_sumsq)
         A.version += 1   # the bf16 shadows changed: the fp8-forward mode re-quantises its weight copies on next use
         return loss
+
+    def covers(self, parameters):
+        """True when the tensors of `parameters` that carry a gradient are exactly the ones this optimizer updates: then
+        `step_with_grad_norm()` equals the reference's get_grad_norm_(parameters) followed by step()."""
+        own = {id(p) for g in self.param_groups for p in g["params"] if p.grad is not None}
+        given = {id(p) for p in parameters if p.grad is not None}
+        return len(own) > 0 and given == own
+
+    @torch.no_grad()
+    def step_with_grad_norm(self):
+        """One pass over the gradient arena: the update AND sum(g^2) of what it consumed (util/misc.py:280-292 computes the norm in
+        a separate pass over 733 MB just before the step).  -> 0-d tensor, the global L2 gradient norm before the update."""
+        A = self._bind()
+        s = ops.zeros((1,), A.device)
+        self.step(grad_sumsq=s)
+        return s.sqrt().reshape(())
 
     def zero_grad(self, set_to_none=False):
         """One memset of the gradient arena; p.grad stay views of it (set_to_none would detach them)."""

@@ -249,6 +249,9 @@ def get_grad_norm_(parameters, norm_type=2.0):
     return torch.norm(torch.stack([torch.norm(p.grad.detach(), norm_type).to(device) for p in parameters]), norm_type)
 
 
+_FUSED_GRAD_NORM = os.environ.get("ECAMP_FUSED_GRAD_NORM", "1") != "0"   # 0: separate sum-of-squares pass, as the reference does
+
+
 class NativeScalerWithGradNormCount:
     """Call signature and return value of misc.py:251-277.  bf16 / f32 training needs no loss scaling, so the scale is
     identically 1 (`state_dict` keeps the GradScaler keys so reference checkpoints round-trip)."""
@@ -268,7 +271,10 @@ class NativeScalerWithGradNormCount:
             assert parameters is not None
             norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
         else:
-            norm = get_grad_norm_(parameters if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]])
+            ps = list(parameters) if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]]
+            if _FUSED_GRAD_NORM and hasattr(optimizer, "step_with_grad_norm") and optimizer.covers(ps):
+                return optimizer.step_with_grad_norm()   # the norm falls out of the AdamW pass over the gradients
+            norm = get_grad_norm_(ps)
         optimizer.step()
         return norm
 

@@ -158,8 +158,10 @@ int ecamp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int6
 
 int ecamp_adamw_grouped(float* p, const float* g, float* m, float* v, void* p_bf16, const uint8_t* block_group, int64_t n,
                         int32_t ngroups, const float* lr_host, const float* wd_host, float beta1, float beta2, float eps,
-                        int64_t step, float grad_scale,
-                        ecampStream_t stream); /* whole-arena AdamW with timm's decay/no-decay groups, main_pretrain.py:253-254 */
+                        int64_t step, float grad_scale, float* grad_sumsq,
+                        ecampStream_t stream); /* whole-arena AdamW with timm's decay/no-decay groups, main_pretrain.py:253-254;
+                                                * grad_sumsq (nullable, caller-zeroed): += sum of (g * grad_scale)^2 over the updated
+                                                * elements -- the global gradient norm of util/misc.py:280-292 without a second pass */
 
 /* ---- optional in-process timing (bench.py roofline): HIP-event pairs around every GEMM / attention launch ---- */
 int ecamp_prof_enable(int on);
