@@ -14,6 +14,7 @@ import torch
 from . import hip_ops as ops
 
 ALIGN = 64
+LAZY_ZERO = __import__("os").environ.get("ECAMP_LAZY_ZERO_GRAD", "1") != "0"   # 0: zero_grad() memsets the whole gradient arena
 
 
 class ParamArena:
@@ -62,6 +63,12 @@ class ParamArena:
             self.index[id(p)] = i
         self.unused = [i for i, p in enumerate(self.params) if getattr(p, "_ecamp_unused", False)]
         self.on_ready = None  # callback(list of slot ids) set by the data-parallel reducer
+        # Lazy zero_grad: a weight matrix whose gradient is produced by ONE weight-gradient GEMM per backward pass is never zeroed --
+        # the first GEMM after zero_grad() OVERWRITES it (no 733 MB memset, no read of the zeros); everything else (biases, LayerNorm,
+        # embeddings, tokens: kernels add into them with atomics) is zeroed by one table-driven kernel.
+        self._gemm_written = set()   # slots seen in gradw(): learnt from the backward passes actually run
+        self._fresh = set()          # of those, the ones not yet written since the last zero_grad()
+        self._zero_flags = None      # uint8 per 64-element block: 1 = zero me in zero_grad(); rebuilt when _gemm_written grows
         self.version = 0      # bumped whenever the values the kernels read change (optimizer step, sync_shadow)
         self._w8 = {}         # slot -> (version, e4m3 copy, scale): the fp8-forward mode's weights, re-quantised once per step
         self.sync_shadow()
@@ -79,6 +86,33 @@ class ParamArena:
         i = self.index[id(p)]
         o, n = self.offsets[i], self.sizes[i]
         return self.flat_p16[o:o + n].view(p.shape)
+
+    def gradw(self, ps, shape=None):
+        """(gradient view, accumulate flag) for the weight-gradient GEMM of parameter `ps` (or of a list of adjacent parameters
+        computed as ONE GEMM, viewed as `shape`): accumulate is False for the first GEMM after zero_grad()."""
+        plist = list(ps) if isinstance(ps, (list, tuple)) else [ps]
+        slots = [self.index[id(p)] for p in plist]
+        view = self.fused_grad(plist, shape) if len(plist) > 1 else (self.grad(plist[0]) if shape is None else self.grad(plist[0]).view(shape))
+        new = [i for i in slots if i not in self._gemm_written]
+        if new:
+            self._gemm_written.update(new)   # still zeroed by the last zero_grad(): accumulate this time, overwrite from now on
+            self._zero_flags = None
+        fresh = [i in self._fresh for i in slots]
+        if all(fresh):
+            self._fresh.difference_update(slots)
+            return view, False
+        if any(fresh):   # a fused group written partly: make the rest zero first (not on the hot path)
+            self.flush_fresh(slots)
+        return view, True
+
+    def flush_fresh(self, slots=None):
+        """Zero the gradients of overwrite-mode weights that NO GEMM has written since zero_grad() (a module that did not run this
+        step): called before anything consumes the gradient arena as a whole (grad-norm, all-reduce finalisation, optimizer)."""
+        todo = [i for i in (self._fresh if slots is None else slots) if i in self._fresh]
+        for i in todo:
+            o, n = self.offsets[i], self.sizes[i]
+            ops.zero_(self.flat_g[o:o + n])
+        self._fresh.difference_update(todo)
 
     def w8(self, p):
         """(uint8 e4m3 copy of parameter p, f32[1] scale) for the fp8 forward GEMMs (configs[4]); quantised from the bf16 shadow
@@ -119,7 +153,21 @@ class ParamArena:
         self.version += 1
 
     def zero_grad(self):
-        ops.zero_(self.flat_g)
+        if not self._gemm_written or not LAZY_ZERO:
+            ops.zero_(self.flat_g)
+            self._fresh.clear()
+            return
+        if self._zero_flags is None:
+            flags = torch.ones(self.total // ALIGN, dtype=torch.uint8)
+            for i in self._gemm_written:
+                o, n = self.offsets[i], self.sizes[i]
+                flags[o // ALIGN:(o + n + ALIGN - 1) // ALIGN] = 0
+            for i in self.unused:        # never written by anything: must read as zero
+                o, n = self.offsets[i], self.sizes[i]
+                flags[o // ALIGN:(o + n + ALIGN - 1) // ALIGN] = 1
+            self._zero_flags = flags.to(self.device)
+        ops.zero_blocks_(self.flat_g, self._zero_flags)
+        self._fresh = set(self._gemm_written) - set(self.unused)
 
     def attach_grads(self):
         """Re-point p.grad at the arena if someone set it to None (stock optimizers' zero_grad(set_to_none=True))."""

@@ -55,6 +55,22 @@ extern "C" int ecamp_zero(void* p, int64_t bytes, hipStream_t stream) {
     return 0;
 }
 
+// Zero only the 64-element blocks whose flag is set (the gradient arena's small tensors -- biases, LayerNorm, embeddings, tokens --
+// that kernels ACCUMULATE into with atomics; weight matrices are overwritten by their weight-gradient GEMM instead).
+__global__ __launch_bounds__(256) void zero_blocks_kernel(float* __restrict__ g, const unsigned char* __restrict__ flags, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        if (flags[i >> 4]) *reinterpret_cast<float4*>(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+extern "C" int ecamp_zero_blocks(float* g, const uint8_t* block_flags, int64_t n, hipStream_t stream) {
+    ECAMP_CHECK_ARG(g && block_flags && n > 0 && n % 64 == 0, "ecamp_zero_blocks: bad args");
+    const long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(zero_blocks_kernel, dim3(nb), dim3(256), 0, stream, g, block_flags, n4);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[n] += alpha * sum_{m in rows selected} X[m*ld + n].   Row selection: all rows, or with period `per`
 // only rows with (m % per) >= skip_lo  ("skip the cls row of every sample"), or only rows (m % per) < only_hi.

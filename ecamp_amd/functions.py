@@ -26,6 +26,14 @@ def _none(n):
     return (None,) * n
 
 
+def _wgrad(A, dy, x, w, gb=None, alpha_dev=None, shape=None):
+    """Weight gradient of one nn.Linear (or of adjacent ones run as a single GEMM) on the side stream: dW (+)= dy^T x straight into
+    the gradient arena -- overwriting on the first backward after zero_grad(), accumulating afterwards (ParamArena.gradw) -- and
+    db += column sums of dy inside the same GEMM."""
+    gw, acc = A.gradw(w, shape)
+    ops.linear_wgrad_async(dy, x, gw, alpha_dev=alpha_dev, gb=gb, accumulate=acc)
+
+
 def _vit_linear(m, x, lin, **kw):
     """Forward of a timm Attention.qkv / proj or Mlp.fc1 / fc2 layer: bf16 GEMM, or -- model.fp8_forward, BASELINE configs[4] --
     the e4m3 GEMM on per-tensor-quantised copies of x and the weight.  The backward is the bf16 one either way."""
@@ -64,7 +72,7 @@ class StemFn(torch.autograd.Function):
         m, A, Tt = ctx.m, ctx.m.arena, ctx.Lk + 1
         dx = dx.contiguous()
         pe = m.patch_embed.proj
-        ops.linear_wgrad_async(dx, ctx.cols, A.grad(pe.weight).view(m.embed_dim, -1))
+        _wgrad(A, dx, ctx.cols, pe.weight, shape=(m.embed_dim, -1))
         ops.colsum(dx, A.grad(pe.bias), period=Tt, lo=1, hi=Tt)  # cls rows carry no patch: excluded from the bias gradient
         ops.colsum(dx, A.grad(m.cls_token).view(-1), period=Tt, lo=0, hi=1)
         A.ready(pe.weight, pe.bias, m.cls_token)
@@ -102,20 +110,20 @@ class VitBlockFn(torch.autograd.Function):
         hd = D // heads
         dx2 = dx2.contiguous()
         fc1, fc2, proj, qk = blk.mlp.fc1, blk.mlp.fc2, blk.attn.proj, blk.attn.qkv
-        ops.linear_wgrad_async(dx2, u, G(fc2.weight), gb=G(fc2.bias))
+        _wgrad(A, dx2, u, fc2.weight, gb=G(fc2.bias))
         dpre = ops.linear_dgrad(dx2, A.w(fc2.weight), gmul=pre)
-        ops.linear_wgrad_async(dpre, h2, G(fc1.weight), gb=G(fc1.bias))
+        _wgrad(A, dpre, h2, fc1.weight, gb=G(fc1.bias))
         dh2 = ops.linear_dgrad(dpre, A.w(fc1.weight))
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), dres=dx2)
         A.ready(fc2.weight, fc2.bias, fc1.weight, fc1.bias, blk.norm2.weight, blk.norm2.bias)
-        ops.linear_wgrad_async(dx1, a, G(proj.weight), gb=G(proj.bias))
+        _wgrad(A, dx1, a, proj.weight, gb=G(proj.bias))
         da = ops.linear_dgrad(dx1, A.w(proj.weight))
         dqkv = torch.empty_like(qkv)
         st = (T * 3 * D, 3 * D, hd)
         f, df = qkv.view(-1), dqkv.view(-1)
         ops.attn_bwd(f, f[D:], f[2 * D:], a.view(B, T, D), da.view(B, T, D), lse, df, df[D:], df[2 * D:], B, heads, T, T, hd,
                      st, st, st, st, st, st, hd ** -0.5)
-        ops.linear_wgrad_async(dqkv, h, G(qk.weight), gb=G(qk.bias))
+        _wgrad(A, dqkv, h, qk.weight, gb=G(qk.bias))
         dh = ops.linear_dgrad(dqkv, A.w(qk.weight))
         dx = ops.layernorm_bwd(dh, x, mean1, rstd1, blk.norm1.weight.data, G(blk.norm1.weight), G(blk.norm1.bias), dres=dx1)
         A.ready(proj.weight, proj.bias, qk.weight, qk.bias, blk.norm1.weight, blk.norm1.bias)
@@ -161,7 +169,7 @@ class DecStemFn(torch.autograd.Function):
         L, Dd = m.num_patches, m.decoder_embed_dim
         dy = ops.unshuffle_bwd(dxd.contiguous(), ids_restore, ids_keep, G(m.mask_token).view(-1), B, L, Lk, Dd).view(-1, Dd)
         de = m.decoder_embed
-        ops.linear_wgrad_async(dy, latent, G(de.weight), gb=G(de.bias))
+        _wgrad(A, dy, latent, de.weight, gb=G(de.bias))
         dlat = ops.linear_dgrad(dy, A.w(de.weight))
         A.ready(de.weight, de.bias, m.mask_token)
         ctx.s = None
@@ -182,7 +190,7 @@ def _dec_head_bwd(m, rec, dpred):
     A = m.arena
     G = A.grad
     dp, ln = m.decoder_pred, m.decoder_norm
-    ops.linear_wgrad_async(dpred, h, G(dp.weight), gb=G(dp.bias))
+    _wgrad(A, dpred, h, dp.weight, gb=G(dp.bias))
     dh = ops.linear_dgrad(dpred, A.w(dp.weight))
     dxd = ops.layernorm_bwd(dh, xd, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
     A.ready(dp.weight, dp.bias, ln.weight, ln.bias)
@@ -295,7 +303,7 @@ class ReportStemFn(torch.autograd.Function):
         G = A.grad
         dlat = dlat.contiguous()
         ops.seq_bcast(dgap.contiguous(), dlat.view(B, T, H), 1, T, 1.0 / (T - 1), 1)  # in place: we are dlat's only consumer
-        ops.linear_wgrad_async(dlat, latent, G(m.bert_mlp.weight), gb=G(m.bert_mlp.bias))
+        _wgrad(A, dlat, latent, m.bert_mlp.weight, gb=G(m.bert_mlp.bias))
         dl = ops.linear_dgrad(dlat, A.w(m.bert_mlp.weight))
         A.ready(m.bert_mlp.weight, m.bert_mlp.bias)
         ctx.s = None
@@ -371,7 +379,7 @@ def _self_attn_bwd(m, rec, dout, B, S, key_mask, pa, ph):
         dz, dy = ops.layernorm_bwd(dout, z, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias), drop_p=ph, seed=s2, offset=o2, want_drop=True)
     else:
         dz = dy = ops.layernorm_bwd(dout, z, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
-    ops.linear_wgrad_async(dy, a, G(out.dense.weight), gb=G(out.dense.bias))
+    _wgrad(A, dy, a, out.dense.weight, gb=G(out.dense.bias))
     da = ops.linear_dgrad(dy, A.w(out.dense.weight))
     dqkv = torch.empty_like(qkv)
     st = (S * 3 * H, 3 * H, hd)
@@ -379,7 +387,7 @@ def _self_attn_bwd(m, rec, dout, B, S, key_mask, pa, ph):
     ops.attn_bwd(f, f[H:], f[2 * H:], a.view(B, S, H), da.view(B, S, H), lse, df, df[H:], df[2 * H:], B, heads, S, S, hd, st, st, st,
                  st, st, st, 1.0 / math.sqrt(hd), key_mask, pa, s1, o1)
     qkvp = _qkv_params(att)
-    ops.linear_wgrad_async(dqkv, h, A.fused_grad([l.weight for l in qkvp], (3 * H, H)), gb=A.fused_grad([l.bias for l in qkvp], (3 * H,)))
+    _wgrad(A, dqkv, h, [l.weight for l in qkvp], shape=(3 * H, H), gb=A.fused_grad([l.bias for l in qkvp], (3 * H,)))
     dh = ops.linear_dgrad(dqkv, A.fused_w([l.weight for l in qkvp], (3 * H, H)), residual=dz)
     A.ready(ln.weight, ln.bias, out.dense.weight, out.dense.bias, *[l.weight for l in qkvp], *[l.bias for l in qkvp])
     return dh
@@ -406,9 +414,9 @@ def _ffn_bwd(m, rec, dout, ph):
         dz, dy = ops.layernorm_bwd(dout, z, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias), drop_p=ph, seed=s, offset=o, want_drop=True)
     else:
         dz = dy = ops.layernorm_bwd(dout, z, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
-    ops.linear_wgrad_async(dy, u, G(out.dense.weight), gb=G(out.dense.bias))
+    _wgrad(A, dy, u, out.dense.weight, gb=G(out.dense.bias))
     dpre = ops.linear_dgrad(dy, A.w(out.dense.weight), gmul=pre)
-    ops.linear_wgrad_async(dpre, x, G(inter.dense.weight), gb=G(inter.dense.bias))
+    _wgrad(A, dpre, x, inter.dense.weight, gb=G(inter.dense.bias))
     dx = ops.linear_dgrad(dpre, A.w(inter.dense.weight), residual=dz)
     A.ready(ln.weight, ln.bias, out.dense.weight, out.dense.bias, inter.dense.weight, inter.dense.bias)
     return dx
@@ -479,11 +487,11 @@ class FusionFn(torch.autograd.Function):
             dz, dy = ops.layernorm_bwd(da2, z, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias), drop_p=ph, seed=s2, offset=o2, want_drop=True)
         else:
             dz = dy = ops.layernorm_bwd(da2, z, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
-        ops.linear_wgrad_async(dy, c2, G(ol.dense.weight), gb=G(ol.dense.bias))
+        _wgrad(A, dy, c2, ol.dense.weight, gb=G(ol.dense.bias))
         dc2 = ops.linear_dgrad(dy, A.w(ol.dense.weight))                       # [B*S, H] == d c (broadcast add passes through)
         dgp = ops.seq_sum(dc2.view(B, S, H), 0, S, 1.0)                          # [B, H]
         gm = fl.gap_mlp
-        ops.linear_wgrad_async(dgp, gap, G(gm.weight), gb=G(gm.bias))
+        _wgrad(A, dgp, gap, gm.weight, gb=G(gm.bias))
         dgap = ops.linear_dgrad(dgp, A.w(gm.weight))
         ca = fl.cross_self_attention
         dq = torch.empty_like(q)
@@ -492,9 +500,9 @@ class FusionFn(torch.autograd.Function):
         qs, ks = (S * H, H, hd), (T * 2 * H, 2 * H, hd)
         ops.attn_bwd(q, f[2 * H:], f[3 * H:], c, dc2.view(B, S, H), lse, dq, df[2 * H:], df[3 * H:], B, heads, S, T - 1, hd, qs, ks, ks,
                      qs, ks, ks, 1.0 / math.sqrt(hd), None, pa, s1, o1)
-        ops.linear_wgrad_async(dkv, lat, A.fused_grad([ca.key.weight, ca.value.weight], (2 * H, H)), gb=A.fused_grad([ca.key.bias, ca.value.bias], (2 * H,)))
+        _wgrad(A, dkv, lat, [ca.key.weight, ca.value.weight], shape=(2 * H, H), gb=A.fused_grad([ca.key.bias, ca.value.bias], (2 * H,)))
         dlat = ops.linear_dgrad(dkv, A.fused_w([ca.key.weight, ca.value.weight], (2 * H, H)))
-        ops.linear_wgrad_async(dq, a1, G(ca.query.weight), gb=G(ca.query.bias))
+        _wgrad(A, dq, a1, ca.query.weight, gb=G(ca.query.bias))
         da1 = ops.linear_dgrad(dq, A.w(ca.query.weight), residual=dz)
         A.ready(ln.weight, ln.bias, ol.dense.weight, ol.dense.bias, gm.weight, gm.bias, ca.query.weight, ca.query.bias,
                 ca.key.weight, ca.key.bias, ca.value.weight, ca.value.bias)
@@ -530,7 +538,7 @@ class MlmHeadFn(torch.autograd.Function):
         G = A.grad
         pr = cls.predictions
         g = g.contiguous()
-        ops.linear_wgrad_async(dlog, t, G(pr.decoder.weight), alpha_dev=g, gb=G(pr.bias))
+        _wgrad(A, dlog, t, pr.decoder.weight, alpha_dev=g, gb=G(pr.bias))
         dt = ops.linear_dgrad(dlog, A.w(pr.decoder.weight), alpha_dev=g)
         ln = pr.transform.LayerNorm
         dt1 = ops.layernorm_bwd(dt, t1, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
@@ -538,7 +546,7 @@ class MlmHeadFn(torch.autograd.Function):
         # fold it into the transform.dense backward: d pre = dt1 * gelu'(pre)
         dpre = ops.mul_gelu_grad(dt1, pre)
         td = pr.transform.dense
-        ops.linear_wgrad_async(dpre, h, G(td.weight), gb=G(td.bias))
+        _wgrad(A, dpre, h, td.weight, gb=G(td.bias))
         dh = ops.linear_dgrad(dpre, A.w(td.weight))
         A.ready(pr.decoder.weight, pr.bias, ln.weight, ln.bias, td.weight, td.bias)
         ctx.s = None

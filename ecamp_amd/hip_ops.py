@@ -115,13 +115,13 @@ def _split_k(n_out, k_in, m, dtype=torch.bfloat16):
     return s
 
 
-def linear_wgrad(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None):
-    """gw[N,K] (f32, accumulated) += alpha * dy[M,N]^T @ x[M,K];  gb[N] (f32, accumulated) += alpha * sum_m dy[m,:] if given."""
+def linear_wgrad(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None, accumulate=True):
+    """gw[N,K] (f32) += (accumulate) or = alpha * dy[M,N]^T @ x[M,K];  gb[N] (f32, always accumulated) += alpha * sum_m dy[m,:] if given."""
     M, N = dy.shape
     K = x.shape[1]
     assert gw.dtype == torch.float32 and gw.is_contiguous() and gw.numel() == N * K
-    gemm(dy, x, gw, N, K, M, False, dy.stride(0), False, x.stride(0), K, alpha=alpha, alpha_dev=alpha_dev, out_f32=True, accumulate=True,
-         split_k=_split_k(N, K, M, dy.dtype), rowsum=gb)
+    gemm(dy, x, gw, N, K, M, False, dy.stride(0), False, x.stride(0), K, alpha=alpha, alpha_dev=alpha_dev, out_f32=True,
+         accumulate=bool(accumulate), split_k=_split_k(N, K, M, dy.dtype), rowsum=gb)
 
 
 def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):
@@ -210,6 +210,12 @@ def cast(src, dst):
     _chk(src, dst)
     call("ecamp_cast", ptr(src), ptr(dst), src.numel(), code(src.dtype), code(dst.dtype), stream())
     return dst
+
+
+def zero_blocks_(g, flags):
+    """Zero the 64-element blocks of the f32 arena `g` whose byte in `flags` (uint8, len = g.numel() / 64) is non-zero."""
+    _chk(g, flags)
+    call("ecamp_zero_blocks", ptr(g), ptr(flags), g.numel(), stream())
 
 
 def zero_(t):
@@ -396,13 +402,13 @@ def _join_side():
     _side["cb"] = False
 
 
-def linear_wgrad_async(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None):
+def linear_wgrad_async(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None, accumulate=True):
     if not OVERLAP_WGRAD:
-        return linear_wgrad(dy, x, gw, alpha, alpha_dev, gb)
+        return linear_wgrad(dy, x, gw, alpha, alpha_dev, gb, accumulate)
     st = side_stream(dy.device)
     st.wait_stream(torch.cuda.current_stream())  # dy, x (and earlier accumulations into gw) are ready
     with torch.cuda.stream(st):
-        linear_wgrad(dy, x, gw, alpha, alpha_dev, gb)
+        linear_wgrad(dy, x, gw, alpha, alpha_dev, gb, accumulate)
     dy.record_stream(st)  # the caching allocator must not recycle these while the side stream reads them
     x.record_stream(st)
     if alpha_dev is not None:

@@ -70,6 +70,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None, grad_sumsq=None):
         loss = closure() if closure is not None else None
         A = self._bind()
+        A.flush_fresh()
         self._step += 1
         g0 = self.param_groups[0]
         ops.adamw_grouped(A.flat_p, A.flat_g, self._m, self._v, A.flat_p16, self._table, [g["lr"] for g in self.param_groups],
@@ -95,8 +96,16 @@ class FusedAdamW(torch.optim.Optimizer):
         return s.sqrt().reshape(())
 
     def zero_grad(self, set_to_none=False):
-        """One memset of the gradient arena; p.grad stay views of it (set_to_none would detach them)."""
+        """p.grad stay views of the gradient arena (set_to_none would detach them).  After the first step this is LAZY for weight
+        matrices: biases / LayerNorm / embedding gradients are zeroed now, a weight matrix keeps its old values until the next
+        backward pass OVERWRITES it (its first weight-gradient GEMM runs with beta = 0), or until `flush_grads()` / `step()` find
+        it untouched and zero it.  Read p.grad after backward, not between zero_grad() and backward.  ECAMP_LAZY_ZERO_GRAD=0 restores
+        the plain memset."""
         self._bind().zero_grad()
+
+    def flush_grads(self):
+        """Make every p.grad consistent (zero the weight gradients no GEMM has written since zero_grad())."""
+        self._bind().flush_fresh()
 
     # -- checkpoint format compatible with torch.optim.AdamW (misc.py:295-338) ---------------------------------
     def state_dict(self):

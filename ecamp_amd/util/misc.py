@@ -240,6 +240,7 @@ def get_grad_norm_(parameters, norm_type=2.0):
         arena = getattr(parameters[0], "_ecamp_arena", None)
         if arena is not None and all(getattr(p, "_ecamp_arena", None) is arena for p in parameters) and len(parameters) == len(arena.params):
             from .. import hip_ops as ops
+            arena.flush_fresh()
             s = ops.zeros((1,), arena.device)
             ops.sumsq(arena.flat_g, s)
             return s.sqrt().reshape(())
@@ -264,6 +265,8 @@ class NativeScalerWithGradNormCount:
         loss.backward(create_graph=create_graph)
         if not update_grad:
             return None
+        if hasattr(optimizer, "flush_grads"):
+            optimizer.flush_grads()  # weights no GEMM wrote this window read as zero (lazy zero_grad)
         reducer = getattr(optimizer, "_ecamp_reducer", None)
         if reducer is not None:
             reducer.finalize()  # all gradient buckets reduced before anyone reads them

@@ -151,6 +151,10 @@ int ecamp_ce_fwd_bwd(void* logits, const int64_t* labels, const float* weights, 
                      float inv_count, int32_t dtype, ecampStream_t stream); /* bert_modeling.py:213-217 */
 
 /* ---- optimizer side ---- */
+/* optimizer.zero_grad() (main_pretrain.py:169) without touching the weight matrices: zero the 64-element blocks of the gradient arena
+ * whose flag byte is non-zero (n = arena length, a multiple of 64).  The weight-gradient GEMMs of the next backward pass overwrite
+ * their outputs (ecamp_gemm accumulate = 0) instead of adding to a zeroed buffer. */
+int ecamp_zero_blocks(float* g, const uint8_t* block_flags, int64_t n, ecampStream_t stream);
 int ecamp_sumsq(const float* x, int64_t n, float* out, ecampStream_t stream); /* util/misc.py:280-292 */
 int ecamp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int64_t step, float grad_scale,

@@ -149,3 +149,64 @@ def test_bench_prints_one_contract_line(dev):
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "cpu_baseline" not in r
+
+
+def test_lazy_zero_grad_matches_memset_and_flushes_unwritten_weights(dev):
+    """FusedAdamW.zero_grad() zeroes only the atomically-accumulated gradients; weight matrices are overwritten by the first
+    weight-gradient GEMM of the next backward.  (1) with accum_iter=2, the gradients after the overwriting micro-step and after the
+    accumulating one, and the gradient norm, equal the eager memset path (to the run-to-run noise of the atomic sums); (2) a weight
+    whose module did not run in a window reads as zero once flushed."""
+    import ecamp_amd.arena as arena_mod
+    from ecamp_amd import optim
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.util.misc import NativeScalerWithGradNormCount
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    cfg = orc.cfg_tiny()
+    state = recipe.recipe_state(cfg, seed=0)
+    batches = [recipe.recipe_batch(cfg, 4, 128, seed=s) for s in range(2)]
+    noise = recipe.recipe_noise(4, cfg.num_patches, seed=0)
+    out = {}
+    for lazy in (True, False):
+        arena_mod.LAZY_ZERO = lazy
+        torch.manual_seed(0)
+        model = me.ecamp_tiny(compute_dtype=torch.bfloat16)
+        model.load_state_dict(state, strict=True)
+        model.to(dev).eval()
+        model.prepare()
+        opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-3, betas=(0.9, 0.95))
+        scaler = NativeScalerWithGradNormCount()
+        opt.zero_grad()
+        snaps = []
+        for it in range(3):
+            mim, res, mlm = model(batches[it % 2], mask_ratio=0.75, noise=noise)
+            ((mim + res + mlm) / 2).backward()
+            if it == 0:     # the first backward teaches the arena which weights are GEMM-written; no parameter update in this test,
+                opt.zero_grad()   # so both modes see identical activations: this zero_grad() is the first lazy one
+                continue
+            opt.flush_grads()     # it = 1 overwrites, it = 2 accumulates
+            snaps.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+        from ecamp_amd.util import misc
+        out[lazy] = (snaps, misc.get_grad_norm_(model.parameters()).item())
+        if lazy:
+            A = model.arena
+            assert len(A._gemm_written) > 50 and A._zero_flags is not None
+            assert int(A._zero_flags.sum().item()) < A._zero_flags.numel() // 3   # the scatter-added word-embedding table is most of the rest
+            # (2) a window in which the report side does not run: its weights keep old values until flushed, then read zero
+            opt.zero_grad()
+            lat, mask, ids_restore, ids_keep = model.image_encoder(orc.bicubic_resize(batches[0]["image"], cfg.img_size), 0.75, noise=noise)
+            lat.float().sum().backward()
+            w = model.bert_encoder.model.bert.encoder.layer[0].output.dense.weight
+            opt.flush_grads()
+            assert w.grad.abs().max().item() == 0.0
+            assert model.blocks[0].mlp.fc1.weight.grad.abs().max().item() > 0.0
+    arena_mod.LAZY_ZERO = True
+    assert abs(out[True][1] - out[False][1]) <= 1e-4 * out[False][1], (out[True][1], out[False][1])
+    for a, b in zip(out[True][0], out[False][0]):
+        for k, g in a.items():
+            if k.endswith("key.bias"):      # true gradient is zero (softmax shift invariance): only rounding noise lives there
+                continue
+            if g.dim() == 2 and k.endswith(".weight") and "embeddings" not in k:
+                assert torch.equal(g, b[k]), k          # deterministic GEMMs on identical activations: bit for bit
+            else:                                       # tokens, biases, LayerNorm, embedding rows: atomic sums, order varies
+                assert (g - b[k]).abs().max().item() <= 5e-3 * b[k].abs().max().item() + 1e-9, k
