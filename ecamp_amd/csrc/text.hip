@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(T* __restrict__ logits,
     }
     // block combine of (max, sum)
     float wm = wave_max(mx);
-    sm *= __expf(mx - wm);
+    sm = mx == -INFINITY ? 0.f : sm * __expf(mx - wm);   // a lane (or a whole wave) without elements: exp(-inf + inf) would be NaN
     sm = wave_sum(sm);
     if ((threadIdx.x & 63) == 0) {
         shm_[threadIdx.x >> 6] = wm;
@@ -263,8 +263,9 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(T* __restrict__ logits,
     }
     __syncthreads();
     float gmx = fmaxf(fmaxf(shm_[0], shm_[1]), fmaxf(shm_[2], shm_[3]));
-    float gsm = shm_[4] * __expf(shm_[0] - gmx) + shm_[5] * __expf(shm_[1] - gmx) + shm_[6] * __expf(shm_[2] - gmx) +
-                shm_[7] * __expf(shm_[3] - gmx);
+    float gsm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gsm += shm_[k] == -INFINITY ? 0.f : shm_[4 + k] * __expf(shm_[k] - gmx);
     const long label = labels[row];
     const float w = weights[row];
     if (threadIdx.x == 0) {
@@ -284,10 +285,88 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(T* __restrict__ logits,
         st4<T>(x + c * 4, p);
     }
 }
+// bf16 rows of up to 32768 logits: the row is read ONCE into registers (16 B per lane per load, NG loads per thread) and the
+// gradient is written from them -- the two-pass kernel above reads every logit twice (2 GB per pass at B*S = 32768, V = 30000).
+template <int NG>
+__global__ __launch_bounds__(256) void ce_fwd_bwd_reg_kernel(bf16_t* __restrict__ logits, const long* __restrict__ labels,
+                                                             const float* __restrict__ weights, float* __restrict__ loss_sum, int V,
+                                                             long ld, float inv_count) {
+    __shared__ float shm_[8];
+    const long row = blockIdx.x;
+    bf16_t* x = logits + row * ld;
+    const int nv8 = V >> 3;
+    uint4 q[NG];
+    float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nv8) {
+            q[j] = *reinterpret_cast<const uint4*>(x + c * 8);
+            const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+            float p[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[2 * r] = __uint_as_float(w[r] << 16);
+                p[2 * r + 1] = __uint_as_float(w[r] & 0xffff0000u);
+            }
+            const float m8 = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+            if (m8 > mx) {
+                sm *= __expf(mx - m8);
+                mx = m8;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sm += __expf(p[r] - mx);
+        }
+    }
+    float wm = wave_max(mx);
+    sm = mx == -INFINITY ? 0.f : sm * __expf(mx - wm);   // a lane (or a whole wave) without elements: exp(-inf + inf) would be NaN
+    sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) {
+        shm_[threadIdx.x >> 6] = wm;
+        shm_[4 + (threadIdx.x >> 6)] = sm;
+    }
+    __syncthreads();
+    const float gmx = fmaxf(fmaxf(shm_[0], shm_[1]), fmaxf(shm_[2], shm_[3]));
+    float gsm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gsm += shm_[k] == -INFINITY ? 0.f : shm_[4 + k] * __expf(shm_[k] - gmx);
+    const long label = labels[row];
+    const float w = weights[row];
+    if (threadIdx.x == 0) {
+        float lse = gmx + __logf(gsm);
+        atomicAdd(loss_sum, w * (lse - to_f<bf16_t>(x[label])));
+    }
+    const float inv = 1.0f / gsm, sc = w * inv_count;
+    __syncthreads();   // thread 0 has read x[label] before anyone overwrites it
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nv8) {
+            const uint32_t wq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+            float g[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                g[2 * r] = __uint_as_float(wq[r] << 16);
+                g[2 * r + 1] = __uint_as_float(wq[r] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) g[r] = sc * (__expf(g[r] - gmx) * inv - ((long)(c * 8 + r) == label ? 1.0f : 0.0f));
+            uint4 o;
+            o.x = pack_bf16x2(g[0], g[1]); o.y = pack_bf16x2(g[2], g[3]); o.z = pack_bf16x2(g[4], g[5]); o.w = pack_bf16x2(g[6], g[7]);
+            *reinterpret_cast<uint4*>(x + c * 8) = o;
+        }
+    }
+}
 extern "C" int ecamp_ce_fwd_bwd(void* logits, const int64_t* labels, const float* weights, float* loss_sum, int64_t M, int32_t V,
                                 int64_t ld, float inv_count, int32_t dtype, hipStream_t stream) {
     ECAMP_CHECK_ARG(logits && labels && weights && loss_sum && V % 4 == 0 && ld % 4 == 0, "ce_fwd_bwd: bad args");
     dim3 grid((unsigned)M), block(256);
+    if (dtype == ECAMP_BF16 && V % 8 == 0 && ld % 8 == 0 && V <= 32768 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        if (V <= 16384) hipLaunchKernelGGL(ce_fwd_bwd_reg_kernel<8>, grid, block, 0, stream, (bf16_t*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count);
+        else hipLaunchKernelGGL(ce_fwd_bwd_reg_kernel<16>, grid, block, 0, stream, (bf16_t*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count);
+        ECAMP_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == ECAMP_F32) hipLaunchKernelGGL(ce_fwd_bwd_kernel<float>, grid, block, 0, stream, (float*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count);
     else hipLaunchKernelGGL(ce_fwd_bwd_kernel<bf16_t>, grid, block, 0, stream, (bf16_t*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count);
     ECAMP_LAUNCH_CHECK();

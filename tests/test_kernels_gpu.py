@@ -446,7 +446,7 @@ def test_bert_embeddings(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,V", [(64, 30000), (33, 1000)])
+@pytest.mark.parametrize("M,V", [(64, 30000), (33, 1000), (7, 256), (5, 64), (3, 20000)])
 def test_weighted_cross_entropy(dev, dtype, M, V):
     o = ops()
     logits = rnd(gen(M, V, seed=1) * 3, dtype)

@@ -39,3 +39,11 @@ ty = torch.zeros(Bt, S, dtype=torch.int64, device=dev)
 gw = torch.zeros(30000, H, device=dev); gp = torch.zeros(512, H, device=dev); gt = torch.zeros(2, H, device=dev); gg = torch.zeros(H, device=dev); gb = torch.zeros(H, device=dev)
 t = timeit(lambda: o.bert_embed_bwd(de, z, mean, rstd, gamma, ids, ty, gw, gp, gt, gg, gb, Bt, S, H))
 print("report embedding backward   %7.1f us  %6.0f GB/s" % (t, (de.numel() * 4 + de.numel() * 4) / t / 1e3))
+# vocabulary cross-entropy, forward + gradient in place over the bf16 logits
+M, V = 32768, 30000
+logits = torch.randn(M, V, device=dev).bfloat16(); labels = torch.randint(0, V, (M,), device=dev); wts = torch.ones(M, device=dev); ls = o.zeros((1,), dev)
+src = logits.clone()
+def ce():
+    logits.copy_(src); o.ce_fwd_bwd_(logits, labels, wts, ls)
+tc = timeit(lambda: logits.copy_(src)); t = timeit(ce) - tc
+print("weighted CE fwd+bwd (in place) %6.1f us  %6.0f GB/s (one read + one write of %d MB)" % (t, 2 * logits.numel() * 2 / t / 1e3, logits.numel() * 2 / 1e6))
