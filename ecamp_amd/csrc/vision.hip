@@ -925,6 +925,11 @@ __global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __res
 __device__ __forceinline__ float sr_ch(const unsigned char* tile, int pix, int c) {   // channel c of interleaved pixel `pix` as f32
     return __uint_as_float((uint32_t)(*reinterpret_cast<const unsigned short*>(tile + pix * 8 + c * 2)) << 16);
 }
+__device__ __forceinline__ void sr_unpack3(uint2 q, float (&v)[3]) {   // the three channels of an interleaved bf16 pixel as f32
+    v[0] = __uint_as_float(q.x << 16);
+    v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16);
+}
 __global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
                                                              const long* __restrict__ column, const long* __restrict__ row, SrP P,
                                                              float* __restrict__ dsr, float* __restrict__ gw, long B, int R, int win) {
@@ -955,20 +960,23 @@ __global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __rest
     const float b1[3] = {P.b1[0], P.b1[1], P.b1[2]}, b2[3] = {P.b2[0], P.b2[1], P.b2[2]};
     const int R2 = 2 * R, G = R2 / SRT, PT = SRT / 2;
     const long T = B * G * G;
-    const int tap0 = wave * 7, ntap = wave == 3 ? 6 : 7;
-    int off1[7], off2[7];   // byte offsets of tap (i,ky,kx) in the interleaved U / C1 tiles
+    // weight gradients: a wave owns 2-3 of the 9 stencil positions q = ky*3+kx with all 3 input channels of each, so that one 8-B
+    // LDS read (an interleaved pixel) feeds 3 taps x 3 outputs (per-tap 2-B reads made this stage a third of the kernel)
+    const int q0 = wave == 0 ? 0 : 1 + 2 * wave, npos = wave == 0 ? 3 : 2;
+    int offu[3], offc[3];   // byte offsets of position q0+k relative to the tap-(0,0) pixel in the U (42-wide) / C1 (40-wide) tiles
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
-        int tap = min(tap0 + t, 26);
-        int i = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-        off1[t] = (ky * 42 + kx) * 8 + i * 2;
-        off2[t] = (ky * 40 + kx) * 8 + i * 2;
+    for (int k = 0; k < 3; ++k) {
+        const int q = min(q0 + k, 8), ky = q / 3, kx = q % 3;
+        offu[k] = (ky * 42 + kx) * 8;
+        offc[k] = (ky * 40 + kx) * 8;
     }
-    float g1[7][3], g2[7][3], bb1[3], bb2[3];
+    float g1[3][3][3], g2[3][3][3], bb1[3], bb2[3];   // [position][input channel][output channel]
 #pragma unroll
-    for (int t = 0; t < 7; ++t)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int o = 0; o < 3; ++o) g1[t][o] = g2[t][o] = 0.f;
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) g1[k][i][o] = g2[k][i][o] = 0.f;
 #pragma unroll
     for (int o = 0; o < 3; ++o) bb1[o] = bb2[o] = 0.f;
     const int py = threadIdx.x / PT, px = threadIdx.x % PT;  // this thread's pred_img pixel of a 16x16 tile
@@ -1114,25 +1122,28 @@ __global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __rest
         }
         __syncthreads();
         // (6) weight gradients over the 32x32 centre: conv2 from (ds, c1), conv1 from (dc1, u)
-#pragma unroll 4
+#pragma unroll 2
         for (int j = 0; j < 16; ++j) {
             const int idx = lane + 64 * j;
             const int y = idx >> 5, x = idx & 31;
-            const int pd2 = (y + 3) * 38 + x + 3, pd1 = (y + 2) * 36 + x + 2;
-            const float d2[3] = {sr_ch(DS16, pd2, 0), sr_ch(DS16, pd2, 1), sr_ch(DS16, pd2, 2)};
-            const float d1[3] = {sr_ch(DC16, pd1, 0), sr_ch(DC16, pd1, 1), sr_ch(DC16, pd1, 2)};
-            const unsigned char* c1p = C16 + ((y + 3) * 40 + x + 3) * 8;   // tap (ky,kx) reads centre + (ky-1, kx-1)
+            float d2[3], d1[3];
+            sr_unpack3(*reinterpret_cast<const uint2*>(DS16 + ((y + 3) * 38 + x + 3) * 8), d2);
+            sr_unpack3(*reinterpret_cast<const uint2*>(DC16 + ((y + 2) * 36 + x + 2) * 8), d1);
+            const unsigned char* c1p = C16 + ((y + 3) * 40 + x + 3) * 8;   // position (ky,kx) reads centre + (ky-1, kx-1)
             const unsigned char* up = U16 + ((y + 4) * 42 + x + 4) * 8;
 #pragma unroll
-            for (int tt = 0; tt < 7; ++tt) {
-                if (tt < ntap) {
-                    const float v2 = __uint_as_float((uint32_t)(*reinterpret_cast<const unsigned short*>(c1p + off2[tt])) << 16);
-                    const float v1 = __uint_as_float((uint32_t)(*reinterpret_cast<const unsigned short*>(up + off1[tt])) << 16);
+            for (int k = 0; k < 3; ++k) {
+                if (k < npos) {   // wave-uniform
+                    float v2[3], v1[3];
+                    sr_unpack3(*reinterpret_cast<const uint2*>(c1p + offc[k]), v2);
+                    sr_unpack3(*reinterpret_cast<const uint2*>(up + offu[k]), v1);
 #pragma unroll
-                    for (int o = 0; o < 3; ++o) {
-                        g2[tt][o] += d2[o] * v2;
-                        g1[tt][o] += d1[o] * v1;
-                    }
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) {
+                            g2[k][i][o] += d2[o] * v2[i];
+                            g1[k][i][o] += d1[o] * v1[i];
+                        }
                 }
             }
             if (wave == 3) {
@@ -1200,15 +1211,17 @@ __global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __rest
 #undef SR_TAPS
     // one cross-lane reduction per kernel: gw layout {dW1[81], db1[3], dW2[81], db2[3]}, dW[o][i][ky][kx] = index o*27 + tap
 #pragma unroll
-    for (int tt = 0; tt < 7; ++tt)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            float s1 = wave_sum(g1[tt][o]), s2 = wave_sum(g2[tt][o]);
-            if (lane == 0 && tt < ntap) {
-                atomicAdd(gw + o * 27 + tap0 + tt, s1);
-                atomicAdd(gw + 84 + o * 27 + tap0 + tt, s2);
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                float s1 = wave_sum(g1[k][i][o]), s2 = wave_sum(g2[k][i][o]);
+                if (lane == 0 && k < npos) {
+                    atomicAdd(gw + o * 27 + i * 9 + q0 + k, s1);
+                    atomicAdd(gw + 84 + o * 27 + i * 9 + q0 + k, s2);
+                }
             }
-        }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
         float s1 = wave_sum(bb1[o]), s2 = wave_sum(bb2[o]);
