@@ -922,9 +922,6 @@ __global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __res
 
 // backward on the matrix cores: the four stencils (conv1, conv2, conv2^T, conv1^T) as in sr_mfma_fwd_kernel; the weight-gradient
 // stage keeps the tap-split f32 accumulation of sr_fused_bwd_kernel, reading the bf16 tiles.  ds / dc1 are rounded to bf16.
-__device__ __forceinline__ float sr_ch(const unsigned char* tile, int pix, int c) {   // channel c of interleaved pixel `pix` as f32
-    return __uint_as_float((uint32_t)(*reinterpret_cast<const unsigned short*>(tile + pix * 8 + c * 2)) << 16);
-}
 __device__ __forceinline__ void sr_unpack3(uint2 q, float (&v)[3]) {   // the three channels of an interleaved bf16 pixel as f32
     v[0] = __uint_as_float(q.x << 16);
     v[1] = __uint_as_float(q.x & 0xffff0000u);
@@ -1093,9 +1090,11 @@ __global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __rest
                     const f32x4_t acc = sr_mfma_conv<40, false>(C16, y, x, a2);
                     float d[3] = {0.f, 0.f, 0.f};
                     if (inw[j]) {
+                        float uu[3];
+                        sr_unpack3(*reinterpret_cast<const uint2*>(U16 + ((y + 2) * 42 + x + 2) * 8), uu);
 #pragma unroll
                         for (int o = 0; o < 3; ++o) {
-                            float sv = fmaxf(acc[o] + b2[o] + sr_ch(U16, (y + 2) * 42 + x + 2, o), 0.f);
+                            float sv = fmaxf(acc[o] + b2[o] + uu[o], 0.f);
                             d[o] = sv > 0.f ? sv - bigv[j][o] : 0.f;
                         }
                     }
@@ -1114,9 +1113,10 @@ __global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __rest
                 const f32x4_t acc = sr_mfma_conv<38, true>(DS16, y, x, a2t);
                 const int Y = Y0 - 2 + y, X = X0 - 2 + x;
                 const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
-                float d[3];
+                float d[3], cc[3];
+                sr_unpack3(*reinterpret_cast<const uint2*>(C16 + ((y + 2) * 40 + x + 2) * 8), cc);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) d[i] = (in && sr_ch(C16, (y + 2) * 40 + x + 2, i) > 0.f) ? acc[i] : 0.f;
+                for (int i = 0; i < 3; ++i) d[i] = (in && cc[i] > 0.f) ? acc[i] : 0.f;
                 if (p < 36 * 36) *reinterpret_cast<bf16x4_t*>(DC16 + p * 8) = sr_pack4(d[0], d[1], d[2]);
             }
         }
@@ -1165,8 +1165,10 @@ __global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __rest
                 const int Y = Y0 - 1 + y, X = X0 - 1 + x;
                 const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
                 if (p < 34 * 34) {
+                    float dd[3];
+                    sr_unpack3(*reinterpret_cast<const uint2*>(DS16 + ((y + 2) * 38 + x + 2) * 8), dd);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) DU[(i * 34 + y) * 34 + x] = in ? acc[i] + sr_ch(DS16, (y + 2) * 38 + x + 2, i) : 0.f;
+                    for (int i = 0; i < 3; ++i) DU[(i * 34 + y) * 34 + x] = in ? acc[i] + dd[i] : 0.f;
                 }
             }
         }
