@@ -257,7 +257,7 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ 
         ld4<T>(dy + i * 4, p);
         ld4<T>(pre + i * 4, q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] *= gelu_grad_f(q[r]);
+        for (int r = 0; r < 4; ++r) p[r] *= gelu_grad_t<T>(q[r]);
         st4<T>(dx + i * 4, p);
     }
 }

@@ -68,13 +68,13 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n0, f32x
     if (g.pre_out) st4<T>(reinterpret_cast<T*>(g.pre_out) + (long)m * g.ldp + n0, v);
     if (g.act == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(g.pre_out ? rnd<T>(v[r]) : v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_t<T>(g.pre_out ? rnd<T>(v[r]) : v[r]);
     }
     if (g.gmul) {
         float p[4];
         ld4<T>(reinterpret_cast<const T*>(g.gmul) + (long)m * g.ldg + n0, p);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(p[r]);
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_t<T>(p[r]);
     }
     if (g.residual) {
         float p[4];
@@ -377,14 +377,14 @@ __device__ __forceinline__ void p8_epilogue_rows(const GemmArgs& g, const f32x4 
             if (g.pre_out) st8<bf16_t>(reinterpret_cast<bf16_t*>(g.pre_out) + (long)m * g.ldp + n, v);
             if (g.act == 1) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = gelu_f(g.pre_out ? rnd<bf16_t>(v[r]) : v[r]);
+                for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16_t>(g.pre_out ? rnd<bf16_t>(v[r]) : v[r]);
             }
             if (gm) {
                 const uint32_t w[4] = {qg[i][h].x, qg[i][h].y, qg[i][h].z, qg[i][h].w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[2 * r] *= gelu_grad_f(__uint_as_float(w[r] << 16));
-                    v[2 * r + 1] *= gelu_grad_f(__uint_as_float(w[r] & 0xffff0000u));
+                    v[2 * r] *= gelu_grad_t<bf16_t>(__uint_as_float(w[r] << 16));
+                    v[2 * r + 1] *= gelu_grad_t<bf16_t>(__uint_as_float(w[r] & 0xffff0000u));
                 }
             }
             if (rs) {
