@@ -1,25 +1,27 @@
 // "Q8": persistent 256x256x64 bf16 GEMM on v_mfma_f32_32x32x16_bf16, eight waves (2 x 4) of 128x64, one workgroup per CU.
 //
-// Structure (round 2; replaces the K=32 DMA-ring kernel "P8" for every form it is built for):
-//  * K tile = 64.  Each operand tile is two HALF-TILES of 128 rows (A_0/A_1: the rows of wave row 0/1; B_0/B_1: the columns of
-//    wave columns 0-1 / 2-3), 16 KB each, filled by direct L2->LDS DMA (global_load_lds_dwordx4: 2 pieces per wave per half-tile).
-//    Half-tiles live in two rings of NSLOT slots (NSLOT = 4: 128 KB, two K tiles; NSLOT = 5: all 160 KB, 2.5 K tiles).
-//  * A K tile is FOUR PHASES per wave, one 64x32 quadrant of the wave's 128x64 block each (8 MFMAs of 32x32x16 = 256 matrix
-//    cycles): quadrants (m0,n0) (m0,n1) (m1,n1) (m1,n0), so consecutive phases share one operand's fragments and a phase reads
-//    4, 8 or 12 ds_read_b128.  A phase is {fragment reads for this phase; one half-tile of DMA for a later K tile; s_barrier;
-//    8 MFMAs; s_barrier}.  Wave row 1 runs ONE BARRIER INTERVAL behind wave row 0: the two waves of a SIMD (w and w+4) are
-//    always in opposite halves of a phase -- one multiplies while the other reads LDS and issues DMA -- which is what keeps
-//    the matrix pipe fed without either wave having to overlap its own memory instructions with its own MFMAs.
-//  * DMA runs LEAD = NSLOT+1 half-tiles ahead of the phase that issues it and is only ever waited for with a counted
-//    s_waitcnt vmcnt(2*(LEAD-4)) once per K tile (phase 3), one full phase before the first read of that K tile.  The
-//    half-tile stream is ONE flat sequence over all the output tiles a workgroup processes, so the next tile's first K tiles
-//    are in LDS before the current tile's epilogue starts.  vmcnt retires in order on gfx9 (loads and stores share it), so
-//    a counted wait is never early; stores in the queue only make it conservative.
-//  * Epilogue in four pieces: quadrant q of an output tile is final after phase q of the tile's last K tile and is stored in
-//    the read half of the NEXT phase (the last one in the first phase of the following tile), so the stores of a tile are
-//    spread over four phases and no accumulator copy is needed.
+// Structure (round 2; replaces the K=32 DMA-ring kernel "P8" of round 1 wherever it applied):
+//  * K tile = 64, two K tiles resident in LDS (128 KB).  Each operand tile is two HALF-TILES of 128 rows (A_0/A_1: the rows of
+//    wave row 0/1; B_0/B_1: the columns of wave columns 0-1 / 2-3), 16 KB each, filled by direct L2->LDS DMA
+//    (buffer_load_dwordx4 ... lds: 8 instructions per wave per K tile) through per-half-tile buffer descriptors built with scalar
+//    ALU only: the per-lane offsets are kernel constants and rows / contraction steps past the end read as zero.
+//  * A K tile is FOUR STEPS per wave, one 64x32 quadrant of the wave's 128x64 block each: {4, 8 or 12 ds_read_b128; 8 MFMAs of
+//    32x32x16 = 256 matrix cycles}, quadrants (m0,n0) (m0,n1) (m1,n1) (m1,n0) so that consecutive steps share one operand.
+//  * ONE s_barrier per K tile.  Wave row 0 meets it after its last MFMA step, wave row 1 BEFORE its last MFMA step: after every
+//    barrier the two waves of a SIMD (w and w+4) start in opposite halves of a step -- one multiplies while the other reads LDS /
+//    issues DMA -- and nothing re-synchronises them inside the K tile, so the matrix pipe is handed back and forth by
+//    the hardware arbiter instead of by barriers (the first version had two barriers per step: 130 idle matrix cycles each).
+//  * The DMA of K tile t+1 is issued right after the barrier that retires K tile t-1 (whose slots it overwrites) and is waited for,
+//    with a counted s_waitcnt, just before the next barrier: a full K tile of latency cover.  The K-tile stream is ONE flat
+//    sequence over all the output tiles a workgroup processes, so the next tile's first K tile is in LDS before the current
+//    tile's epilogue starts.
+//  * Epilogue in four pieces: quadrant q of an output tile is final after step q of the tile's last K tile and is stored right
+//    after that step (the last one after the barrier, in the first K tile of the next output tile, whose MFMAs start from C = 0).
+//    The stores are buffer stores (bounds by descriptor, no exec-masked branches), so their COUNT is exact and the DMA wait
+//    can be "all but the n stores issued after the DMA": vmcnt retires in order on gfx9 and loads and stores share it -- a
+//    counted wait is never early, and with the DMA issued ahead of a K tile's stores it never waits for fresh stores either.
 //  * LDS images are DMA-linear (128-B rows, 8 rows per wave piece); the bank swizzle (16-B chunk ^ ((row >> 1) & 7)) is applied
-//    to the lane's SOURCE address and again on the fragment reads (conflict-free for the 32-row b128 fragments, both row maps).
+//    to the lane's SOURCE offset and again on the fragment reads (conflict-free for the 32-row b128 fragments, both row maps).
 //  * N-side fragment row i is mapped to tile column (i&3) | i3<<2 | i2<<3 | i4<<4, so that with the N fragment as the MFMA's
 //    A operand a lane ends up with 8 consecutive output columns per 8 accumulator registers: every epilogue access is 16 B.
 #pragma once
@@ -94,66 +96,23 @@ __device__ __forceinline__ void q8_stage_half(const unsigned char* base, int rec
 }
 
 // ---- epilogue of 8 consecutive outputs of one row (the host only selects this kernel when every [M, ld] epilogue operand is
-// 16-B aligned at 8-column granularity and N % 8 == 0, so a group of 8 is either wholly inside the matrix or wholly outside).
-// EPI is a compile-time selection of what the epilogue can do -- with every option tested at run time the epilogue's branches
-// push the kernel over its 256 registers:
+// 16-B aligned at 8-column granularity, N % 8 == 0 and every matrix is < 2 GB).  EPI is a compile-time selection of what the
+// epilogue can do -- with every option tested at run time the epilogue's branches push the kernel over its 256 registers:
 //   0  bf16 C = alpha*acc (+bias)            1  ... + save pre-activation + exact GELU        2  ... + residual
 //   3  bf16 C = alpha*acc * gelu'(gmul) (+residual)                                            4  f32: split-K slab, or C (+= old)
-template <int EPI>
-__device__ __forceinline__ void q8_epi8(const GemmArgs& g, int m, int n, float (&v)[8], int z, const float (&bias)[8],
-                                        float al, const uint4& qg, const uint4& qr) {
-    if (m >= g.M || n >= g.N) return;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] *= al;
-    if (EPI <= 2 && g.bias) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += bias[r];
-    }
-    if (EPI == 1) {
-        st8<bf16_t>(reinterpret_cast<bf16_t*>(g.pre_out) + (long)m * g.ldp + n, v);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16_t>(rnd<bf16_t>(v[r]));
-    }
-    if (EPI == 3) {
-        const uint32_t w[4] = {qg.x, qg.y, qg.z, qg.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[2 * r] *= gelu_grad_t<bf16_t>(__uint_as_float(w[r] << 16));
-            v[2 * r + 1] *= gelu_grad_t<bf16_t>(__uint_as_float(w[r] & 0xffff0000u));
-        }
-    }
-    if (EPI == 2 || (EPI == 3 && g.residual)) {
-        const uint32_t w[4] = {qr.x, qr.y, qr.z, qr.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[2 * r] += __uint_as_float(w[r] << 16);
-            v[2 * r + 1] += __uint_as_float(w[r] & 0xffff0000u);
-        }
-    }
-    if (EPI == 4) {
-        if (g.partial) {
-            st8<float>(g.partial + ((long)z * g.M + m) * g.N + n, v);
-        } else {
-            float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n;
-            if (g.accumulate) {
-                float o[8];
-                ld8<float>(c, o);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += o[r];
-            }
-            st8<float>(c, v);
-        }
-    } else {
-        st8<bf16_t>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n, v);
-    }
+// Stores per quadrant (exact, whatever the bounds): 4 for EPI 0/2/3, 8 for EPI 1/4.
+template <int EPI> struct Q8Epi { static constexpr int NST = (EPI == 1 || EPI == 4) ? 8 : 4; };
+typedef unsigned int q8_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
+    return (q8_u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
 }
 
-// DBG bits (development, GemmArgs.dbg): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 16 = epilogue in one piece after the tile
-template <bool A_KC, bool B_KC, int EPI, int NSLOT, int DBG = 0>
+// DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 8 = no s_setprio
+template <bool A_KC, bool B_KC, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
-    static_assert(NSLOT == 4 || NSLOT == 5, "ring of 4 or 5 half-tile slots per operand");
-    constexpr int LEAD = NSLOT + 1;                 // half-tiles the DMA runs ahead of the phase that issues it
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // A ring | B ring; the ONLY LDS object
+    constexpr int NST = Q8Epi<EPI>::NST;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // K tile 0 {A_0 A_1 B_0 B_1} | K tile 1; the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int total = g.nbm * g.nbn * g.nsplit, G = (int)gridDim.x;
@@ -163,39 +122,39 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     // N-side fragment row -> tile column (see header)
     const int ncol = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | ((l31 >> 4) << 4);
 
-    // per-lane fragment offsets inside a half-tile (without slot base and quadrant offset)
+    // per-lane fragment offsets inside a half-tile (without K-tile base and quadrant offset)
     //   kc: row*128 + ((2*ks + lh) ^ key(row)) * 16, one per k-step (the XOR does not commute with the k-step offset)
     //   oc: (ks*16 + 8*kb + r)*256 + ((chunk ^ (r<<2)) * 16) + within, one per 32-output tile index (the XOR touches the tile bits)
     unsigned offM[4], offN[4];
     if (A_KC) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) offM[ks] = (unsigned)(l31 * 128 + (((2 * ks + lh) ^ ((l31 >> 1) & 7)) << 4));
+        for (int ks = 0; ks < 4; ++ks) offM[ks] = (unsigned)(wr * Q8_HALF + l31 * 128 + (((2 * ks + lh) ^ ((l31 >> 1) & 7)) << 4));
     } else {
         const int i16 = lane & 15, ob = (lane >> 4) & 1, kb = lane >> 5, r = i16 >> 2, q = i16 & 3;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {   // tile index t = 2*mh + tm of the wave's 128 rows
             const int col = t * 32 + 16 * ob + 4 * q;
-            offM[t] = (unsigned)((8 * kb + r) * 256 + ((((col >> 3) ^ (r << 2)) & 15) << 4) + (col & 7) * 2);
+            offM[t] = (unsigned)(wr * Q8_HALF + (8 * kb + r) * 256 + ((((col >> 3) ^ (r << 2)) & 15) << 4) + (col & 7) * 2);
         }
     }
     if (B_KC) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) offN[ks] = (unsigned)(((wc & 1) * 64 + ncol) * 128 + (((2 * ks + lh) ^ ((ncol >> 1) & 7)) << 4));
+        for (int ks = 0; ks < 4; ++ks)
+            offN[ks] = (unsigned)((2 + (wc >> 1)) * Q8_HALF + ((wc & 1) * 64 + ncol) * 128 + (((2 * ks + lh) ^ ((ncol >> 1) & 7)) << 4));
     } else {
         const int i16 = lane & 15, ob = (lane >> 4) & 1, kb = lane >> 5, r = i16 >> 2, q = i16 & 3;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {   // t = nh; the pointer of quarter q covers the 4 outputs at 4*(q>>1) + 8*(q&1) (column remap)
             const int col = (wc & 1) * 64 + t * 32 + 16 * ob + 4 * (q >> 1) + 8 * (q & 1);
-            offN[t] = (unsigned)((8 * kb + r) * 256 + ((((col >> 3) ^ (r << 2)) & 15) << 4) + (col & 7) * 2);
+            offN[t] = (unsigned)((2 + (wc >> 1)) * Q8_HALF + (8 * kb + r) * 256 + ((((col >> 3) ^ (r << 2)) & 15) << 4) + (col & 7) * 2);
         }
         offN[2] = offN[3] = 0;
     }
 
     f32x16 acc[4][2];
 
-    // ---- DMA cursor over the flat half-tile stream ---------------------------------------------------------------------------
-    // all of it wave-uniform (SGPRs): byte cursors of the A and B half-tile 0 of the K tile being staged, bytes left in their valid
-    // ranges, contraction elements left in the staged output tile
+    // ---- DMA cursor over the flat K-tile stream; all of it wave-uniform (SGPRs): byte cursors of the A and B half-tile 0 of the
+    // K tile to stage next, bytes left in their valid ranges, contraction elements left in the staged output tile
     int pv = (int)blockIdx.x;
     bool pdone = pv >= total;
     const unsigned char *sa_base, *sb_base;
@@ -212,64 +171,52 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         else      { sb_base = (const unsigned char*)(B + ((long)n_.kbeg * g.ldb + n_.n0)); sb_rec = (int)(((long)p_krem * g.ldb - n_.n0) * 2); }             \
     } while (0)
     if (!pdone) Q8_NEXT_ITEM();
-    int wA = 0, wB = 0;
+    int wslot = 0;                                     // K-tile slot (0/1) the next staged K tile goes to
     unsigned voffA[2], voffB[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { voffA[i] = q8_voff<A_KC>(i, wave, lane, g.lda); voffB[i] = q8_voff<B_KC>(i, wave, lane, g.ldb); }
-    int nstaged = 0;                                   // half-tiles issued so far (for the tail waits)
-#define Q8_STAGE(KIND)                                                                                                   \
+    // stage the next K tile of the stream (8 DMA instructions per wave)
+#define Q8_STAGE_KTILE()                                                                                                 \
     do {                                                                                                                 \
         if (!pdone) {                                                                                                    \
+            unsigned char* d_ = lds + wslot * (4 * Q8_HALF);                                                             \
             if (!(DBG & 2)) {                                                                                            \
-                if ((KIND) == 0) q8_stage_half<A_KC>(sa_base, sa_rec, p_krem, lds + wA * Q8_HALF, voffA, wave, lane);    \
-                if ((KIND) == 1) q8_stage_half<A_KC>(sa_base + a_half, sa_rec - a_half, p_krem, lds + wA * Q8_HALF, voffA, wave, lane);           \
-                if ((KIND) == 2) q8_stage_half<B_KC>(sb_base, sb_rec, p_krem, lds + (NSLOT + wB) * Q8_HALF, voffB, wave, lane);                   \
-                if ((KIND) == 3) q8_stage_half<B_KC>(sb_base + b_half, sb_rec - b_half, p_krem, lds + (NSLOT + wB) * Q8_HALF, voffB, wave, lane); \
+                q8_stage_half<A_KC>(sa_base, sa_rec, p_krem, d_, voffA, wave, lane);                                     \
+                q8_stage_half<A_KC>(sa_base + a_half, sa_rec - a_half, p_krem, d_ + Q8_HALF, voffA, wave, lane);         \
+                q8_stage_half<B_KC>(sb_base, sb_rec, p_krem, d_ + 2 * Q8_HALF, voffB, wave, lane);                       \
+                q8_stage_half<B_KC>(sb_base + b_half, sb_rec - b_half, p_krem, d_ + 3 * Q8_HALF, voffB, wave, lane);     \
             }                                                                                                            \
-            if ((KIND) < 2) wA = wA == NSLOT - 1 ? 0 : wA + 1; else wB = wB == NSLOT - 1 ? 0 : wB + 1;                   \
-            ++nstaged;                                                                                                   \
-            if ((KIND) == 3) {                                                                                           \
-                p_krem -= 64;                                                                                            \
-                sa_base += a_step; sa_rec -= a_step; sb_base += b_step; sb_rec -= b_step;                                \
-                if (p_krem <= 0) {                                                                                       \
-                    pv += G;                                                                                             \
-                    if (pv < total) Q8_NEXT_ITEM(); else pdone = true;                                                   \
-                }                                                                                                        \
+            wslot ^= 1;                                                                                                  \
+            p_krem -= 64;                                                                                                \
+            sa_base += a_step; sa_rec -= a_step; sb_base += b_step; sb_rec -= b_step;                                    \
+            if (p_krem <= 0) {                                                                                           \
+                pv += G;                                                                                                 \
+                if (pv < total) Q8_NEXT_ITEM(); else pdone = true;                                                       \
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
+    // every DMA of mine has landed, except that the `N_` youngest vector-memory operations (stores issued after it) may be pending
+#define Q8_WAIT_DMA(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
 
-    // wait until at most `n_` of my half-tiles are in flight (n_ in 0..2)
-#define Q8_WAIT_HALVES(N_)                                                         \
-    do {                                                                           \
-        const int n_ = (N_);                                                       \
-        if (n_ >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              \
-        else if (n_ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
-    } while (0)
-
-    // prologue: LEAD half-tiles in flight, K tile 0 landed and published
-    Q8_STAGE(0); Q8_STAGE(1); Q8_STAGE(2); Q8_STAGE(3); Q8_STAGE(0);
-    if (LEAD == 6) Q8_STAGE(1);
-    Q8_WAIT_HALVES(nstaged - 4);
+    // prologue: K tile 0 landed and published
+    Q8_STAGE_KTILE();
+    Q8_WAIT_DMA(0);
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier interval behind wave row 0
 
     hw_bf16x8 fm[2][4], fn[4];
-    int rA = 0, rB = 0;                               // ring slots of A_0 / B_0 of the K tile being multiplied
-    int consumed = 0;                                 // K tiles multiplied so far (x4 = half-tiles retired)
+    int rslot = 0;                                    // K-tile slot being multiplied
 
     // fragment reads ------------------------------------------------------------------------------------------------------------
 #define Q8_READ_FM(MH)                                                                                                   \
     do {                                                                                                                 \
         if (A_KC) {                                                                                                      \
-            _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                             \
-                _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                         \
-                    fm[tm][ks] = *reinterpret_cast<const hw_bf16x8*>(sA + offM[ks] + ((MH) * 64 + tm * 32) * 128);       \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
+                _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                         \
+                    fm[tm][ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offM[ks] + ((MH) * 64 + tm * 32) * 128);       \
         } else {                                                                                                         \
-            _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                             \
-                _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                       \
-                    const unsigned char* p_ = sA + offM[2 * (MH) + tm] + ks * 16 * 256;                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
+                _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) {                                                       \
+                    const unsigned char* p_ = sK + offM[2 * (MH) + tm] + ks * 16 * 256;                                  \
                     q8_v4s16 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_));            \
                     q8_v4s16 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_ + 4 * 256));  \
                     fm[tm][ks] = __builtin_bit_cast(hw_bf16x8, (bf16x8){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]}); \
@@ -280,18 +227,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     do {                                                                                                                 \
         if (B_KC) {                                                                                                      \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
-                fn[ks] = *reinterpret_cast<const hw_bf16x8*>(sB + offN[ks] + (NH) * 32 * 128);                           \
+                fn[ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offN[ks] + (NH) * 32 * 128);                           \
         } else {                                                                                                         \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
-                const unsigned char* p_ = sB + offN[(NH)] + ks * 16 * 256;                                               \
+                const unsigned char* p_ = sK + offN[(NH)] + ks * 16 * 256;                                               \
                 q8_v4s16 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_));                \
                 q8_v4s16 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_ + 4 * 256));      \
                 fn[ks] = __builtin_bit_cast(hw_bf16x8, (bf16x8){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]});         \
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
+    /* step 0 reads both operands: k-step by k-step, in the order the MFMAs consume them */                           
+#define Q8_READ_STEP0()                                                                                                  \
+    do {                                                                                                                 \
+        if (A_KC && B_KC) {                                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
+                fn[ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offN[ks]);                                             \
+                fm[0][ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offM[ks]);                                          \
+                fm[1][ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offM[ks] + 32 * 128);                               \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            Q8_READ_FN(0);                                                                                               \
+            Q8_READ_FM(0);                                                                                               \
+        }                                                                                                                \
+    } while (0)
 #define Q8_MFMA(MH, NH, FIRST)                                                                                           \
     do {                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                                                   \
         if (DBG & 1) {   /* keep the fragment reads alive */                                                           \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
                 asm volatile("" ::"v"(fn[ks]), "v"(fm[0][ks]), "v"(fm[1][ks]));                                          \
@@ -303,9 +266,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
                     acc[2 * (MH) + tm][(NH)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
                         fn[ks], fm[tm][ks], ((FIRST) && ks == 0) ? zero16 : acc[2 * (MH) + tm][(NH)], 0, 0, 0);          \
         }                                                                                                                \
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
     } while (0)
 
-    // epilogue of quadrant (MH, NH) of the output tile at (m0, n0), split z: 2 tiles x 2 groups of 8 consecutive columns per lane.
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+    // buffer descriptors of the outputs (kernel constants; every byte offset fits 32 bits, checked by the host)
+    const int esz = EPI == 4 ? 4 : 2;
+    const long ldo = (EPI == 4 && g.partial) ? (long)g.N : g.ldc;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
+        (EPI == 4 && g.partial) ? (void*)g.partial : g.C, 0,
+        (int)(unsigned)(((EPI == 4 && g.partial) ? (long)g.nsplit * g.M : (long)g.M) * ldo * esz), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? g.pre_out : g.C, 0, (int)(unsigned)((long)g.M * g.ldp * 2), 0x00020000);
+    const unsigned lane_o = (unsigned)((l31 * ldo + 8 * lh) * esz);          // lane part of an output offset
+    const unsigned lane_p = (unsigned)((l31 * g.ldp + 8 * lh) * 2);
+    const unsigned lane_g = (unsigned)((l31 * g.ldg + 8 * lh) * 2);
+    const unsigned lane_r = (unsigned)((l31 * g.ldr + 8 * lh) * 2);
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 3 ? g.gmul : g.C), 0, (int)(unsigned)((long)g.M * g.ldg * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == 2 || EPI == 3) && g.residual ? g.residual : g.C), 0,
+                                                                        (int)(unsigned)((long)g.M * g.ldr * 2), 0x00020000);
+    // quadrant (MH, NH) of the output tile at (tm0, tn0), split tz: 2 tiles x 2 groups of 8 consecutive columns per lane.
     // The accumulators are only READ: the first K tile of the next output tile starts from C = 0 in the MFMA itself.
     auto store_quadrant = [&](int tm0, int tn0, int tz, auto mh_c, auto nh_c) {
         constexpr int MH = decltype(mh_c)::value, NH = decltype(nh_c)::value;
@@ -314,9 +294,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
             for (int tm = 0; tm < 2; ++tm) asm volatile("" ::"v"(acc[2 * MH + tm][NH]));
             return;
         }
-        const int nb = tn0 + wc * 64 + NH * 32;              // wave-uniform: first column of the quadrant
-        const int n_l = nb + 8 * lh;                         // + 16*gq below
-        const int m_l = tm0 + wr * 128 + MH * 64 + l31;      // + 32*tm below
+        const int mb = tm0 + wr * 128 + MH * 64;             // wave-uniform first row / column of the quadrant
+        const int nb = tn0 + wc * 64 + NH * 32;
+        const bool edge = nb + 32 > g.N;                     // uniform: some groups of 8 lie past N
         // wave-uniform addresses in the constant address space, pinned to SGPRs: scalar loads (lgkmcnt) that do not touch the DMA
         // queue's vmcnt (a vector load here makes hipcc drain the whole queue with vmcnt(0))
         typedef const float __attribute__((address_space(4))) cfloat4;
@@ -345,18 +325,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
                 }
             }
         }
-        const bf16_t* gm = reinterpret_cast<const bf16_t*>(g.gmul);
-        const bf16_t* rs = reinterpret_cast<const bf16_t*>(g.residual);
-        uint4 qg[2][2], qr[2][2];
+        // byte offsets: uniform tile part + lane part; a group past N gets offset 2^31, past every descriptor (< 2 GB, host-checked): dropped / reads 0
+        unsigned uo[2][2], up[2][2], ug[2][2], ur[2][2];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
-                qg[tm][gq] = make_uint4(0, 0, 0, 0);
-                qr[tm][gq] = make_uint4(0, 0, 0, 0);
-                const int m = min(m_l + tm * 32, g.M - 1), n = min(n_l + 16 * gq, g.N - 8);
-                if (EPI == 3) qg[tm][gq] = *reinterpret_cast<const uint4*>(gm + (long)m * g.ldg + n);
-                if (EPI == 2 || (EPI == 3 && rs)) qr[tm][gq] = *reinterpret_cast<const uint4*>(rs + (long)m * g.ldr + n);
+                const long row = mb + tm * 32, col = nb + 16 * gq;
+                const bool oob = edge && (nb + 16 * gq + 8 * lh >= g.N);
+                uo[tm][gq] = oob ? 0x80000000u : (unsigned)(((EPI == 4 && g.partial ? (long)tz * g.M : 0) + row) * ldo + col) * esz + lane_o;
+                if (EPI == 1) up[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldp + col) * 2) + lane_p;
+                if (EPI == 3) ug[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldg + col) * 2) + lane_g;
+                if (EPI == 2 || EPI == 3) ur[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldr + col) * 2) + lane_r;
+            }
+        // all loads of the quadrant ahead of its first store
+        q8_u32x4 qg[2][2], qr[2][2], qo[2][2][2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+                if (EPI == 3) qg[tm][gq] = __builtin_amdgcn_raw_buffer_load_b128(rG, ug[tm][gq], 0, 0);
+                if (EPI == 2 || (EPI == 3 && g.residual)) qr[tm][gq] = __builtin_amdgcn_raw_buffer_load_b128(rR, ur[tm][gq], 0, 0);
+                if (EPI == 4 && !g.partial && g.accumulate) {
+                    qo[tm][gq][0] = __builtin_amdgcn_raw_buffer_load_b128(rC, uo[tm][gq], 0, 0);
+                    qo[tm][gq][1] = __builtin_amdgcn_raw_buffer_load_b128(rC, uo[tm][gq] + 16, 0, 0);
+                }
             }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -364,66 +357,83 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
             for (int gq = 0; gq < 2; ++gq) {
                 float v[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = acc[2 * MH + tm][NH][8 * gq + r];
-                q8_epi8<EPI>(g, m_l + tm * 32, n_l + 16 * gq, v, tz, bias[gq], al, qg[tm][gq], qr[tm][gq]);
+                for (int r = 0; r < 8; ++r) v[r] = acc[2 * MH + tm][NH][8 * gq + r] * al;
+                if (EPI <= 2 && g.bias) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bias[gq][r];
+                }
+                if (EPI == 1) {
+                    __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rP, up[tm][gq], 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16_t>(rnd<bf16_t>(v[r]));
+                }
+                if (EPI == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[2 * r] *= gelu_grad_t<bf16_t>(__uint_as_float(qg[tm][gq][r] << 16));
+                        v[2 * r + 1] *= gelu_grad_t<bf16_t>(__uint_as_float(qg[tm][gq][r] & 0xffff0000u));
+                    }
+                }
+                if (EPI == 2 || (EPI == 3 && g.residual)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[2 * r] += __uint_as_float(qr[tm][gq][r] << 16);
+                        v[2 * r + 1] += __uint_as_float(qr[tm][gq][r] & 0xffff0000u);
+                    }
+                }
+                if (EPI == 4) {
+                    if (!g.partial && g.accumulate) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] += __uint_as_float(qo[tm][gq][0][r]); v[4 + r] += __uint_as_float(qo[tm][gq][1][r]); }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128((q8_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rC, uo[tm][gq], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((q8_u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rC, uo[tm][gq] + 16, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rC, uo[tm][gq], 0, 0);
+                }
             }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    // ---- one K tile = four phases.  FIRST: first K tile of an output tile (C = 0; the previous tile's last quadrant is stored in
-    // phase 0).  LAST: last K tile (quadrants stored as they become final).  Literal flags: three straight-line copies of the
-    // body, so that no accumulator is live across a branch that writes it (which costs a second register copy of all of them).
-#define Q8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define Q8_MULT(MH, NH, FIRST)                   \
-    do {                                         \
-        Q8_BAR();                                \
-        __builtin_amdgcn_s_setprio(1);           \
-        Q8_MFMA(MH, NH, FIRST);                  \
-        __builtin_amdgcn_s_setprio(0);           \
-        Q8_BAR();                                \
-    } while (0)
+    // ---- one K tile.  FIRST: first K tile of an output tile (C = 0; the previous tile's last quadrant is stored at its start).
+    // LAST: last K tile (quadrants stored as they become final).  Literal flags: three straight-line copies of the body, so that
+    // no accumulator is live across a branch that writes it (which costs a second register copy of all of them).
+    // Vector-memory operations issued after the DMA in one K tile: FIRST (with a pending tile) NST stores, LAST 3*NST stores.
 #define Q8_KTILE(FIRST, LAST)                                                                                            \
     do {                                                                                                                 \
-        const unsigned char* sA = lds + (rA + wr >= NSLOT ? rA + wr - NSLOT : rA + wr) * Q8_HALF;                         \
-        const int sb_ = rB + (wc >> 1);                                                                                  \
-        const unsigned char* sB = lds + (NSLOT + (sb_ >= NSLOT ? sb_ - NSLOT : sb_)) * Q8_HALF;                          \
-        /* phase 0: quadrant (m0, n0) */                                                                                 \
-        Q8_READ_FN(0);                                                                                                   \
+        const unsigned char* sK = lds + rslot * (4 * Q8_HALF);                                                           \
+        if (wr == 1) { Q8_STAGE_KTILE(); __builtin_amdgcn_sched_barrier(0); }                                            \
+        Q8_READ_STEP0();                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_READ_FM(0);                                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_STAGE((0 + LEAD) & 3);                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (wr == 0) { Q8_STAGE_KTILE(); __builtin_amdgcn_sched_barrier(0); }                                            \
         if ((FIRST) && have_pend) store_quadrant(pm0, pn0, pz, I1(), I0());                                              \
-        Q8_MULT(0, 0, FIRST);                                                                                            \
-        /* phase 1: quadrant (m0, n1) */                                                                                 \
-        Q8_READ_FN(1);                                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_STAGE((1 + LEAD) & 3);                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        Q8_MFMA(0, 0, FIRST);                                                                                            \
         if (LAST) store_quadrant(cm0, cn0, cz, I0(), I0());                                                              \
-        Q8_MULT(0, 1, FIRST);                                                                                            \
-        /* phase 2: quadrant (m1, n1) */                                                                                 \
-        Q8_READ_FM(1);                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_STAGE((2 + LEAD) & 3);                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        Q8_READ_FN(1);                                                                                                   \
+        Q8_MFMA(0, 1, FIRST);                                                                                            \
         if (LAST) store_quadrant(cm0, cn0, cz, I0(), I1());                                                              \
-        Q8_MULT(1, 1, FIRST);                                                                                            \
-        /* phase 3: quadrant (m1, n0); the wait that publishes the NEXT K tile (read from the next phase on) */          \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        Q8_READ_FM(1);                                                                                                   \
+        Q8_MFMA(1, 1, FIRST);                                                                                            \
+        if (LAST) store_quadrant(cm0, cn0, cz, I1(), I1());                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
         Q8_READ_FN(0);                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_STAGE((3 + LEAD) & 3);                                                                                        \
+        if (wr == 0) {                                                                                                   \
+            Q8_MFMA(1, 0, FIRST);                                                                                        \
+            if ((FIRST) && have_pend) Q8_WAIT_DMA(NST); else if (LAST) Q8_WAIT_DMA(3 * NST); else Q8_WAIT_DMA(0);        \
+            __builtin_amdgcn_s_barrier();                                                                                \
+        } else {                                                                                                         \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* my reads of this K tile are done before its slot is refilled */ \
+            if ((FIRST) && have_pend) Q8_WAIT_DMA(NST); else if (LAST) Q8_WAIT_DMA(3 * NST); else Q8_WAIT_DMA(0);        \
+            __builtin_amdgcn_s_barrier();                                                                                \
+            Q8_MFMA(1, 0, FIRST);                                                                                        \
+        }                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_WAIT_HALVES(nstaged - 4 * (consumed + 2));                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (LAST) store_quadrant(cm0, cn0, cz, I1(), I1());                                                              \
-        Q8_MULT(1, 0, FIRST);                                                                                            \
-        rA = rA + 2 >= NSLOT ? rA + 2 - NSLOT : rA + 2;                                                                  \
-        rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
-        ++consumed;                                                                                                      \
+        rslot ^= 1;                                                                                                      \
     } while (0)
 
     // ---- main loop over this workgroup's output tiles (every tile has at least two K tiles: the host guarantees K/split >= 128)
@@ -439,14 +449,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         have_pend = true; pm0 = cm0; pn0 = cn0; pz = cz;
     }
     if (have_pend) store_quadrant(pm0, pn0, pz, I1(), I0());
-    if (wr == 0) __builtin_amdgcn_s_barrier();        // pairs with wave row 1's extra barrier
 #undef Q8_KTILE
-#undef Q8_MULT
-#undef Q8_BAR
-#undef Q8_STAGE
+#undef Q8_STAGE_KTILE
 #undef Q8_NEXT_ITEM
-#undef Q8_WAIT_HALVES
+#undef Q8_WAIT_DMA
 #undef Q8_READ_FM
+#undef Q8_READ_STEP0
 #undef Q8_READ_FN
 #undef Q8_MFMA
 }
