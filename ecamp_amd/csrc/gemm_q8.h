@@ -81,7 +81,7 @@ __device__ __forceinline__ unsigned q8_voff(int i, int wave, int lane, long ld) 
 }
 // `base`/`rec`: wave-uniform first byte of the half-tile and bytes from there to the end of the valid range (<= 0: nothing valid);
 // `krem`: contraction elements left from this K tile's first column (kc operands: chunks at k >= krem read as zero)
-template <bool KC>
+template <bool KC, int PIECES = 3>
 __device__ __forceinline__ void q8_stage_half(const unsigned char* base, int rec, int krem, unsigned char* dst,
                                               const unsigned (&voff)[2], int wave, int lane) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rec < 0 ? 0 : rec, 0x00020000);
@@ -91,8 +91,8 @@ __device__ __forceinline__ void q8_stage_half(const unsigned char* base, int rec
         if (kc0 * 8 >= krem) { v0 = 0xFFFFFF00u; v1 = 0xFFFFFF00u; }
     }
     typedef void __attribute__((address_space(3))) lds_void;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + wave * 1024), 16, (int)v0, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + 8192 + wave * 1024), 16, (int)v1, 0, 0, 0);
+    if (PIECES & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + wave * 1024), 16, (int)v0, 0, 0, 0);
+    if (PIECES & 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + 8192 + wave * 1024), 16, (int)v1, 0, 0, 0);
 }
 
 // ---- epilogue of 8 consecutive outputs of one row (the host only selects this kernel when every [M, ld] epilogue operand is
@@ -108,7 +108,8 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
     return (q8_u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
 }
 
-// DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 8 = no s_setprio
+// DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 8 = no s_setprio, 16 = no barrier in the
+// loop, 32 = no fragment reads (timing decomposition only: 16 and 32 give wrong results)
 template <bool A_KC, bool B_KC, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     constexpr int NST = Q8Epi<EPI>::NST;
@@ -175,99 +176,72 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     unsigned voffA[2], voffB[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { voffA[i] = q8_voff<A_KC>(i, wave, lane, g.lda); voffB[i] = q8_voff<B_KC>(i, wave, lane, g.ldb); }
-    // stage the next K tile of the stream (8 DMA instructions per wave)
-#define Q8_STAGE_KTILE()                                                                                                 \
+    // stage pieces PCS (bit 0: piece `wave`, bit 1: piece `8 + wave`) of half-tile PART (0: A_0, 1: A_1, 2: B_0, 3: B_1) of the next
+    // K tile of the stream; the cursor moves on with the second piece of part 3
+#define Q8_STAGE_PCS(PART, PCS)                                                                                          \
     do {                                                                                                                 \
         if (!pdone) {                                                                                                    \
-            unsigned char* d_ = lds + wslot * (4 * Q8_HALF);                                                             \
+            unsigned char* d_ = lds + wslot * (4 * Q8_HALF) + (PART) * Q8_HALF;                                          \
             if (!(DBG & 2)) {                                                                                            \
-                q8_stage_half<A_KC>(sa_base, sa_rec, p_krem, d_, voffA, wave, lane);                                     \
-                q8_stage_half<A_KC>(sa_base + a_half, sa_rec - a_half, p_krem, d_ + Q8_HALF, voffA, wave, lane);         \
-                q8_stage_half<B_KC>(sb_base, sb_rec, p_krem, d_ + 2 * Q8_HALF, voffB, wave, lane);                       \
-                q8_stage_half<B_KC>(sb_base + b_half, sb_rec - b_half, p_krem, d_ + 3 * Q8_HALF, voffB, wave, lane);     \
+                if ((PART) == 0) q8_stage_half<A_KC, (PCS)>(sa_base, sa_rec, p_krem, d_, voffA, wave, lane);             \
+                if ((PART) == 1) q8_stage_half<A_KC, (PCS)>(sa_base + a_half, sa_rec - a_half, p_krem, d_, voffA, wave, lane);  \
+                if ((PART) == 2) q8_stage_half<B_KC, (PCS)>(sb_base, sb_rec, p_krem, d_, voffB, wave, lane);             \
+                if ((PART) == 3) q8_stage_half<B_KC, (PCS)>(sb_base + b_half, sb_rec - b_half, p_krem, d_, voffB, wave, lane);  \
             }                                                                                                            \
-            wslot ^= 1;                                                                                                  \
-            p_krem -= 64;                                                                                                \
-            sa_base += a_step; sa_rec -= a_step; sb_base += b_step; sb_rec -= b_step;                                    \
-            if (p_krem <= 0) {                                                                                           \
-                pv += G;                                                                                                 \
-                if (pv < total) Q8_NEXT_ITEM(); else pdone = true;                                                       \
+            if ((PART) == 3 && ((PCS) & 2)) {                                                                            \
+                wslot ^= 1;                                                                                              \
+                p_krem -= 64;                                                                                            \
+                sa_base += a_step; sa_rec -= a_step; sb_base += b_step; sb_rec -= b_step;                                \
+                if (p_krem <= 0) {                                                                                       \
+                    pv += G;                                                                                             \
+                    if (pv < total) Q8_NEXT_ITEM(); else pdone = true;                                                   \
+                }                                                                                                        \
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
+#define Q8_STAGE_PART(PART) Q8_STAGE_PCS(PART, 3)
     // every DMA of mine has landed, except that the `N_` youngest vector-memory operations (stores issued after it) may be pending
 #define Q8_WAIT_DMA(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
 
-    // prologue: K tile 0 landed and published
-    Q8_STAGE_KTILE();
-    Q8_WAIT_DMA(0);
-    __builtin_amdgcn_s_barrier();
-
-    hw_bf16x8 fm[2][4], fn[4];
+    hw_bf16x8 xm[4] = {}, xn[2] = {}, ym[4] = {}, yn[2] = {};   // two fragment groups (one k-step of 16 each): 4 M-side + 2 N-side
     int rslot = 0;                                    // K-tile slot being multiplied
 
-    // fragment reads ------------------------------------------------------------------------------------------------------------
-#define Q8_READ_FM(MH)                                                                                                   \
+    // fragment I (0..5, in the order the MFMAs consume them: n0 m0 m1 n1 m2 m3) of k-step KS of the K tile at SK into group (FM, FN)
+#define Q8_RD1(FM, FN, SK, KS, I)                                                                                        \
     do {                                                                                                                 \
-        if (A_KC) {                                                                                                      \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
-                _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                         \
-                    fm[tm][ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offM[ks] + ((MH) * 64 + tm * 32) * 128);       \
-        } else {                                                                                                         \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
-                _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) {                                                       \
-                    const unsigned char* p_ = sK + offM[2 * (MH) + tm] + ks * 16 * 256;                                  \
+        constexpr int isn_ = ((I) == 0 || (I) == 3), idx_ = (I) == 0 ? 0 : (I) == 3 ? 1 : (I) < 3 ? (I) - 1 : (I) - 2;   \
+        if (!(DBG & 32)) {                                                                                               \
+            if (isn_) {                                                                                                  \
+                if (B_KC) FN[idx_] = *reinterpret_cast<const hw_bf16x8*>((SK) + offN[KS] + idx_ * 32 * 128);             \
+                else {                                                                                                   \
+                    const unsigned char* p_ = (SK) + offN[idx_] + (KS) * 16 * 256;                                       \
                     q8_v4s16 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_));            \
                     q8_v4s16 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_ + 4 * 256));  \
-                    fm[tm][ks] = __builtin_bit_cast(hw_bf16x8, (bf16x8){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]}); \
+                    FN[idx_] = __builtin_bit_cast(hw_bf16x8, (bf16x8){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]});   \
                 }                                                                                                        \
-        }                                                                                                                \
-    } while (0)
-#define Q8_READ_FN(NH)                                                                                                   \
-    do {                                                                                                                 \
-        if (B_KC) {                                                                                                      \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
-                fn[ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offN[ks] + (NH) * 32 * 128);                           \
-        } else {                                                                                                         \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
-                const unsigned char* p_ = sK + offN[(NH)] + ks * 16 * 256;                                               \
-                q8_v4s16 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_));                \
-                q8_v4s16 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_ + 4 * 256));      \
-                fn[ks] = __builtin_bit_cast(hw_bf16x8, (bf16x8){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]});         \
+            } else {                                                                                                     \
+                if (A_KC) FM[idx_] = *reinterpret_cast<const hw_bf16x8*>((SK) + offM[KS] + idx_ * 32 * 128);             \
+                else {                                                                                                   \
+                    const unsigned char* p_ = (SK) + offM[idx_] + (KS) * 16 * 256;                                       \
+                    q8_v4s16 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_));            \
+                    q8_v4s16 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_ + 4 * 256));  \
+                    FM[idx_] = __builtin_bit_cast(hw_bf16x8, (bf16x8){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]});   \
+                }                                                                                                        \
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
-    /* step 0 reads both operands: k-step by k-step, in the order the MFMAs consume them */                           
-#define Q8_READ_STEP0()                                                                                                  \
+#define Q8_READ_GROUP(FM, FN, SK, KS) \
+    do { Q8_RD1(FM, FN, SK, KS, 0); Q8_RD1(FM, FN, SK, KS, 1); Q8_RD1(FM, FN, SK, KS, 2); Q8_RD1(FM, FN, SK, KS, 3); Q8_RD1(FM, FN, SK, KS, 4); Q8_RD1(FM, FN, SK, KS, 5); } while (0)
+    // MFMA J (0..7) of a group: quadrants in the order (m0 n0) (m0 n1) (m1 n1) (m1 n0), two 32x32 tiles each
+#define Q8_MFMA1(FM, FN, J, ZERO)                                                                                        \
     do {                                                                                                                 \
-        if (A_KC && B_KC) {                                                                                              \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
-                fn[ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offN[ks]);                                             \
-                fm[0][ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offM[ks]);                                          \
-                fm[1][ks] = *reinterpret_cast<const hw_bf16x8*>(sK + offM[ks] + 32 * 128);                               \
-            }                                                                                                            \
+        constexpr int q_ = (J) >> 1, mh_ = q_ >> 1, nh_ = (q_ == 1 || q_ == 2) ? 1 : 0, tm_ = 2 * mh_ + ((J) & 1);       \
+        if (DBG & 1) {                                                                                                   \
+            asm volatile("" ::"v"(FN[nh_]), "v"(FM[tm_]));                                                               \
+            if (ZERO) acc[tm_][nh_] = zero16;                                                                            \
         } else {                                                                                                         \
-            Q8_READ_FN(0);                                                                                               \
-            Q8_READ_FM(0);                                                                                               \
+            acc[tm_][nh_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FN[nh_], FM[tm_], (ZERO) ? zero16 : acc[tm_][nh_], 0, 0, 0); \
         }                                                                                                                \
-    } while (0)
-#define Q8_MFMA(MH, NH, FIRST)                                                                                           \
-    do {                                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                                                   \
-        if (DBG & 1) {   /* keep the fragment reads alive */                                                           \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
-                asm volatile("" ::"v"(fn[ks]), "v"(fm[0][ks]), "v"(fm[1][ks]));                                          \
-                if (FIRST) { acc[2 * (MH)][(NH)] = zero16; acc[2 * (MH) + 1][(NH)] = zero16; }                           \
-            }                                                                                                            \
-        } else {                                                                                                         \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
-                _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                         \
-                    acc[2 * (MH) + tm][(NH)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
-                        fn[ks], fm[tm][ks], ((FIRST) && ks == 0) ? zero16 : acc[2 * (MH) + tm][(NH)], 0, 0, 0);          \
-        }                                                                                                                \
-        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
     } while (0)
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
@@ -396,45 +370,87 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define Q8_STORE_Q(TM0, TN0, TZ, Q)                                                           \
+    do {                                                                                      \
+        if ((Q) == 0) store_quadrant(TM0, TN0, TZ, I0(), I0());                               \
+        if ((Q) == 1) store_quadrant(TM0, TN0, TZ, I0(), I1());                               \
+        if ((Q) == 2) store_quadrant(TM0, TN0, TZ, I1(), I1());                               \
+        if ((Q) == 3) store_quadrant(TM0, TN0, TZ, I1(), I0());                               \
+    } while (0)
+#define Q8_SB() __builtin_amdgcn_sched_barrier(0)
+    // one group of a K tile: 8 MFMAs on group (CM, CN) with the six fragment reads of the NEXT group (NM, NN) <- k-step NKS of the
+    // K tile at NSK issued one by one between them.  DA / DB: DMA half-tile parts of this group (-1: none), one instruction per
+    // slot; wave row 0 issues in the slots after MFMA 0-3, wave row 1 after MFMA 4-7: an LDS-DMA issue blocks its wave for
+    // 60-180 cycles (the CU's address path takes one wave instruction at a time) and the two waves of a SIMD are in lock step,
+    // so with both in the same slot the matrix pipe would idle; this way the SIMD's other wave multiplies meanwhile.
+    // EPI_HOOK: the previous output tile's quadrants are stored ahead of the MFMAs that overwrite them.  No explicit wait
+    // for (CM, CN): hipcc counts the ds_reads itself (lgkmcnt(n) per MFMA).
+#define Q8_DMA_SLOT(J, DA, DB)                                                                                           \
+    do {                                                                                                                 \
+        if (((J) & 3) == 0 && (DA) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DA) < 0 ? 0 : (DA), 1); Q8_SB(); }          \
+        if (((J) & 3) == 1 && (DA) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DA) < 0 ? 0 : (DA), 2); Q8_SB(); }          \
+        if (((J) & 3) == 2 && (DB) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DB) < 0 ? 0 : (DB), 1); Q8_SB(); }          \
+        if (((J) & 3) == 3 && (DB) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DB) < 0 ? 0 : (DB), 2); Q8_SB(); }          \
+    } while (0)
+#define Q8_GROUP(CM, CN, NM, NN, NSK, NKS, DA, DB, EPI_HOOK, ZERO)                                                       \
+    do {                                                                                                                 \
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                                                   \
+        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); } Q8_SB(); }                                       \
+        Q8_MFMA1(CM, CN, 0, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 0); Q8_SB(); Q8_DMA_SLOT(0, DA, DB);                \
+        Q8_MFMA1(CM, CN, 1, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 1); Q8_SB(); Q8_DMA_SLOT(1, DA, DB);                \
+        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 1); } Q8_SB(); }                                       \
+        Q8_MFMA1(CM, CN, 2, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 2); Q8_SB(); Q8_DMA_SLOT(2, DA, DB);                \
+        Q8_MFMA1(CM, CN, 3, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 3); Q8_SB(); Q8_DMA_SLOT(3, DA, DB);                \
+        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 2); } Q8_SB(); }                                       \
+        Q8_MFMA1(CM, CN, 4, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 4); Q8_SB(); Q8_DMA_SLOT(4, DA, DB);                \
+        Q8_MFMA1(CM, CN, 5, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 5); Q8_SB(); Q8_DMA_SLOT(5, DA, DB);                \
+        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 3); } Q8_SB(); }                                       \
+        Q8_MFMA1(CM, CN, 6, ZERO); Q8_SB(); Q8_DMA_SLOT(6, DA, DB);                                                      \
+        Q8_MFMA1(CM, CN, 7, ZERO); Q8_SB(); Q8_DMA_SLOT(7, DA, DB);                                                      \
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);                                                                   \
+    } while (0)
 
-    // ---- one K tile.  FIRST: first K tile of an output tile (C = 0; the previous tile's last quadrant is stored at its start).
-    // LAST: last K tile (quadrants stored as they become final).  Literal flags: three straight-line copies of the body, so that
-    // no accumulator is live across a branch that writes it (which costs a second register copy of all of them).
-    // Vector-memory operations issued after the DMA in one K tile: FIRST (with a pending tile) NST stores, LAST 3*NST stores.
+    // ---- one K tile = four groups (k-steps of 16), fragments double-buffered X/Y one group ahead.
+    // FIRST: first K tile of an output tile: the previous tile's quadrants are stored between the quadrants of group 0, whose
+    //        MFMAs start from C = 0; its DMA was issued whole at the previous tile's last barrier, so groups 0-1 issue none.
+    // LAST:  last K tile: at its barrier the whole next-but-one K tile is issued (before the epilogue's stores: counted waits).
+    // Literal flags: three straight-line copies of the body (no accumulator is live across a branch that writes it).
 #define Q8_KTILE(FIRST, LAST)                                                                                            \
     do {                                                                                                                 \
         const unsigned char* sK = lds + rslot * (4 * Q8_HALF);                                                           \
-        if (wr == 1) { Q8_STAGE_KTILE(); __builtin_amdgcn_sched_barrier(0); }                                            \
-        Q8_READ_STEP0();                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (wr == 0) { Q8_STAGE_KTILE(); __builtin_amdgcn_sched_barrier(0); }                                            \
-        if ((FIRST) && have_pend) store_quadrant(pm0, pn0, pz, I1(), I0());                                              \
-        Q8_MFMA(0, 0, FIRST);                                                                                            \
-        if (LAST) store_quadrant(cm0, cn0, cz, I0(), I0());                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_READ_FN(1);                                                                                                   \
-        Q8_MFMA(0, 1, FIRST);                                                                                            \
-        if (LAST) store_quadrant(cm0, cn0, cz, I0(), I1());                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_READ_FM(1);                                                                                                   \
-        Q8_MFMA(1, 1, FIRST);                                                                                            \
-        if (LAST) store_quadrant(cm0, cn0, cz, I1(), I1());                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        Q8_READ_FN(0);                                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (wr == 0) {                                                                                                   \
-            Q8_MFMA(1, 0, FIRST);                                                                                        \
-            if ((FIRST) && have_pend) Q8_WAIT_DMA(NST); else if (LAST) Q8_WAIT_DMA(3 * NST); else Q8_WAIT_DMA(0);        \
-            __builtin_amdgcn_s_barrier();                                                                                \
-        } else {                                                                                                         \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* my reads of this K tile are done before its slot is refilled */ \
-            if ((FIRST) && have_pend) Q8_WAIT_DMA(NST); else if (LAST) Q8_WAIT_DMA(3 * NST); else Q8_WAIT_DMA(0);        \
-            __builtin_amdgcn_s_barrier();                                                                                \
-            Q8_MFMA(1, 0, FIRST);                                                                                        \
-        }                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        const unsigned char* sN = lds + (rslot ^ 1) * (4 * Q8_HALF);                                                     \
+        Q8_GROUP(xm, xn, ym, yn, sK, 1, (FIRST) ? -1 : 1, (FIRST) ? -1 : 2, FIRST, FIRST);                               \
+        Q8_GROUP(ym, yn, xm, xn, sK, 2, (FIRST) ? -1 : 3, -1, false, false);                                             \
+        Q8_GROUP(xm, xn, ym, yn, sK, 3, -1, -1, false, false);                                                           \
+        /* group 3: all my reads of this K tile are done; my DMA of the next K tile has landed; barrier = published + slot free */ \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+        if ((FIRST) && have_pend) Q8_WAIT_DMA(4 * NST); else Q8_WAIT_DMA(0);                                             \
+        if (!(DBG & 16)) __builtin_amdgcn_s_barrier();                                                                   \
+        Q8_SB();                                                                                                         \
+        if (LAST) { Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3); Q8_SB(); }                   \
+        Q8_GROUP(ym, yn, xm, xn, sN, 0, (LAST) ? -1 : 0, -1, false, false);                                              \
         rslot ^= 1;                                                                                                      \
     } while (0)
+
+    // prologue: K tiles 0 and 1 issued, K tile 0 landed and published, its first group requested
+    Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
+    const bool two_ = !pdone;
+    Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
+    if (two_) Q8_WAIT_DMA(8); else Q8_WAIT_DMA(0);
+    __builtin_amdgcn_s_barrier();
+    Q8_READ_GROUP(xm, xn, lds, 0);
+    if ((DBG & 32) && A_KC && B_KC) {   // timing decomposition: real (random) fragments, read once and never again
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xm[i] = *reinterpret_cast<const hw_bf16x8*>(lds + offM[0] + i * 4096);
+            ym[i] = *reinterpret_cast<const hw_bf16x8*>(lds + offM[1] + i * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            xn[i] = *reinterpret_cast<const hw_bf16x8*>(lds + offN[0] + i * 4096);
+            yn[i] = *reinterpret_cast<const hw_bf16x8*>(lds + offN[1] + i * 4096);
+        }
+    }
 
     // ---- main loop over this workgroup's output tiles (every tile has at least two K tiles: the host guarantees K/split >= 128)
     bool have_pend = false;
@@ -448,13 +464,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         Q8_KTILE(false, true);
         have_pend = true; pm0 = cm0; pn0 = cn0; pz = cz;
     }
-    if (have_pend) store_quadrant(pm0, pn0, pz, I1(), I0());
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the dangling request of the group after the last
+    if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); }
+#undef Q8_GROUP
+#undef Q8_STORE_Q
+#undef Q8_SB
+#undef Q8_READ_GROUP
+#undef Q8_MFMA1
+#undef Q8_RD1
+#undef Q8_STAGE_PART
+#undef Q8_STAGE_PCS
+#undef Q8_DMA_SLOT
 #undef Q8_KTILE
-#undef Q8_STAGE_KTILE
 #undef Q8_NEXT_ITEM
 #undef Q8_WAIT_DMA
-#undef Q8_READ_FM
-#undef Q8_READ_STEP0
-#undef Q8_READ_FN
-#undef Q8_MFMA
 }

@@ -41,6 +41,7 @@ static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
     if (a_kc && b_kc) {
         if (epi == 1) { if (dbg == 1) return V(true, true, 1, 1); if (dbg == 2) return V(true, true, 1, 2); if (dbg == 4) return V(true, true, 1, 4);
                         if (dbg == 3) return V(true, true, 1, 3); if (dbg == 6) return V(true, true, 1, 6); if (dbg == 5) return V(true, true, 1, 5);
+                        if (dbg == 22) return V(true, true, 1, 22); if (dbg == 38) return V(true, true, 1, 38); if (dbg == 54) return V(true, true, 1, 54);
                         if (dbg == 8) return V(true, true, 1, 8); if (dbg == 12) return V(true, true, 1, 12); if (dbg == 14) return V(true, true, 1, 14);
                         return V(true, true, 1, 0); }
         if (epi == 0) { if (dbg == 8) return V(true, true, 0, 8); return V(true, true, 0, 0); }
