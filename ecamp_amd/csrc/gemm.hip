@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "gemm_args.h"
+#include "gemm_q8.h"
 
 // =============================================================================================
 // bf16
@@ -931,9 +932,59 @@ static bool p8_selected(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int
     return (a_kc != 0) == (b_kc != 0);
 }
 
+// ---- Q8 (gemm_q8.h): the round-2 persistent kernel.  ECAMP_GEMM_Q8 / option "q8_mode": -1 automatic (default), 0 never, 2 whenever legal.
+static int g_q8_mode = -2;
+static int q8_env() {
+    static const int v = getenv("ECAMP_GEMM_Q8") ? atoi(getenv("ECAMP_GEMM_Q8")) : -1;
+    return g_q8_mode != -2 ? g_q8_mode : v;
+}
+// epilogue variant of a call (-1: none fits)
+static int q8_epi(const float* bias, const void* residual, const void* pre_out, const void* gmul, int act, int out_f32) {
+    if (out_f32) return (!bias && !residual && !pre_out && !gmul && !act) ? 4 : -1;
+    if (gmul) return (!bias && !pre_out && !act) ? 3 : -1;
+    if (pre_out || act) return (pre_out && act == 1 && !residual) ? 1 : -1;
+    if (residual) return 2;
+    return 0;
+}
+static long g_q8_launches = 0;
+extern "C" int64_t ecamp_gemm_q8_launches(void) { return g_q8_launches; }
+typedef void (*q8_fn)(GemmArgs);
+static q8_fn q8_pick(int a_kc, int b_kc, int epi, bool rowsum) {
+    if (a_kc && b_kc) return epi == 0 ? gemm_bf16_q8_kernel<true, true, 0> : epi == 1 ? gemm_bf16_q8_kernel<true, true, 1> : epi == 2 ? gemm_bf16_q8_kernel<true, true, 2> : (q8_fn) nullptr;
+    if (a_kc && !b_kc) return epi == 0 ? gemm_bf16_q8_kernel<true, false, 0> : epi == 2 ? gemm_bf16_q8_kernel<true, false, 2> : epi == 3 ? gemm_bf16_q8_kernel<true, false, 3> : (q8_fn) nullptr;
+    if (!a_kc && !b_kc && epi == 4) return rowsum ? gemm_bf16_q8_kernel<false, false, 4, 0, true> : gemm_bf16_q8_kernel<false, false, 4, 0, false>;
+    return nullptr;
+}
+static bool q8_legal(const void* A, const void* B, const void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda, int b_kc, int64_t ldb, int64_t ldc,
+                     const float* bias, const void* residual, int64_t ldr, const void* pre_out, int64_t ldp, const void* gmul, int64_t ldg, int act,
+                     int dtype, int out_f32, int split_k, const float* splitk_ws, const float* rowsum) {
+    if (dtype != ECAMP_BF16) return false;
+    const int epi = q8_epi(bias, residual, pre_out, gmul, act, out_f32);
+    if (epi < 0 || !q8_pick(a_kc, b_kc, epi, rowsum != nullptr)) return false;
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1 && epi != 4) return false;
+    long kps = (K + split_k - 1) / split_k;
+    kps = (kps + 63) / 64 * 64;
+    const long ns = (K + kps - 1) / kps, last = K - (ns - 1) * kps;
+    if (kps < 128 || last <= 64) return false;   // every work item (the last slice included) has at least two K tiles
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const long lim = 0x7fffffffl;
+    if (N % 8 || lda % 8 || ldb % 8 || !al16(A) || !al16(B) || !al16(C)) return false;
+    if ((a_kc ? M * lda : K * lda) * 2 > lim || (b_kc ? N * ldb : K * ldb) * 2 > lim) return false;
+    if (!a_kc && M % 8) return false;
+    if (split_k > 1) { if (!al16(splitk_ws) || (long)split_k * M * N * 4 > lim) return false; }
+    else if (ldc % 8 || M * ldc * (epi == 4 ? 4 : 2) > lim) return false;
+    if (bias && !al16(bias)) return false;
+    if (pre_out && (ldp % 8 || !al16(pre_out) || M * ldp * 2 > lim)) return false;
+    if (gmul && (ldg % 8 || !al16(gmul) || M * ldg * 2 > lim)) return false;
+    if (residual && (ldr % 8 || !al16(residual) || M * ldr * 2 > lim)) return false;
+    return true;
+}
+
 extern "C" int ecamp_set_option(const char* name, int32_t value) {
     ECAMP_CHECK_ARG(name != nullptr, "set_option: null name");
     if (strcmp(name, "p8_mode") == 0) { g_p8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 always
+    if (strcmp(name, "q8_mode") == 0) { g_q8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 whenever legal
     if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
     return ecamp_set_error(-1, "set_option: unknown option '%s'", name);
@@ -1008,6 +1059,43 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     if (split_k > 1) { g.alpha = 1.0f; g.alpha_dev = nullptr; }
     g.nbm = ceil_div(M, BM); g.nbn = ceil_div(N, BN);
     dim3 grid(g.nbm * g.nbn, 1, split_k), block(256);
+    {
+        const int q8m = q8_env();
+        const long items8 = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
+        if (q8m != 0 && (q8m == 2 || items8 >= (long)(0.75 * p8_num_cu())) &&
+            q8_legal(A, B, C, M, N, K, a_kc, lda, b_kc, ldb, ldc, bias, residual, ldr, pre_out, ldp, gmul, ldg, act, dtype, g.out_f32, split_k, splitk_ws, rowsum)) {
+            const int epi = q8_epi(bias, residual, pre_out, gmul, act, g.out_f32);
+            const q8_fn fn = q8_pick(a_kc, b_kc, epi, rowsum != nullptr);
+            g.nbm = ceil_div(M, 256); g.nbn = ceil_div(N, 256);
+            g.nsplit = split_k; g.wide = 1;
+            int ncu = p8_num_cu();
+            if (!(a_kc && b_kc) && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;
+            const long total8 = (long)g.nbm * g.nbn * split_k;
+            const size_t shm = 10 * Q8_HALF;   // the whole 160 KB LDS of a CU
+            static q8_fn attr_done[16];
+            static int n_attr = 0;
+            bool seen = false;
+            for (int i = 0; i < n_attr; ++i) seen = seen || attr_done[i] == fn;
+            if (!seen) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                if (n_attr < 16) attr_done[n_attr++] = fn;
+            }
+            const bool prof8 = ecamp_prof_active();
+            if (prof8) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream);
+            hipLaunchKernelGGL(fn, dim3((unsigned)(total8 < ncu ? total8 : ncu)), dim3(512), shm, stream, g);
+            ++g_q8_launches;
+            if (split_k > 1) {
+                long n4 = M * N / 4;
+                int nb = (int)((n4 + 255) / 256);
+                if (nb > 2048) nb = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, splitk_ws, reinterpret_cast<float*>(C), (long)M, (long)N,
+                                   (long)ldc, split_k, alpha, alpha_dev, accumulate);
+            }
+            if (prof8) ecamp_prof_end(stream);
+            ECAMP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (p8_selected(M, N, K, a_kc, b_kc, dtype, split_k)) {
         const int nbm8 = ceil_div(M, 256), nbn8 = ceil_div(N, 256);
         {

@@ -1,27 +1,30 @@
 // "Q8": persistent 256x256x64 bf16 GEMM on v_mfma_f32_32x32x16_bf16, eight waves (2 x 4) of 128x64, one workgroup per CU.
 //
-// Structure (round 2; replaces the K=32 DMA-ring kernel "P8" of round 1 wherever it applied):
-//  * K tile = 64, two K tiles resident in LDS (128 KB).  Each operand tile is two HALF-TILES of 128 rows (A_0/A_1: the rows of
-//    wave row 0/1; B_0/B_1: the columns of wave columns 0-1 / 2-3), 16 KB each, filled by direct L2->LDS DMA
-//    (buffer_load_dwordx4 ... lds: 8 instructions per wave per K tile) through per-half-tile buffer descriptors built with scalar
-//    ALU only: the per-lane offsets are kernel constants and rows / contraction steps past the end read as zero.
-//  * A K tile is FOUR STEPS per wave, one 64x32 quadrant of the wave's 128x64 block each: {4, 8 or 12 ds_read_b128; 8 MFMAs of
-//    32x32x16 = 256 matrix cycles}, quadrants (m0,n0) (m0,n1) (m1,n1) (m1,n0) so that consecutive steps share one operand.
-//  * ONE s_barrier per K tile.  Wave row 0 meets it after its last MFMA step, wave row 1 BEFORE its last MFMA step: after every
-//    barrier the two waves of a SIMD (w and w+4) start in opposite halves of a step -- one multiplies while the other reads LDS /
-//    issues DMA -- and nothing re-synchronises them inside the K tile, so the matrix pipe is handed back and forth by
-//    the hardware arbiter instead of by barriers (the first version had two barriers per step: 130 idle matrix cycles each).
-//  * The DMA of K tile t+1 is issued right after the barrier that retires K tile t-1 (whose slots it overwrites) and is waited for,
-//    with a counted s_waitcnt, just before the next barrier: a full K tile of latency cover.  The K-tile stream is ONE flat
-//    sequence over all the output tiles a workgroup processes, so the next tile's first K tile is in LDS before the current
-//    tile's epilogue starts.
-//  * Epilogue in four pieces: quadrant q of an output tile is final after step q of the tile's last K tile and is stored right
-//    after that step (the last one after the barrier, in the first K tile of the next output tile, whose MFMAs start from C = 0).
-//    The stores are buffer stores (bounds by descriptor, no exec-masked branches), so their COUNT is exact and the DMA wait
-//    can be "all but the n stores issued after the DMA": vmcnt retires in order on gfx9 and loads and stores share it -- a
-//    counted wait is never early, and with the DMA issued ahead of a K tile's stores it never waits for fresh stores either.
+// What the measurements on MI355X say (tools/gemm_lab, profiles/r02_gemm_lab_*.txt) and how the kernel answers them:
+//  * With random operands the matrix pipes are power-limited: a pure MFMA stream (no LDS, no DMA) runs at ~1.6 PFLOP/s, and the
+//    L2->LDS DMA path tops out at ~14 TB/s chip-wide (~26 B/clk/CU).  A 256^2 tile needs 64 KB per K=64 tile: 1.18 us of DMA
+//    against 1.33 us of MFMA.  Both are near saturation, so the loop is built to keep BOTH queues non-empty all the time.
+//  * Operand tiles are HALF-TILES of 128 rows x 64 k (16 KB: A_0/A_1 = rows of wave row 0/1, B_0/B_1 = columns of wave columns
+//    0-1 / 2-3) in two rings of 5 slots (all 160 KB of LDS = 2.5 K tiles).  They are filled by buffer_load_dwordx4 ... lds through
+//    per-half-tile descriptors built with scalar ALU only (per-lane offsets are kernel constants; rows / contraction steps past
+//    the end read as zero).  ONE half-tile (2 instructions per wave) is issued per MFMA group, 4 to 6 groups ahead of its use, so
+//    the DMA engine always has work queued; it is waited for with a counted s_waitcnt once per K tile.
+//  * A K tile is four GROUPS (k-steps of 16): 8 independent MFMAs (the wave's 4 x 2 tiles of 32x32) on 4 + 2 fragments that were
+//    read from LDS one group earlier into the other half of a register double buffer, the 6 reads of the NEXT group being issued
+//    one by one between this group's MFMAs.  No MFMA ever waits for LDS latency and the accumulators are never dependent
+//    within 8 instructions.  The loop with DMA and epilogue removed reaches 93 % of the pure-MFMA rate.
+//  * ONE s_barrier per K tile, at the start of group 3: by then a wave has received every fragment of this K tile (slot
+//    free) and has waited for its own DMA pieces of the next one (published).
+//  * LDS-DMA issue blocks the issuing wave (the CU's address path takes one wave instruction at a time): wave row 0 issues in the
+//    first half of a group, wave row 1 in the second, so the other wave of the SIMD keeps multiplying.
+//  * Epilogue: the previous output tile's quadrants are stored between the quadrants of the first group of the next tile, whose
+//    MFMAs start from C = 0 (no accumulator copy, no drain).  Buffer stores (bounds by descriptor, no exec-masked branches), so
+//    their COUNT is exact: vmcnt retires in order on gfx9 and loads and stores share it, and the one DMA wait that follows a
+//    tile's stores excludes exactly those stores.
 //  * LDS images are DMA-linear (128-B rows, 8 rows per wave piece); the bank swizzle (16-B chunk ^ ((row >> 1) & 7)) is applied
-//    to the lane's SOURCE offset and again on the fragment reads (conflict-free for the 32-row b128 fragments, both row maps).
+//    to the lane's SOURCE offset and again on the fragment reads (conflict-free for the 32-row b128 fragments, both row maps:
+//    SQ_LDS_BANK_CONFLICT = 0).  Strided operands stay as they lie in HBM (64 k-rows x 256 B) and are read with
+//    ds_read_b64_tr_b16 -- through inline asm: hipcc puts s_waitcnt vmcnt(0) in front of the builtin whenever an LDS-DMA is in flight.
 //  * N-side fragment row i is mapped to tile column (i&3) | i3<<2 | i2<<3 | i4<<4, so that with the N fragment as the MFMA's
 //    A operand a lane ends up with 8 consecutive output columns per 8 accumulator registers: every epilogue access is 16 B.
 #pragma once
@@ -95,6 +98,36 @@ __device__ __forceinline__ void q8_stage_half(const unsigned char* base, int rec
     if (PIECES & 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + 8192 + wave * 1024), 16, (int)v1, 0, 0, 0);
 }
 
+// ---- fragment registers ----------------------------------------------------------------------------------------------------------
+// contraction-contiguous operand: one ds_read_b128 that hipcc tracks itself.  Strided operand: two ds_read_b64_tr_b16 in inline
+// asm (see header); the halves stay separate values until `wait()` has named them after an explicit s_waitcnt lgkmcnt(0).
+template <bool KC> struct Q8Frag;
+template <> struct Q8Frag<true> {
+    hw_bf16x8 v;
+    template <int OFF> __device__ __forceinline__ void read(const unsigned char* p) { v = *reinterpret_cast<const hw_bf16x8*>(p + OFF); }
+    __device__ __forceinline__ hw_bf16x8 get() const { return v; }
+};
+template <> struct Q8Frag<false> {
+    q8_v4s16 lo, hi;
+    template <int OFF> __device__ __forceinline__ void read(const unsigned char* p) {
+        const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(OFF + 4 * 256));
+    }
+    __device__ __forceinline__ hw_bf16x8 get() const {
+        return __builtin_bit_cast(hw_bf16x8, (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    }
+};
+// the explicit wait of a group whose fragments include asm reads: names every half so no consumer is scheduled above it
+__device__ __forceinline__ void q8_wait4(Q8Frag<false> (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo), "+v"(f[3].hi));
+}
+__device__ __forceinline__ void q8_wait2(Q8Frag<false> (&f)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi));
+}
+__device__ __forceinline__ void q8_wait4(Q8Frag<true> (&)[4]) {}
+__device__ __forceinline__ void q8_wait2(Q8Frag<true> (&)[2]) {}
+
 // ---- epilogue of 8 consecutive outputs of one row (the host only selects this kernel when every [M, ld] epilogue operand is
 // 16-B aligned at 8-column granularity, N % 8 == 0 and every matrix is < 2 GB).  EPI is a compile-time selection of what the
 // epilogue can do -- with every option tested at run time the epilogue's branches push the kernel over its 256 registers:
@@ -109,11 +142,16 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
 }
 
 // DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 8 = no s_setprio, 16 = no barrier in the
-// loop, 32 = no fragment reads (timing decomposition only: 16 and 32 give wrong results)
-template <bool A_KC, bool B_KC, int EPI, int DBG = 0>
+// loop, 32 = no fragment reads, 64 = every DMA re-reads the tile's first K tile (timing decomposition only: 16, 32, 64 give wrong results)
+// ROWSUM (weight-gradient form only): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient -- summed on the VALU from the M-side
+// fragments by the first wave column of the tiles in the first N-tile column, added with 4 buffer atomics per wave and tile.
+template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false>
 __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
-    constexpr int NST = Q8Epi<EPI>::NST;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // K tile 0 {A_0 A_1 B_0 B_1} | K tile 1; the ONLY LDS object
+    static_assert(!ROWSUM || (!A_KC && !B_KC && EPI == 4), "rowsum is built for the weight-gradient form");
+    constexpr int NST = (DBG & 4) ? 0 : Q8Epi<EPI>::NST;   // stores per quadrant (none in the no-epilogue timing variant)
+    constexpr int NSLOT = 5;                          // half-tile slots per operand ring
+    constexpr int ST_AUX = (DBG & 128) ? 2 : (DBG & 256) ? 16 : 0;   // cache policy of the bf16 output stores: 2 = nt, 16 = sc1 (write-through)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // A ring (5 x 16 KB) | B ring (5 x 16 KB); the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int total = g.nbm * g.nbn * g.nsplit, G = (int)gridDim.x;
@@ -123,31 +161,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     // N-side fragment row -> tile column (see header)
     const int ncol = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | ((l31 >> 4) << 4);
 
-    // per-lane fragment offsets inside a half-tile (without K-tile base and quadrant offset)
-    //   kc: row*128 + ((2*ks + lh) ^ key(row)) * 16, one per k-step (the XOR does not commute with the k-step offset)
-    //   oc: (ks*16 + 8*kb + r)*256 + ((chunk ^ (r<<2)) * 16) + within, one per 32-output tile index (the XOR touches the tile bits)
+    // per-lane fragment offsets inside a half-tile
+    //   kc: row*128 + ((2*ks + lh) ^ key(row)) * 16, one per k-step (the XOR does not commute with the k-step offset); tile t at + t*4096
+    //   oc: (8*kb + r)*256 + ((chunk ^ (r<<2)) * 16) + within, one per 32-output tile (the XOR touches the tile bits); k-step ks at + ks*4096
     unsigned offM[4], offN[4];
     if (A_KC) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) offM[ks] = (unsigned)(wr * Q8_HALF + l31 * 128 + (((2 * ks + lh) ^ ((l31 >> 1) & 7)) << 4));
+        for (int ks = 0; ks < 4; ++ks) offM[ks] = (unsigned)(l31 * 128 + (((2 * ks + lh) ^ ((l31 >> 1) & 7)) << 4));
     } else {
         const int i16 = lane & 15, ob = (lane >> 4) & 1, kb = lane >> 5, r = i16 >> 2, q = i16 & 3;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {   // tile index t = 2*mh + tm of the wave's 128 rows
+        for (int t = 0; t < 4; ++t) {   // 32-row tile t of the wave's 128 rows
             const int col = t * 32 + 16 * ob + 4 * q;
-            offM[t] = (unsigned)(wr * Q8_HALF + (8 * kb + r) * 256 + ((((col >> 3) ^ (r << 2)) & 15) << 4) + (col & 7) * 2);
+            offM[t] = (unsigned)((8 * kb + r) * 256 + ((((col >> 3) ^ (r << 2)) & 15) << 4) + (col & 7) * 2);
         }
     }
     if (B_KC) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            offN[ks] = (unsigned)((2 + (wc >> 1)) * Q8_HALF + ((wc & 1) * 64 + ncol) * 128 + (((2 * ks + lh) ^ ((ncol >> 1) & 7)) << 4));
+        for (int ks = 0; ks < 4; ++ks) offN[ks] = (unsigned)(((wc & 1) * 64 + ncol) * 128 + (((2 * ks + lh) ^ ((ncol >> 1) & 7)) << 4));
     } else {
         const int i16 = lane & 15, ob = (lane >> 4) & 1, kb = lane >> 5, r = i16 >> 2, q = i16 & 3;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {   // t = nh; the pointer of quarter q covers the 4 outputs at 4*(q>>1) + 8*(q&1) (column remap)
+        for (int t = 0; t < 2; ++t) {   // the pointer of quarter q covers the 4 outputs at 4*(q>>1) + 8*(q&1) (column remap)
             const int col = (wc & 1) * 64 + t * 32 + 16 * ob + 4 * (q >> 1) + 8 * (q & 1);
-            offN[t] = (unsigned)((2 + (wc >> 1)) * Q8_HALF + (8 * kb + r) * 256 + ((((col >> 3) ^ (r << 2)) & 15) << 4) + (col & 7) * 2);
+            offN[t] = (unsigned)((8 * kb + r) * 256 + ((((col >> 3) ^ (r << 2)) & 15) << 4) + (col & 7) * 2);
         }
         offN[2] = offN[3] = 0;
     }
@@ -155,7 +192,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     f32x16 acc[4][2];
 
     // ---- DMA cursor over the flat K-tile stream; all of it wave-uniform (SGPRs): byte cursors of the A and B half-tile 0 of the
-    // K tile to stage next, bytes left in their valid ranges, contraction elements left in the staged output tile
+    // K tile being staged, bytes left in their valid ranges, contraction elements left in the staged output tile.  The four parts
+    // of a K tile are staged in the order A_0, B_0 ("early": their ring slots were vacated two K tiles ago), A_1, B_1 ("late").
     int pv = (int)blockIdx.x;
     bool pdone = pv >= total;
     const unsigned char *sa_base, *sb_base;
@@ -172,26 +210,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         else      { sb_base = (const unsigned char*)(B + ((long)n_.kbeg * g.ldb + n_.n0)); sb_rec = (int)(((long)p_krem * g.ldb - n_.n0) * 2); }             \
     } while (0)
     if (!pdone) Q8_NEXT_ITEM();
-    int wslot = 0;                                     // K-tile slot (0/1) the next staged K tile goes to
+    int wA = 0, wB = 0;                                // ring slots the next A / B half-tile goes to
     unsigned voffA[2], voffB[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { voffA[i] = q8_voff<A_KC>(i, wave, lane, g.lda); voffB[i] = q8_voff<B_KC>(i, wave, lane, g.ldb); }
-    // stage pieces PCS (bit 0: piece `wave`, bit 1: piece `8 + wave`) of half-tile PART (0: A_0, 1: A_1, 2: B_0, 3: B_1) of the next
-    // K tile of the stream; the cursor moves on with the second piece of part 3
+    // stage pieces PCS (bit 0: piece `wave`, bit 1: piece `8 + wave`) of part PART (0: A_0, 1: B_0, 2: A_1, 3: B_1) of the K tile
+    // being staged; the cursor moves on with the second piece of part 3
 #define Q8_STAGE_PCS(PART, PCS)                                                                                          \
     do {                                                                                                                 \
         if (!pdone) {                                                                                                    \
-            unsigned char* d_ = lds + wslot * (4 * Q8_HALF) + (PART) * Q8_HALF;                                          \
             if (!(DBG & 2)) {                                                                                            \
-                if ((PART) == 0) q8_stage_half<A_KC, (PCS)>(sa_base, sa_rec, p_krem, d_, voffA, wave, lane);             \
-                if ((PART) == 1) q8_stage_half<A_KC, (PCS)>(sa_base + a_half, sa_rec - a_half, p_krem, d_, voffA, wave, lane);  \
-                if ((PART) == 2) q8_stage_half<B_KC, (PCS)>(sb_base, sb_rec, p_krem, d_, voffB, wave, lane);             \
-                if ((PART) == 3) q8_stage_half<B_KC, (PCS)>(sb_base + b_half, sb_rec - b_half, p_krem, d_, voffB, wave, lane);  \
+                if ((PART) == 0) q8_stage_half<A_KC, (PCS)>(sa_base, sa_rec, p_krem, lds + wA * Q8_HALF, voffA, wave, lane);                       \
+                if ((PART) == 1) q8_stage_half<B_KC, (PCS)>(sb_base, sb_rec, p_krem, lds + (NSLOT + wB) * Q8_HALF, voffB, wave, lane);             \
+                if ((PART) == 2) q8_stage_half<A_KC, (PCS)>(sa_base + a_half, sa_rec - a_half, p_krem, lds + wA * Q8_HALF, voffA, wave, lane);     \
+                if ((PART) == 3) q8_stage_half<B_KC, (PCS)>(sb_base + b_half, sb_rec - b_half, p_krem, lds + (NSLOT + wB) * Q8_HALF, voffB, wave, lane); \
+            }                                                                                                            \
+            if ((PCS) & 2) {                                                                                             \
+                if ((PART) == 0 || (PART) == 2) wA = wA == NSLOT - 1 ? 0 : wA + 1; else wB = wB == NSLOT - 1 ? 0 : wB + 1; \
             }                                                                                                            \
             if ((PART) == 3 && ((PCS) & 2)) {                                                                            \
-                wslot ^= 1;                                                                                              \
                 p_krem -= 64;                                                                                            \
-                sa_base += a_step; sa_rec -= a_step; sb_base += b_step; sb_rec -= b_step;                                \
+                if (!(DBG & 64)) { sa_base += a_step; sa_rec -= a_step; sb_base += b_step; sb_rec -= b_step; }           \
                 if (p_krem <= 0) {                                                                                       \
                     pv += G;                                                                                             \
                     if (pv < total) Q8_NEXT_ITEM(); else pdone = true;                                                   \
@@ -200,47 +239,45 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         }                                                                                                                \
     } while (0)
 #define Q8_STAGE_PART(PART) Q8_STAGE_PCS(PART, 3)
-    // every DMA of mine has landed, except that the `N_` youngest vector-memory operations (stores issued after it) may be pending
+    // every DMA of mine has landed, except that the `N_` youngest vector-memory operations (issued after it) may be pending
 #define Q8_WAIT_DMA(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
 
-    hw_bf16x8 xm[4] = {}, xn[2] = {}, ym[4] = {}, yn[2] = {};   // two fragment groups (one k-step of 16 each): 4 M-side + 2 N-side
-    int rslot = 0;                                    // K-tile slot being multiplied
+    Q8Frag<A_KC> xm[4], ym[4];                        // two fragment groups (one k-step of 16 each): 4 M-side + 2 N-side
+    Q8Frag<B_KC> xn[2], yn[2];
+    int rA = 0, rB = 0;                               // ring slots of A_0 / B_0 of the K tile being multiplied
+    float rs[4] = {0.f, 0.f, 0.f, 0.f}, rsp[4] = {0.f, 0.f, 0.f, 0.f};   // ROWSUM: running / finished-tile partial sums of row l31 of tile tm
+    bool rs_on = false, rsp_on = false;
+    int rsp_m0 = 0;
+    // this lane's 8 contraction values of M-side fragment F summed into S (strided operand: lo/hi halves)
+#define Q8_RS_ACC(FM)                                                                                                    \
+    do {                                                                                                                 \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                               \
+            const hw_bf16x8 f_ = FM[t_].get();                                                                           \
+            const bf16x8 b_ = __builtin_bit_cast(bf16x8, f_);                                                            \
+            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) rs[t_] += bf2f((bf16_t)b_[e_]);                             \
+        }                                                                                                                \
+    } while (0)
 
-    // fragment I (0..5, in the order the MFMAs consume them: n0 m0 m1 n1 m2 m3) of k-step KS of the K tile at SK into group (FM, FN)
-#define Q8_RD1(FM, FN, SK, KS, I)                                                                                        \
+    // fragment I (0..5, in the order the MFMAs consume them: n0 m0 m1 n1 m2 m3) of k-step KS from the half-tiles at SM / SN
+#define Q8_RD1(FM, FN, SM, SN, KS, I)                                                                                    \
     do {                                                                                                                 \
         constexpr int isn_ = ((I) == 0 || (I) == 3), idx_ = (I) == 0 ? 0 : (I) == 3 ? 1 : (I) < 3 ? (I) - 1 : (I) - 2;   \
         if (!(DBG & 32)) {                                                                                               \
-            if (isn_) {                                                                                                  \
-                if (B_KC) FN[idx_] = *reinterpret_cast<const hw_bf16x8*>((SK) + offN[KS] + idx_ * 32 * 128);             \
-                else {                                                                                                   \
-                    const unsigned char* p_ = (SK) + offN[idx_] + (KS) * 16 * 256;                                       \
-                    q8_v4s16 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_));            \
-                    q8_v4s16 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_ + 4 * 256));  \
-                    FN[idx_] = __builtin_bit_cast(hw_bf16x8, (bf16x8){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]});   \
-                }                                                                                                        \
-            } else {                                                                                                     \
-                if (A_KC) FM[idx_] = *reinterpret_cast<const hw_bf16x8*>((SK) + offM[KS] + idx_ * 32 * 128);             \
-                else {                                                                                                   \
-                    const unsigned char* p_ = (SK) + offM[idx_] + (KS) * 16 * 256;                                       \
-                    q8_v4s16 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_));            \
-                    q8_v4s16 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((q8_v4s16 __attribute__((address_space(3)))*)(p_ + 4 * 256));  \
-                    FM[idx_] = __builtin_bit_cast(hw_bf16x8, (bf16x8){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]});   \
-                }                                                                                                        \
-            }                                                                                                            \
+            if (isn_) { if (B_KC) FN[idx_].template read<idx_ * 4096>((SN) + offN[KS]); else FN[idx_].template read<(KS) * 4096>((SN) + offN[idx_]); } \
+            else      { if (A_KC) FM[idx_].template read<idx_ * 4096>((SM) + offM[KS]); else FM[idx_].template read<(KS) * 4096>((SM) + offM[idx_]); } \
         }                                                                                                                \
     } while (0)
-#define Q8_READ_GROUP(FM, FN, SK, KS) \
-    do { Q8_RD1(FM, FN, SK, KS, 0); Q8_RD1(FM, FN, SK, KS, 1); Q8_RD1(FM, FN, SK, KS, 2); Q8_RD1(FM, FN, SK, KS, 3); Q8_RD1(FM, FN, SK, KS, 4); Q8_RD1(FM, FN, SK, KS, 5); } while (0)
+#define Q8_READ_GROUP(FM, FN, SM, SN, KS) \
+    do { Q8_RD1(FM, FN, SM, SN, KS, 0); Q8_RD1(FM, FN, SM, SN, KS, 1); Q8_RD1(FM, FN, SM, SN, KS, 2); Q8_RD1(FM, FN, SM, SN, KS, 3); Q8_RD1(FM, FN, SM, SN, KS, 4); Q8_RD1(FM, FN, SM, SN, KS, 5); } while (0)
     // MFMA J (0..7) of a group: quadrants in the order (m0 n0) (m0 n1) (m1 n1) (m1 n0), two 32x32 tiles each
 #define Q8_MFMA1(FM, FN, J, ZERO)                                                                                        \
     do {                                                                                                                 \
         constexpr int q_ = (J) >> 1, mh_ = q_ >> 1, nh_ = (q_ == 1 || q_ == 2) ? 1 : 0, tm_ = 2 * mh_ + ((J) & 1);       \
         if (DBG & 1) {                                                                                                   \
-            asm volatile("" ::"v"(FN[nh_]), "v"(FM[tm_]));                                                               \
+            asm volatile("" ::"v"(FN[nh_].get()), "v"(FM[tm_].get()));                                                   \
             if (ZERO) acc[tm_][nh_] = zero16;                                                                            \
         } else {                                                                                                         \
-            acc[tm_][nh_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FN[nh_], FM[tm_], (ZERO) ? zero16 : acc[tm_][nh_], 0, 0, 0); \
+            acc[tm_][nh_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FN[nh_].get(), FM[tm_].get(), (ZERO) ? zero16 : acc[tm_][nh_], 0, 0, 0); \
         }                                                                                                                \
     } while (0)
 
@@ -306,7 +343,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 const long row = mb + tm * 32, col = nb + 16 * gq;
-                const bool oob = edge && (nb + 16 * gq + 8 * lh >= g.N);
+                // (rows past M fall outside the descriptors by themselves -- except inside the stack of split-K slabs)
+                const bool oob = (edge && (nb + 16 * gq + 8 * lh >= g.N)) || (EPI == 4 && g.partial && mb + tm * 32 + l31 >= g.M);
                 uo[tm][gq] = oob ? 0x80000000u : (unsigned)(((EPI == 4 && g.partial ? (long)tz * g.M : 0) + row) * ldo + col) * esz + lane_o;
                 if (EPI == 1) up[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldp + col) * 2) + lane_p;
                 if (EPI == 3) ug[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldg + col) * 2) + lane_g;
@@ -337,7 +375,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
                     for (int r = 0; r < 8; ++r) v[r] += bias[gq][r];
                 }
                 if (EPI == 1) {
-                    __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rP, up[tm][gq], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rP, up[tm][gq], 0, ST_AUX);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16_t>(rnd<bf16_t>(v[r]));
                 }
@@ -363,9 +401,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
                     __builtin_amdgcn_raw_buffer_store_b128((q8_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rC, uo[tm][gq], 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128((q8_u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rC, uo[tm][gq] + 16, 0, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rC, uo[tm][gq], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rC, uo[tm][gq], 0, ST_AUX);
                 }
             }
+    };
+    // ROWSUM: the finished tile's partial sums: the two k-halves of a row sit in lanes l and l+32; lanes < 32 add (buffer atomics:
+    // exactly 4 instructions whatever the bounds, like the stores)
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)(ROWSUM && g.rowsum ? (void*)g.rowsum : g.C), 0, (int)(unsigned)((long)g.M * 4), 0x00020000);
+    auto rowsum_flush = [&]() {
+        typedef const float __attribute__((address_space(4))) cfloat4;
+        float al = g.alpha_out;
+        if (g.alpha_dev_out) { float ad = *(cfloat4*)g.alpha_dev_out; asm volatile("" : "+s"(ad)); al *= ad; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float tot = (rsp[t] + __shfl_xor(rsp[t], 32, 64)) * al;
+            const unsigned off = lh ? 0x80000000u : (unsigned)((rsp_m0 + wr * 128 + t * 32 + l31) * 4);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, rS, off, 0, 0);
+        }
+        rsp_on = false;
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -379,12 +432,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     } while (0)
 #define Q8_SB() __builtin_amdgcn_sched_barrier(0)
     // one group of a K tile: 8 MFMAs on group (CM, CN) with the six fragment reads of the NEXT group (NM, NN) <- k-step NKS of the
-    // K tile at NSK issued one by one between them.  DA / DB: DMA half-tile parts of this group (-1: none), one instruction per
-    // slot; wave row 0 issues in the slots after MFMA 0-3, wave row 1 after MFMA 4-7: an LDS-DMA issue blocks its wave for
-    // 60-180 cycles (the CU's address path takes one wave instruction at a time) and the two waves of a SIMD are in lock step,
-    // so with both in the same slot the matrix pipe would idle; this way the SIMD's other wave multiplies meanwhile.
-    // EPI_HOOK: the previous output tile's quadrants are stored ahead of the MFMAs that overwrite them.  No explicit wait
-    // for (CM, CN): hipcc counts the ds_reads itself (lgkmcnt(n) per MFMA).
+    // half-tiles at NSM / NSN issued one by one between them, and the two DMA instructions of half-tile part D (-1: none; D2: a
+    // second part) -- wave row 0 in the slots after MFMA 0-3, wave row 1 after MFMA 4-7 (see header).  EPI_HOOK: the previous
+    // output tile's quadrants are stored ahead of the MFMAs that overwrite them.  Fragments read by hipcc-tracked loads need no
+    // explicit wait (lgkmcnt(n) per MFMA); asm transpose reads are waited for at the top.
 #define Q8_DMA_SLOT(J, DA, DB)                                                                                           \
     do {                                                                                                                 \
         if (((J) & 3) == 0 && (DA) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DA) < 0 ? 0 : (DA), 1); Q8_SB(); }          \
@@ -392,63 +443,75 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         if (((J) & 3) == 2 && (DB) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DB) < 0 ? 0 : (DB), 1); Q8_SB(); }          \
         if (((J) & 3) == 3 && (DB) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DB) < 0 ? 0 : (DB), 2); Q8_SB(); }          \
     } while (0)
-#define Q8_GROUP(CM, CN, NM, NN, NSK, NKS, DA, DB, EPI_HOOK, ZERO)                                                       \
+#define Q8_GROUP(CM, CN, NM, NN, NSM, NSN, NKS, DA, DB, EPI_HOOK, ZERO)                                                  \
     do {                                                                                                                 \
+        if (!A_KC || !B_KC) { q8_wait4(CM); q8_wait2(CN); Q8_SB(); }                                                     \
+        if (ROWSUM) { if (rs_on) { Q8_RS_ACC(CM); } Q8_SB(); }                                                           \
         if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                                                   \
         if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); } Q8_SB(); }                                       \
-        Q8_MFMA1(CM, CN, 0, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 0); Q8_SB(); Q8_DMA_SLOT(0, DA, DB);                \
-        Q8_MFMA1(CM, CN, 1, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 1); Q8_SB(); Q8_DMA_SLOT(1, DA, DB);                \
+        Q8_MFMA1(CM, CN, 0, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 0); Q8_SB(); Q8_DMA_SLOT(0, DA, DB);           \
+        Q8_MFMA1(CM, CN, 1, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 1); Q8_SB(); Q8_DMA_SLOT(1, DA, DB);           \
         if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 1); } Q8_SB(); }                                       \
-        Q8_MFMA1(CM, CN, 2, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 2); Q8_SB(); Q8_DMA_SLOT(2, DA, DB);                \
-        Q8_MFMA1(CM, CN, 3, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 3); Q8_SB(); Q8_DMA_SLOT(3, DA, DB);                \
+        Q8_MFMA1(CM, CN, 2, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 2); Q8_SB(); Q8_DMA_SLOT(2, DA, DB);           \
+        Q8_MFMA1(CM, CN, 3, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 3); Q8_SB(); Q8_DMA_SLOT(3, DA, DB);           \
         if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 2); } Q8_SB(); }                                       \
-        Q8_MFMA1(CM, CN, 4, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 4); Q8_SB(); Q8_DMA_SLOT(4, DA, DB);                \
-        Q8_MFMA1(CM, CN, 5, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSK, NKS, 5); Q8_SB(); Q8_DMA_SLOT(5, DA, DB);                \
-        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 3); } Q8_SB(); }                                       \
+        Q8_MFMA1(CM, CN, 4, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 4); Q8_SB(); Q8_DMA_SLOT(4, DA, DB);           \
+        Q8_MFMA1(CM, CN, 5, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 5); Q8_SB(); Q8_DMA_SLOT(5, DA, DB);           \
+        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 3); } if (ROWSUM) { if (rsp_on) rowsum_flush(); } Q8_SB(); } \
         Q8_MFMA1(CM, CN, 6, ZERO); Q8_SB(); Q8_DMA_SLOT(6, DA, DB);                                                      \
         Q8_MFMA1(CM, CN, 7, ZERO); Q8_SB(); Q8_DMA_SLOT(7, DA, DB);                                                      \
         if (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);                                                                   \
     } while (0)
 
-    // ---- one K tile = four groups (k-steps of 16), fragments double-buffered X/Y one group ahead.
-    // FIRST: first K tile of an output tile: the previous tile's quadrants are stored between the quadrants of group 0, whose
-    //        MFMAs start from C = 0; its DMA was issued whole at the previous tile's last barrier, so groups 0-1 issue none.
-    // LAST:  last K tile: at its barrier the whole next-but-one K tile is issued (before the epilogue's stores: counted waits).
+    // ---- one K tile t = four groups (k-steps of 16), fragments double-buffered X/Y one group ahead.  DMA issued during it:
+    //   group 0: B_1(t+1)   group 1: A_0(t+2)   group 2: B_0(t+2)   [barrier]   group 3: A_1(t+2)
+    // (A_1 / B_1 of K tile u overwrite A_0 / B_0 of K tile u-2, free after the barrier of K tile u-2; A_0 / B_0 of K tile u go to
+    // the ring's fifth slot, vacated a K tile earlier.)  At the barrier K tile t+1 must have landed: the 4 DMA instructions of
+    // groups 1-2 are younger and may stay in flight.
+    // FIRST: first K tile of an output tile: the previous tile's quadrants are stored between the quadrants of group 0, whose MFMAs
+    //        start from C = 0; its group 0 issues no DMA (see LAST).
+    // LAST:  last K tile: group 3 also issues the next tile's group-0 part, so that every DMA the next barrier waits for is OLDER
+    //        than the epilogue's stores and the wait can exclude exactly them.
     // Literal flags: three straight-line copies of the body (no accumulator is live across a branch that writes it).
 #define Q8_KTILE(FIRST, LAST)                                                                                            \
     do {                                                                                                                 \
-        const unsigned char* sK = lds + rslot * (4 * Q8_HALF);                                                           \
-        const unsigned char* sN = lds + (rslot ^ 1) * (4 * Q8_HALF);                                                     \
-        Q8_GROUP(xm, xn, ym, yn, sK, 1, (FIRST) ? -1 : 1, (FIRST) ? -1 : 2, FIRST, FIRST);                               \
-        Q8_GROUP(ym, yn, xm, xn, sK, 2, (FIRST) ? -1 : 3, -1, false, false);                                             \
-        Q8_GROUP(xm, xn, ym, yn, sK, 3, -1, -1, false, false);                                                           \
-        /* group 3: all my reads of this K tile are done; my DMA of the next K tile has landed; barrier = published + slot free */ \
+        const int ra_ = rA + wr, rb_ = rB + (wc >> 1), na_ = rA + 2 + wr, nb_ = rB + 2 + (wc >> 1);                      \
+        const bool rsp_was = ROWSUM && (FIRST) && rsp_on;   /* 4 atomics follow this tile's epilogue stores */            \
+        const unsigned char* sM = lds + (ra_ >= NSLOT ? ra_ - NSLOT : ra_) * Q8_HALF;                                    \
+        const unsigned char* sN = lds + (NSLOT + (rb_ >= NSLOT ? rb_ - NSLOT : rb_)) * Q8_HALF;                          \
+        const unsigned char* tM = lds + (na_ >= NSLOT ? na_ - NSLOT : na_) * Q8_HALF;                                    \
+        const unsigned char* tN = lds + (NSLOT + (nb_ >= NSLOT ? nb_ - NSLOT : nb_)) * Q8_HALF;                          \
+        Q8_GROUP(xm, xn, ym, yn, sM, sN, 1, (FIRST) ? -1 : 3, -1, FIRST, FIRST);                                         \
+        Q8_GROUP(ym, yn, xm, xn, sM, sN, 2, 0, -1, false, false);                                                        \
+        Q8_GROUP(xm, xn, ym, yn, sM, sN, 3, 1, -1, false, false);                                                        \
+        /* group 3: every fragment of this K tile has arrived (slot free); my DMA of the next K tile has landed (published) */ \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-        if ((FIRST) && have_pend) Q8_WAIT_DMA(4 * NST); else Q8_WAIT_DMA(0);                                             \
+        if (pdone) Q8_WAIT_DMA(0);   /* end of the stream: groups 1-2 issued nothing */                                   \
+        else if ((FIRST) && have_pend) { if (ROWSUM && rsp_was) Q8_WAIT_DMA(4 * NST + 8); else Q8_WAIT_DMA(4 * NST + 4); } \
+        else Q8_WAIT_DMA(4);                                                                                             \
         if (!(DBG & 16)) __builtin_amdgcn_s_barrier();                                                                   \
         Q8_SB();                                                                                                         \
-        if (LAST) { Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3); Q8_SB(); }                   \
-        Q8_GROUP(ym, yn, xm, xn, sN, 0, (LAST) ? -1 : 0, -1, false, false);                                              \
-        rslot ^= 1;                                                                                                      \
+        Q8_GROUP(ym, yn, xm, xn, tM, tN, 0, 2, (LAST) ? 3 : -1, false, false);                                           \
+        rA = rA + 2 >= NSLOT ? rA + 2 - NSLOT : rA + 2;                                                                  \
+        rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
     } while (0)
 
     // prologue: K tiles 0 and 1 issued, K tile 0 landed and published, its first group requested
     Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
-    const bool two_ = !pdone;
     Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
-    if (two_) Q8_WAIT_DMA(8); else Q8_WAIT_DMA(0);
+    Q8_WAIT_DMA(8);
     __builtin_amdgcn_s_barrier();
-    Q8_READ_GROUP(xm, xn, lds, 0);
-    if ((DBG & 32) && A_KC && B_KC) {   // timing decomposition: real (random) fragments, read once and never again
+    Q8_READ_GROUP(xm, xn, lds + wr * Q8_HALF, lds + (NSLOT + (wc >> 1)) * Q8_HALF, 0);
+    if constexpr ((DBG & 32) != 0 && A_KC && B_KC) {   // timing decomposition: real (random) fragments, read once and never again
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            xm[i] = *reinterpret_cast<const hw_bf16x8*>(lds + offM[0] + i * 4096);
-            ym[i] = *reinterpret_cast<const hw_bf16x8*>(lds + offM[1] + i * 4096);
+            xm[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + offM[0] + i * 4096);
+            ym[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + offM[1] + i * 4096);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            xn[i] = *reinterpret_cast<const hw_bf16x8*>(lds + offN[0] + i * 4096);
-            yn[i] = *reinterpret_cast<const hw_bf16x8*>(lds + offN[1] + i * 4096);
+            xn[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + NSLOT * Q8_HALF + offN[0] + i * 4096);
+            yn[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + NSLOT * Q8_HALF + offN[1] + i * 4096);
         }
     }
 
@@ -458,14 +521,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     for (int cv = (int)blockIdx.x; cv < total; cv += G) {
         const Q8Item cit = q8_decode(g, cv, total);
         const int cm0 = cit.m0, cn0 = cit.n0, cz = cit.z, cnt = cit.nt;
+        if (ROWSUM) rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0;
         Q8_KTILE(true, false);
 #pragma unroll 1
         for (int t = 2; t < cnt; ++t) Q8_KTILE(false, false);
         Q8_KTILE(false, true);
         have_pend = true; pm0 = cm0; pn0 = cn0; pz = cz;
+        if (ROWSUM) {
+            rsp_on = rs_on; rsp_m0 = cm0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { rsp[t] = rs[t]; rs[t] = 0.f; }
+        }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the dangling request of the group after the last
+    if (!A_KC || !B_KC) { q8_wait4(xm); q8_wait2(xn); }   // the dangling request of the group after the last
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); }
+    if (ROWSUM) { if (rsp_on) rowsum_flush(); }
 #undef Q8_GROUP
 #undef Q8_STORE_Q
 #undef Q8_SB
@@ -475,6 +546,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
 #undef Q8_STAGE_PART
 #undef Q8_STAGE_PCS
 #undef Q8_DMA_SLOT
+#undef Q8_RS_ACC
 #undef Q8_KTILE
 #undef Q8_NEXT_ITEM
 #undef Q8_WAIT_DMA

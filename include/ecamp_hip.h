@@ -52,6 +52,10 @@ int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc
  * one-workgroup-per-CU kernel.  "p8_wgrad_reserve_cus" (default 0): launch that kernel with this many fewer workgroups than CUs --
  * set by the data-parallel wrapper, whose all-reduce kernels share the CUs during backward. */
 int ecamp_set_option(const char* name, int32_t value);
+/* "q8_mode" (ecamp_set_option): -1 automatic (default), 0 never, 2 whenever its alignment / size conditions hold -- the round-2
+ * persistent 256x256x64 kernel (csrc/gemm_q8.h) that serves the forward, data-gradient and weight-gradient forms.
+ * Development aid: number of GEMM calls the library has routed to that kernel so far (tests assert that it really ran). */
+int64_t ecamp_gemm_q8_launches(void);
 
 /* ---- fp8 forward (BASELINE.json configs[4]: "fp8 MFMA forward (bf16 grads) for QKV/MLP GEMMs"; no reference counterpart -- the
  * reference runs these nn.Linear layers under torch.cuda.amp, main_pretrain.py:138).  Per-tensor scaling, OCP e4m3:

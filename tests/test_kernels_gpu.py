@@ -78,6 +78,8 @@ def test_gemm_dgrad_wgrad(dev, dtype, M, N, K):
     F.gelu(pr).backward(dy @ w)
     check("dgrad*gelu'", o.linear_dgrad(dyd, wd, gmul=pred), pr.grad, tol)
     check("dgrad alpha", o.linear_dgrad(dyd, wd, alpha=0.25), 0.25 * (dy @ w), tol)
+    check("dgrad + residual", o.linear_dgrad(dyd, wd, residual=pred), dy @ w + pre, tol)
+    check("dgrad*gelu' + residual", o.linear_dgrad(dyd, wd, gmul=pred, residual=xd), pr.grad + x, tol)
     g0 = gen(N, K, seed=7)
     gw = g0.to(dev).contiguous()
     o.linear_wgrad(dyd, xd, gw, alpha=0.5)
@@ -563,6 +565,39 @@ def test_gemm_persistent_kernel_dgrad_wgrad_ragged(dev, p8_always, M, N, K):
     test_gemm_dgrad_wgrad(dev, torch.bfloat16, M, N, K)
 
 
+@pytest.fixture
+def q8_always():
+    """Route every bf16 GEMM that meets its alignment / size conditions to the round-2 persistent kernel (gemm_q8.h); the automatic
+    rule only picks it from ~192 tiles of 256x256 up."""
+    o = ops()
+    o.set_option("q8_mode", 2)
+    yield o
+    o.set_option("q8_mode", -1)
+
+
+def _q8_count():
+    from ecamp_amd import _lib
+    return int(_lib.load().ecamp_gemm_q8_launches())
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 2304, 768), (512, 128, 3072), (256, 30000, 768), (1000, 1000, 200), (300, 520, 136)])
+def test_gemm_q8_fwd_epilogues_ragged(dev, q8_always, M, N, K):
+    """test_gemm_fwd_epilogues on the Q8 kernel: ragged M and N (edge tiles, groups of 8 past N), K with a partial last K tile,
+    two to 48 K tiles, one or many output tiles per workgroup (N = 30000: 118 tiles)."""
+    n0 = _q8_count()
+    test_gemm_fwd_epilogues(dev, torch.bfloat16, M, N, K)
+    assert _q8_count() >= n0 + 3, "the Q8 kernel did not run"
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 3072, 768), (256, 30000, 768), (1000, 520, 264)])
+def test_gemm_q8_dgrad_wgrad_ragged(dev, q8_always, M, N, K):
+    """Data gradient (strided weight operand, transpose reads) with gelu' / residual epilogues, weight gradient (both operands
+    strided, split-K slabs) and the bias gradient summed inside it, on ragged shapes."""
+    n0 = _q8_count()
+    test_gemm_dgrad_wgrad(dev, torch.bfloat16, M, N, K)
+    assert _q8_count() >= n0 + 5, "the Q8 kernel did not run"
+
+
 def test_gemm_full_size_kernels_agree(dev):
     """BASELINE configs[1] sizes (timm Mlp.fc1 of the encoder at B=256: 12800 x 3072 x 768): forward with bias + GELU + saved
     pre-activation, data gradient through GELU', weight + bias gradient -- the persistent kernel against the 128^2 kernel on the
@@ -574,25 +609,28 @@ def test_gemm_full_size_kernels_agree(dev):
     b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
     dy = torch.randn(M, N, generator=torch.Generator().manual_seed(4)).to(dev, torch.bfloat16)
     res = {}
-    for mode in (0, 2):
-        o.set_option("p8_mode", mode)
+    for mode in (0, 2, 8):   # 128^2 kernel, round-1 persistent kernel, round-2 persistent kernel (Q8)
+        o.set_option("p8_mode", 2 if mode == 2 else 0)
+        o.set_option("q8_mode", 2 if mode == 8 else 0)
         y, pre = o.linear_fwd(x, w, b, act=1, save_pre=True)
         dx = o.linear_dgrad(dy, w)
         gw, gb = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
         o.linear_wgrad(dy, x, gw, gb=gb)
         res[mode] = (y.float(), pre.float(), dx.float(), gw, gb)
     o.set_option("p8_mode", -1)
-    for name, a, c, tol in zip(("y", "pre", "dx", "gw", "gb"), res[0], res[2], (1e-2, 1e-2, 1e-2, 2e-3, 2e-3)):
-        err = float((a - c).abs().max() / c.abs().max())
-        print("  full-size %-3s 128^2 vs persistent rel %.3e" % (name, err))
-        assert err < tol, name
+    o.set_option("q8_mode", -1)
+    for other, label in ((2, "P8"), (8, "Q8")):
+        for name, a, c, tol in zip(("y", "pre", "dx", "gw", "gb"), res[0], res[other], (1e-2, 1e-2, 1e-2, 2e-3, 2e-3)):
+            err = float((a - c).abs().max() / c.abs().max())
+            print("  full-size %-3s 128^2 vs %s rel %.3e" % (name, label, err))
+            assert err < tol, (label, name)
     rows = torch.arange(0, M, 997, device=dev)
     ref_pre = x[rows].double() @ w.double().t() + b.double()
-    assert float((res[2][1][rows].double() - ref_pre).abs().max() / ref_pre.abs().max()) < 1e-2
+    assert float((res[8][1][rows].double() - ref_pre).abs().max() / ref_pre.abs().max()) < 1e-2
     cols = torch.arange(0, N, 211, device=dev)
     ref_gw = dy[:, cols].double().t() @ x.double()
-    assert float((res[2][3][cols].double() - ref_gw).abs().max() / ref_gw.abs().max()) < 2e-3
-    assert float((res[2][4].double() - dy.double().sum(0)).abs().max() / dy.double().sum(0).abs().max()) < 2e-3
+    assert float((res[8][3][cols].double() - ref_gw).abs().max() / ref_gw.abs().max()) < 2e-3
+    assert float((res[8][4].double() - dy.double().sum(0)).abs().max() / dy.double().sum(0).abs().max()) < 2e-3
 
 
 # ------------------------------------------------------------------------------------------------ fp8 forward (BASELINE configs[4])

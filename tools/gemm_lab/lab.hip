@@ -42,9 +42,9 @@ static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
         if (epi == 1) { if (dbg == 1) return V(true, true, 1, 1); if (dbg == 2) return V(true, true, 1, 2); if (dbg == 4) return V(true, true, 1, 4);
                         if (dbg == 3) return V(true, true, 1, 3); if (dbg == 6) return V(true, true, 1, 6); if (dbg == 5) return V(true, true, 1, 5);
                         if (dbg == 22) return V(true, true, 1, 22); if (dbg == 38) return V(true, true, 1, 38); if (dbg == 54) return V(true, true, 1, 54);
-                        if (dbg == 8) return V(true, true, 1, 8); if (dbg == 12) return V(true, true, 1, 12); if (dbg == 14) return V(true, true, 1, 14);
+                        if (dbg == 68) return V(true, true, 1, 68); if (dbg == 69) return V(true, true, 1, 69); if (dbg == 128) return V(true, true, 1, 128); if (dbg == 256) return V(true, true, 1, 256); if (dbg == 8) return V(true, true, 1, 8); if (dbg == 12) return V(true, true, 1, 12); if (dbg == 14) return V(true, true, 1, 14);
                         return V(true, true, 1, 0); }
-        if (epi == 0) { if (dbg == 8) return V(true, true, 0, 8); return V(true, true, 0, 0); }
+        if (epi == 0) { if (dbg == 8) return V(true, true, 0, 8); if (dbg == 128) return V(true, true, 0, 128); if (dbg == 256) return V(true, true, 0, 256); return V(true, true, 0, 0); }
     }
     if (a_kc && !b_kc && epi == 0) return V(true, false, 0, 0);
     if (!a_kc && !b_kc && epi == 4) return V(false, false, 4, 0);
@@ -84,7 +84,7 @@ static void launch_q8(const Run& r, int nslot, int dbg, int grid_override, hipSt
     const int epi = r.out_f32 ? 4 : r.gmul ? 3 : r.residual ? 2 : r.pre ? 1 : 0;
     q8_fn fn = pick(r.a_kc, r.b_kc, epi, nslot, dbg);
     if (!fn) { fprintf(stderr, "no Q8 instance for form %d%d epi %d dbg %d\n", r.a_kc, r.b_kc, epi, dbg); exit(1); }
-    const size_t shm = (size_t)8 * Q8_HALF;
+    const size_t shm = (size_t)10 * Q8_HALF;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(fn, grid, dim3(512), shm, s, g);
 }
@@ -180,12 +180,14 @@ int main(int argc, char** argv) {
             Run r2 = {M, N, K, 1, 1, K, K, N, x, w, y0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 1, nullptr};
             Run q2 = r2; q2.C = y1;
             launch_ref(r2, 0, s);
-            for (int ns : nslots) {
-                launch_q8(q2, ns, 0, grid_override, s);
+            for (int dbg : dbgs) {
+                if (dbg != 0 && dbg != 128 && dbg != 256) continue;
+                const int ns = 4;
+                launch_q8(q2, ns, dbg, grid_override, s);
                 CK(hipStreamSynchronize(s));
                 double rn; double d = compare(y1, y0, (size_t)M * N, false, &rn);
-                float t = time_us([&] { launch_q8(q2, ns, 0, grid_override, s); });
-                char v[64]; snprintf(v, sizeof v, "Q8 nslot=%d plain", ns);
+                float t = time_us([&] { launch_q8(q2, ns, dbg, grid_override, s); });
+                char v[64]; snprintf(v, sizeof v, "Q8 plain dbg=%d", dbg);
                 printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f  maxdiff %.3g\n", sh.name, "fwd", M, N, K, v, t, fl / t / 1e6, d);
             }
         }
