@@ -1062,7 +1062,8 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     {
         const int q8m = q8_env();
         const long items8 = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
-        if (q8m != 0 && (q8m == 2 || items8 >= (long)(0.75 * p8_num_cu())) &&
+        static const long q8_min_items = getenv("ECAMP_Q8_MIN_ITEMS") ? atol(getenv("ECAMP_Q8_MIN_ITEMS")) : (long)(0.5 * p8_num_cu());   // measured: 150 tiles on 256 CUs still beat the 128^2 kernel by 10-20 %
+        if (q8m != 0 && (q8m == 2 || items8 >= q8_min_items) &&
             q8_legal(A, B, C, M, N, K, a_kc, lda, b_kc, ldb, ldc, bias, residual, ldr, pre_out, ldp, gmul, ldg, act, dtype, g.out_f32, split_k, splitk_ws, rowsum)) {
             const int epi = q8_epi(bias, residual, pre_out, gmul, act, g.out_f32);
             const q8_fn fn = q8_pick(a_kc, b_kc, epi, rowsum != nullptr);
