@@ -7,8 +7,13 @@
 A "step" = one full optimizer-inclusive pre-training micro-step of configs[1]: ViT-B/16 MAE encoder/decoder + SR
 head + reference BERT (6L/6H/1536, vocab 30000) with context fusion, B=256 pairs per GPU, 224^2 encoder input (448^2
 images resized on device), reports of S=128 tokens, bf16 activations / f32 master weights, train mode (dropout
-active), forward + backward + grad all-reduce (N>1) + grad-norm + fused AdamW + zero_grad (accum_iter=1).
-Inputs are synthetic and already resident in HBM when the timed region starts.
+active), host->HBM copy of the batch + forward + backward + grad all-reduce (N>1) + grad-norm + fused AdamW + zero_grad
+(accum_iter=1).  The batch starts in pinned HOST memory (what a DataLoader with pin_memory hands over) and crosses PCIe inside
+the timed region, one step ahead on a copy stream (ecamp_amd.data.DevicePrefetcher): `value` is the PCIe-inclusive rate;
+`resident_pairs_per_s` (inputs already in HBM), forward-only and forward+backward-only rates are reported beside it.
+
+`python bench.py --gpus N` with N > 1 and no RANK in the environment launches its own N ranks (one child process per GPU,
+RCCL over xGMI) before anything in this process touches the GPU; under torch.distributed.run it uses the ranks it is given.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the bf16 MFMA GEMM family, timed live with HIP
 events on the launch stream over the timed region) and `cpu_baseline` (the oracle -- a CPU restatement of the
@@ -18,6 +23,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +36,27 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak of MI355X (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
 METRIC = "pretrain image-report pairs/sec (ViT-B/16, 224^2, seq=128)"
+
+
+def cpu_info():
+    """CPU model and physical core count of this box (/proc/cpuinfo)."""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or None), os.cpu_count()
 
 
 def cpu_baseline(seq, budget_s=25.0):
@@ -64,9 +92,23 @@ def cpu_baseline(seq, budget_s=25.0):
         step(n + 1)
         n += 1
     dt = time.time() - t0
-    return {"value": round(B * n / dt, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "oracle/ecamp_oracle.py (CPU restatement of the reference, fp32): %d optimizer-inclusive steps of B=%d, S=%d, "
-                      "448^2 images, dropout on, after 1 warm-up; torch %s, %d threads" % (n, B, seq, torch.__version__, cores)}
+    model, phys, logical = cpu_info()
+    # the other legs of BASELINE.md section 3 (B=32, S=256): one step each, no warm-up (bounded: the default run stays within minutes)
+    legs = []
+    for b2, s2 in ((8, 256), (32, seq)):
+        try:
+            batch = recipe.recipe_batch(cfg, b2, s2, seed=1)
+            B = b2
+            tl = time.time()
+            step(100)
+            legs.append({"B": b2, "S": s2, "pairs_per_s": round(b2 / (time.time() - tl), 4), "steps": 1})
+        except Exception as e:
+            legs.append({"B": b2, "S": s2, "error": repr(e)})
+    return {"value": round(8 * n / dt, 4), "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": model, "physical_cores": phys,
+            "logical_cpus": logical, "other_legs": legs,
+            "sample": "oracle/ecamp_oracle.py (CPU restatement of the reference, fp32): %d optimizer-inclusive steps of B=8, S=%d, "
+                      "448^2 images, dropout on, after 1 warm-up; torch %s, %d threads (torch's CPU kernels stop scaling far below the box's "
+                      "thread count)" % (n, seq, torch.__version__, cores)}
 
 
 def main():
@@ -81,9 +123,28 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # self-launch: one fresh child process per GPU, BEFORE anything here initialises the GPU (never re-exec a process that has)
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = 0
+        for pr in procs:
+            rc = max(rc, abs(pr.wait()))
+        raise SystemExit(rc)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch `python bench.py --gpus N` (self-launching) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -91,7 +152,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     from ecamp_amd import _lib, optim
     from ecamp_amd.data import synthetic_batch
@@ -106,29 +166,66 @@ def main():
     net = DistributedDataParallel(model) if world > 1 else model
     opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
     scaler = NativeScalerWithGradNormCount()
-    batch = synthetic_batch(args.batch, args.seq, 448, seed=rank, device=dev)  # resident in HBM before timing
+    from ecamp_amd.data import DevicePrefetcher
+    host_batch = {k: v.pin_memory() for k, v in synthetic_batch(args.batch, args.seq, 448, seed=rank, device="cpu").items()}   # what a
+    # pin_memory DataLoader yields (main_pretrain.py:232-240); it crosses PCIe inside the timed region, one step ahead of its use
+    batch = {k: v.to(dev) for k, v in host_batch.items()}   # resident copy for the side measurements
     net.train()
     opt.zero_grad()
 
-    def step():
-        mim, res, mlm = net(batch)
+    def step(b=None):
+        mim, res, mlm = net(batch if b is None else b)
         norm = scaler(mim + res + mlm, opt, parameters=model.parameters(), update_grad=True)
         opt.zero_grad()
         return mim, res, mlm, norm
 
+    def timed(fn, n):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(n)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0
+
     for _ in range(args.warmup):
         out = step()
     lib = _lib.load()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+
+    def run_inclusive(n):
+        nonlocal out
+        for b in DevicePrefetcher([host_batch] * n, dev):
+            out = step(b)
+
+    out = None
+    dt = timed(run_inclusive, args.steps)          # THE metric: K steps, host batch -> HBM inside
+
+    def run_resident(n):
+        for _ in range(n):
+            step()
+
+    side_n = max(1, min(args.steps, 5))
+    dt_res = timed(run_resident, side_n) / side_n
+
+    def run_fwd(n):
+        with torch.no_grad():
+            for _ in range(n):
+                net(batch)
+
+    def run_fwd_bwd(n):
+        if hasattr(net, "set_grad_sync"):
+            net.set_grad_sync(False)
+        for _ in range(n):
+            mim, res, mlm = net(batch)
+            (mim + res + mlm).backward()
+        if hasattr(net, "set_grad_sync"):
+            net.set_grad_sync(True)
+        opt.zero_grad()
+
+    dt_fwd = timed(run_fwd, side_n) / side_n
+    dt_fb = timed(run_fwd_bwd, side_n) / side_n
     losses = [float(t.detach()) for t in out[:3]]
     # Roofline pass (not part of `value`): the same step, with the weight-gradient GEMMs back on the main stream so that every
     # launch runs alone and its HIP-event duration is its own (in the timed region above they overlap the dgrad chain on a side
@@ -150,9 +247,9 @@ def main():
         lib.ecamp_prof_enable(0)
         hip_ops.OVERLAP_WGRAD = True
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, dt_res, dt_fwd, dt_fb], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_res, dt_fwd, dt_fb = (float(x) for x in t.tolist())
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -163,7 +260,11 @@ def main():
                                       "+ context fusion; full train step (fwd+bwd+grad-norm+AdamW, dropout on)",
                           "pairs_per_gpu": args.batch, "global_batch": args.batch * world, "image": "448^2 -> 224^2 encoder input",
                           "seq_len": args.seq, "mask_ratio": 0.75, "accum_iter": 1, "parallelism": "dp%d" % world,
-                          "last_losses_mim_res_mlm": [round(x, 5) for x in losses]}}
+                          "last_losses_mim_res_mlm": [round(x, 5) for x in losses]},
+               "input": "pinned host memory -> HBM inside the timed region (prefetched one step ahead on a copy stream)",
+               "resident_pairs_per_s": round(args.batch * world / dt_res, 2), "resident_ms_per_step": round(1e3 * dt_res, 3),
+               "fwd_only_ms": round(1e3 * dt_fwd, 3), "fwd_only_pairs_per_s": round(args.batch * world / dt_fwd, 2),
+               "fwd_bwd_ms": round(1e3 * dt_fb, 3), "fwd_bwd_pairs_per_s": round(args.batch * world / dt_fb, 2)}
         if not args.no_prof:
             ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
             cat = 0 if args.dtype == "bf16" else 1
@@ -184,7 +285,7 @@ def main():
                     traffic = None
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "gemm_bf16_p8_kernel + gemm_bf16_kernel" if args.dtype == "bf16" else "gemm_f32_kernel",
+                               "kernel": "gemm_bf16_q8_kernel + gemm_bf16_kernel (bf16 GEMM family)" if args.dtype == "bf16" else "gemm_f32_kernel",
                                "launches_per_step": n.value // max(prof_steps, 1),
                                "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2),
                                "algorithmic_gflop_per_launch": round(fl.value / max(n.value, 1) / 1e9, 3),

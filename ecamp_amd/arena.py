@@ -63,6 +63,7 @@ class ParamArena:
             self.index[id(p)] = i
         self.unused = [i for i, p in enumerate(self.params) if getattr(p, "_ecamp_unused", False)]
         self.on_ready = None  # callback(list of slot ids) set by the data-parallel reducer
+        self.reducer = None   # the GradReducer itself (parallel.DistributedDataParallel): the loss scaler / optimizer check it
         # Lazy zero_grad: a weight matrix whose gradient is produced by ONE weight-gradient GEMM per backward pass is never zeroed --
         # the first GEMM after zero_grad() OVERWRITES it (no 733 MB memset, no read of the zeros); everything else (biases, LayerNorm,
         # embeddings, tokens: kernels add into them with atomics) is zeroed by one table-driven kernel.

@@ -266,9 +266,12 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(T* __restrict__ logits,
     float gsm = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) gsm += shm_[k] == -INFINITY ? 0.f : shm_[4 + k] * __expf(shm_[k] - gmx);
+    // a label outside [0, V) -- CrossEntropyLoss's ignore_index -100 (bert_modeling.py:212) -- contributes no loss and a zero
+    // gradient row, and is never used as an index
     const long label = labels[row];
-    const float w = weights[row];
-    if (threadIdx.x == 0) {
+    const bool ign = label < 0 || label >= (long)V;
+    const float w = ign ? 0.f : weights[row];
+    if (threadIdx.x == 0 && !ign) {
         float lse = gmx + __logf(gsm);
         atomicAdd(loss_sum, w * (lse - to_f<T>(x[label])));
     }
@@ -331,8 +334,9 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_reg_kernel(bf16_t* __restrict_
 #pragma unroll
     for (int k = 0; k < 4; ++k) gsm += shm_[k] == -INFINITY ? 0.f : shm_[4 + k] * __expf(shm_[k] - gmx);
     const long label = labels[row];
-    const float w = weights[row];
-    if (threadIdx.x == 0) {
+    const bool ign = label < 0 || label >= (long)V;   // ignore_index (see the generic kernel)
+    const float w = ign ? 0.f : weights[row];
+    if (threadIdx.x == 0 && !ign) {
         float lse = gmx + __logf(gsm);
         atomicAdd(loss_sum, w * (lse - to_f<bf16_t>(x[label])));
     }

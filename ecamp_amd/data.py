@@ -47,3 +47,54 @@ class SyntheticContextBertDataset(Dataset):
     @staticmethod
     def collate_fn(instances):
         return {k: torch.stack([inst[k] for inst in instances]) for k in instances[0]}
+
+
+class DevicePrefetcher:
+    """Host -> HBM staging of the batch dict one step ahead, on its own HIP stream.
+
+    The reference moves every batch inside `ECAMP.forward` with blocking `.cuda()` calls (model_ecamp.py:304-317): 616 MB of f32
+    images per 256 pairs sit on the critical path (~10 ms at PCIe Gen5 rates).  Here batch i+1 is copied from (pinned) host memory
+    while step i computes; the compute stream only waits for the copy's event.  Yields dicts of device tensors -- `forward` accepts
+    them unchanged (its `.to(device)` calls become no-ops).  Used by `train_one_epoch` and by bench.py's timed region."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        dev = self.device
+        side = torch.cuda.Stream(device=dev)
+
+        def stage(batch):
+            with torch.cuda.stream(side):
+                out = {}
+                for k, v in batch.items():
+                    if torch.is_tensor(v) and v.device.type == "cpu":
+                        if not v.is_pinned():
+                            v = v.pin_memory()
+                        out[k] = v.to(dev, non_blocking=True)
+                    else:
+                        out[k] = v
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return out, ev
+
+        it = iter(self.loader)
+        try:
+            nxt = stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = stage(next(it))
+            except StopIteration:
+                nxt = None
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(ev)
+            for v in cur.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)   # allocated on the side stream, consumed on the compute stream
+            yield cur

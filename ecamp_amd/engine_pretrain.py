@@ -8,12 +8,32 @@ the reference calls `.item()` x3 + `torch.cuda.synchronize()` + three scalar all
 are only read back when a meter is printed (every `print_freq` steps) or averaged at the end of the epoch.
 Gradient all-reduce runs once per optimizer step (not per micro-step), overlapped with backward.
 """
+import contextlib
+import ctypes
 import math
 from typing import Iterable
 
 import torch
 
 from .util import lr_sched, misc
+
+
+@contextlib.contextmanager
+def _range(on, name):
+    """roctx range (torch.cuda.nvtx is roctx on ROCm builds) when profiling is on; free otherwise."""
+    if not on:
+        yield
+        return
+    try:
+        torch.cuda.nvtx.range_push(name)
+        pushed = True
+    except Exception:   # a build without roctx: profiling ranges are best effort
+        pushed = False
+    try:
+        yield
+    finally:
+        if pushed:
+            torch.cuda.nvtx.range_pop()
 
 
 def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer, device: torch.device,
@@ -28,6 +48,15 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     if log_writer is not None:
         print("log_dir: {}".format(log_writer.log_dir))
     n_iter = len(data_loader)
+    prof = bool(getattr(args, "profile", False))
+    if prof:
+        from . import _lib
+        lib = _lib.load()
+        lib.ecamp_prof_collect(-1, None, None, None)
+        lib.ecamp_prof_enable(1)   # HIP events around every GEMM / attention launch (csrc/profile.hip)
+    if torch.device(device).type == "cuda" and getattr(args, "prefetch", True):
+        from .data import DevicePrefetcher
+        data_loader = DevicePrefetcher(data_loader, device)   # batch i+1 crosses PCIe while step i computes
     for data_iter_step, batch in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
         # per-iteration (not per-epoch) lr schedule, updated at accumulation boundaries only (main_pretrain.py:137-138)
         if data_iter_step % accum_iter == 0:
@@ -35,11 +64,14 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
         update_grad = (data_iter_step + 1) % accum_iter == 0
         if hasattr(model, "set_grad_sync"):
             model.set_grad_sync(update_grad)
-        mim_loss, res_loss, mlm_loss = model(batch, mask_ratio=args.mask_ratio)
-        loss = (mim_loss + res_loss + mlm_loss) / accum_iter
-        loss_scaler(loss, optimizer, parameters=model.parameters(), update_grad=update_grad)
-        if update_grad:
-            optimizer.zero_grad()
+        with _range(prof, "ecamp/step %d" % data_iter_step):
+            with _range(prof, "ecamp/forward"):
+                mim_loss, res_loss, mlm_loss = model(batch, mask_ratio=args.mask_ratio)
+                loss = (mim_loss + res_loss + mlm_loss) / accum_iter
+            with _range(prof, "ecamp/backward+allreduce+adamw" if update_grad else "ecamp/backward"):
+                loss_scaler(loss, optimizer, parameters=model.parameters(), update_grad=update_grad)
+                if update_grad:
+                    optimizer.zero_grad()
         losses = torch.stack([mim_loss.detach(), res_loss.detach(), mlm_loss.detach()])
         metric_logger.update(mim_loss=losses[0], res_loss=losses[1], mlm_loss=losses[2])
         lr = optimizer.param_groups[0]["lr"]
@@ -55,6 +87,15 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
             log_writer.add_scalar("res_loss", r[1], epoch_1000x)
             log_writer.add_scalar("mlm_loss", r[2], epoch_1000x)
             log_writer.add_scalar("lr", lr, epoch_1000x)
+    if prof:
+        torch.cuda.synchronize()
+        lib.ecamp_prof_enable(0)
+        for cat, name in ((0, "bf16 GEMM"), (1, "f32 GEMM"), (2, "attention")):
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            lib.ecamp_prof_collect(cat, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+            if n.value:
+                print("profile: %-10s %7d launches  %9.2f ms/step  %7.1f TFLOP/s (HIP events on the launch stream)"
+                      % (name, n.value, ms.value / max(n_iter, 1), fl.value / max(ms.value, 1e-9) / 1e9))
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

@@ -301,8 +301,8 @@ class ReportStemFn(torch.autograd.Function):
         latent, m, B, T, H = ctx.s
         A = m.arena
         G = A.grad
-        dlat = dlat.contiguous()
-        ops.seq_bcast(dgap.contiguous(), dlat.view(B, T, H), 1, T, 1.0 / (T - 1), 1)  # in place: we are dlat's only consumer
+        dlat = dlat.clone(memory_format=torch.contiguous_format)   # autograd may still own the incoming buffer (a second consumer of
+        ops.seq_bcast(dgap.contiguous(), dlat.view(B, T, H), 1, T, 1.0 / (T - 1), 1)   # `lat`, retain_graph): add into a private copy
         _wgrad(A, dlat, latent, m.bert_mlp.weight, gb=G(m.bert_mlp.bias))
         dl = ops.linear_dgrad(dlat, A.w(m.bert_mlp.weight))
         A.ready(m.bert_mlp.weight, m.bert_mlp.bias)

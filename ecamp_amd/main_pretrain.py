@@ -3,9 +3,12 @@ unchanged), on the MI355X-native model / optimizer / data-parallel reducer.
 
     python -m torch.distributed.run --nproc_per_node=8 -m ecamp_amd.main_pretrain --batch_size 256 --accum_iter 8 ...
 
-Extra flags (all optional): --compute_dtype {bf16,fp32}, --max_caption_length, --synthetic_len, --print_freq.
+Extra flags (all optional): --compute_dtype {bf16,fp32}, --max_caption_length, --synthetic, --synthetic_len, --print_freq, --profile, --no_prefetch.
 When `--data_path` holds the MIMIC-CXR CSVs the `ContextBertDataset` of module/pretrain_datasets.py is used (batched
-entity-aware masker, bit-exact against the reference loop); otherwise the synthetic stand-in with the same batch schema.
+entity-aware masker, bit-exact against the reference loop).  A missing CSV is an error (as in the reference) unless `--synthetic`
+asks for the synthetic stand-in with the same batch schema.  `--profile` puts roctx ranges around every step and its phases
+(visible to `rocprofv3 --marker-trace --kernel-trace -- python -m ecamp_amd.main_pretrain ...`) and prints the library's own
+HIP-event totals of the GEMM and attention kernels per epoch.
 """
 import argparse
 import datetime
@@ -69,7 +72,12 @@ def get_args_parser():
     # additions of this implementation
     p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--max_caption_length", default=256, type=int)
+    p.add_argument("--synthetic", action="store_true", help="train on the synthetic stand-in dataset (random images and tokens) instead "
+                   "of <data_path>/mimic-cxr-2.0.0-entity-llm.csv; without this flag a missing CSV is an error, as in the reference")
     p.add_argument("--synthetic_len", default=4096, type=int, help="samples per epoch of the synthetic dataset")
+    p.add_argument("--profile", action="store_true", help="roctx ranges around every optimizer step and its phases (rocprofv3 --marker-trace)")
+    p.add_argument("--no_prefetch", action="store_false", dest="prefetch", help="copy each batch inside forward like the reference does")
+    p.set_defaults(prefetch=True)
     p.add_argument("--print_freq", default=20, type=int)
     p.add_argument("--snapshot_code", action="store_true", help="copy ./ into output_dir/job_dir like the reference does")
     return p
@@ -84,12 +92,18 @@ def main(args):
     torch.manual_seed(seed)
     np.random.seed(seed)
 
-    if os.path.exists(os.path.join(args.data_path, "mimic-cxr-2.0.0-entity-llm.csv")):   # main_pretrain.py:195
+    csv = os.path.join(args.data_path, "mimic-cxr-2.0.0-entity-llm.csv")   # main_pretrain.py:195
+    if args.synthetic:
+        print("WARNING: --synthetic: training on RANDOM images and tokens (no dataset is read); checkpoints are meaningless")
+        dataset_train = SyntheticContextBertDataset(args.synthetic_len, args.max_caption_length, args.input_size, seed=args.seed)
+    elif os.path.exists(csv):
         from .module.pretrain_datasets import ContextBertDataset
         random.seed(seed)  # the item pipeline draws from Python's `random` (pretrain_datasets.py:98,121,123)
         dataset_train = ContextBertDataset(os.path.join(args.data_path), max_caption_length=args.max_caption_length)
     else:
-        dataset_train = SyntheticContextBertDataset(args.synthetic_len, args.max_caption_length, args.input_size, seed=args.seed)
+        raise FileNotFoundError("%s not found: check --data_path (the reference fails in ContextBertDataset.__init__ here too); pass "
+                                "--synthetic to run on the synthetic stand-in dataset instead" % csv)
+    args.data = "synthetic" if args.synthetic else "mimic-cxr"   # recorded in config.yaml and log.txt
     num_tasks, global_rank = misc.get_world_size(), misc.get_rank()
     sampler_train = DistributedSampler(dataset_train, num_replicas=num_tasks, rank=global_rank, shuffle=True)
     print("Sampler_train = %s" % str(sampler_train))
@@ -155,7 +169,7 @@ def main(args):
                 if not write_description:
                     f.write(args.description + "\n")
                     write_description = True
-                f.write(json.dumps(log_stats) + "\n")
+                f.write(json.dumps(dict(log_stats, data=args.data)) + "\n")
     total_time = time.time() - start_time
     print("Training time {}".format(str(datetime.timedelta(seconds=int(total_time)))))
 

@@ -35,8 +35,12 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("all groups must share betas and eps")
         self._arena = None
         self._step = 0
-        self._ecamp_reducer = None
         self.grad_scale = 1.0
+
+    @property
+    def arena(self):
+        """The parameter arena this optimizer updates (bound on first use); `arena.reducer` is the data-parallel reducer, if any."""
+        return self._bind()
 
     def _bind(self):
         if self._arena is not None:
@@ -70,6 +74,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None, grad_sumsq=None):
         loss = closure() if closure is not None else None
         A = self._bind()
+        if A.reducer is not None:
+            A.reducer.assert_reduced()   # loud failure instead of a silent step on un-reduced gradients
         A.flush_fresh()
         self._step += 1
         g0 = self.param_groups[0]

@@ -40,7 +40,11 @@ class GradReducer:
         self.side = torch.cuda.Stream(device=flat_g.device) if flat_g.is_cuda else None
         backend = dist.get_backend(group) if dist.is_initialized() else None
         self.use_avg = backend == "nccl"  # RCCL has ncclAvg; gloo does not
+        # gloo on device tensors (two ranks sharing ONE GPU in the model-level equivalence test; RCCL refuses duplicate devices):
+        # buckets are staged through host memory, synchronously -- a test / debugging path, never the production one
+        self.host_staged = backend == "gloo" and flat_g.is_cuda
         self._cb_queued = False
+        self.dirty = False      # a backward pass has reported gradients that finalize() has not yet reduced
         self.reset()
 
     def reset(self):
@@ -57,6 +61,16 @@ class GradReducer:
         lo, hi, _ = self.buckets[b]
         buf = self.flat_g[lo:hi]
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        if self.host_staged:
+            from . import hip_ops
+            wst = hip_ops._side.get(self.flat_g.device)
+            if wst is not None:
+                torch.cuda.current_stream().wait_stream(wst)
+            host = buf.cpu()
+            dist.all_reduce(host, op=op, group=self.group)
+            buf.copy_(host)
+            self.works.append((None, b))
+            return
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -75,12 +89,15 @@ class GradReducer:
         """Called from inside the backward stages as soon as a parameter's gradient is final."""
         if not self.enabled:
             return
+        self.dirty = True
         if not self._cb_queued:
             self._cb_queued = True
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(self.finalize)
             except RuntimeError:
-                self._cb_queued = False  # not inside a backward pass (unit tests drive finalize() themselves)
+                # not inside a backward pass (unit tests drive finalize() themselves).  `dirty` stays set: the loss scaler calls
+                # finalize() before the gradients are read, and FusedAdamW refuses to step on an un-reduced arena (assert_reduced)
+                self._cb_queued = False
         for s in slots:
             if s in self.unused:
                 continue
@@ -90,18 +107,27 @@ class GradReducer:
                 self._launch(b)
 
     def finalize(self):
-        """Runs at the end of backward: every bucket is reduced and visible to the compute stream afterwards."""
-        if not self.enabled:
+        """Runs at the end of backward (autograd engine callback) and again, as a no-op, from the loss scaler: every bucket is
+        reduced and visible to the compute stream afterwards."""
+        if not self.enabled or not self.dirty:
             return
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
         for w, b in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
             if not self.use_avg and self.world > 1:
                 lo, hi, _ = self.buckets[b]
                 self.flat_g[lo:hi].div_(self.world)
+        self.dirty = False
         self.reset()
+
+    def assert_reduced(self):
+        """Called by the optimizer before it reads the gradient arena."""
+        if self.enabled and self.dirty:
+            raise RuntimeError("GradReducer: the optimizer is about to step on gradients that were reported by backward but never "
+                               "all-reduced (finalize() did not run: no autograd callback and no loss-scaler call)")
 
 
 class DistributedDataParallel(nn.Module):
@@ -113,7 +139,12 @@ class DistributedDataParallel(nn.Module):
         self.module = module
         arena = module.prepare()
         if dist.is_initialized() and dist.get_world_size(process_group) > 1:
-            dist.broadcast(arena.flat_p, src=0, group=process_group)  # C1: parameters rank0 -> all (one 733 MB message)
+            if dist.get_backend(process_group) == "gloo" and arena.flat_p.is_cuda:   # host-staged (see GradReducer.host_staged)
+                host = arena.flat_p.cpu()
+                dist.broadcast(host, src=0, group=process_group)
+                arena.flat_p.copy_(host)
+            else:
+                dist.broadcast(arena.flat_p, src=0, group=process_group)  # C1: parameters rank0 -> all (one 733 MB message)
             arena.sync_shadow()
             # RCCL's all-reduce workgroups share the CUs with the backward pass, and a persistent one-workgroup-per-CU GEMM
             # whose CU is taken starts that workgroup late (tools/hog_probe.py): leave 32 CUs to the communication kernels
@@ -121,6 +152,7 @@ class DistributedDataParallel(nn.Module):
             hip_ops.set_option("p8_wgrad_reserve_cus", int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")))
         self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group, force_comm)
         arena.on_ready = self.reducer.mark_ready
+        arena.reducer = self.reducer   # the loss scaler and the optimizer find it here
 
     def forward(self, *args, **kwargs):
         if self.module.arena is not None and self.module.arena.on_ready is None:

@@ -267,9 +267,10 @@ class NativeScalerWithGradNormCount:
             return None
         if hasattr(optimizer, "flush_grads"):
             optimizer.flush_grads()  # weights no GEMM wrote this window read as zero (lazy zero_grad)
-        reducer = getattr(optimizer, "_ecamp_reducer", None)
+        arena = getattr(optimizer, "arena", None)
+        reducer = getattr(arena, "reducer", None) if arena is not None else None
         if reducer is not None:
-            reducer.finalize()  # all gradient buckets reduced before anyone reads them
+            reducer.finalize()  # normally a no-op (the autograd callback has run); the safety net when no callback could be queued
         if clip_grad is not None:
             assert parameters is not None
             norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)

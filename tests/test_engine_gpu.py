@@ -15,7 +15,7 @@ def _args(tmp, extra=()):
     from ecamp_amd.main_pretrain import get_args_parser
     argv = ["--model", "ecamp_tiny", "--batch_size", "8", "--accum_iter", "2", "--epochs", "3", "--warmup_epochs", "1", "--max_epoch", "4",
             "--lr", "5e-4", "--weight_decay", "0.05", "--mask_ratio", "0.75", "--norm_pix_loss", "--num_workers", "0",
-            "--output_dir", str(tmp), "--data_path", str(tmp), "--synthetic_len", "32", "--max_caption_length", "64", "--print_freq", "2",
+            "--output_dir", str(tmp), "--data_path", str(tmp), "--synthetic", "--synthetic_len", "32", "--max_caption_length", "64", "--print_freq", "2",
             "--compute_dtype", "bf16"] + list(extra)
     return argparse.ArgumentParser(parents=[get_args_parser()]).parse_args(argv)
 
@@ -210,3 +210,75 @@ def test_lazy_zero_grad_matches_memset_and_flushes_unwritten_weights(dev):
                 assert torch.equal(g, b[k]), k          # deterministic GEMMs on identical activations: bit for bit
             else:                                       # tokens, biases, LayerNorm, embedding rows: atomic sums, order varies
                 assert (g - b[k]).abs().max().item() <= 5e-3 * b[k].abs().max().item() + 1e-9, k
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum):
+    """SURVEY.md section 4, "distributed without a cluster" (main_pretrain.py:247-250): two data-parallel ranks of B=4 (accum 1) or
+    2 x B=2 with no_sync on the first micro-step (accum 2) must leave, after the bucketed all-reduce, the SAME gradient arena and
+    the same parameters after one AdamW step as ONE process on the concatenated B=8 batch.  Both ranks share cuda:0 (this pool
+    has one GPU per box), so the process group is gloo on device tensors; rank 1 starts from a different initialisation, which the
+    wrapper's parameter broadcast must overwrite.  fp32 parity mode, tiny config, recipe inputs."""
+    import socket
+    import subprocess
+    import sys
+    from ecamp_amd import optim
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.util import misc
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = orc.cfg_tiny()
+    B, S = 8, 64
+    batch = recipe.recipe_batch(cfg, B, S, seed=5)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=5)
+    model = me.ecamp_tiny(compute_dtype=torch.float32)
+    model.load_state_dict(recipe.recipe_state(cfg, seed=0))
+    model.to(dev).eval()
+    model.prepare()
+    opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    opt.zero_grad()
+    sum(model(batch, noise=noise)).backward()
+    model.arena.flush_fresh()
+    torch.cuda.synchronize()
+    ref_g = model.arena.flat_g.detach().cpu().clone()
+    ref_norm = float(misc.get_grad_norm_(model.parameters()))
+    opt.step()
+    torch.cuda.synchronize()
+    ref_p = model.arena.flat_p.detach().cpu().clone()
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    out = os.path.join(tmp_path, "ddp_rank0.pt")
+    worker = os.path.join(root, "tests", "_ddp_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(accum), out], cwd=root) for r in range(2)]
+    rcs = [p.wait(timeout=600) for p in procs]
+    assert rcs == [0, 0], rcs
+    got = torch.load(out, map_location="cpu")
+    eg = float((got["flat_g"] - ref_g).abs().max() / ref_g.abs().max())
+    ep = float((got["flat_p"] - ref_p).abs().max() / ref_p.abs().max())
+    print("  DDP 2 ranks (accum %d) vs single process: grad arena rel %.2e, params after AdamW rel %.2e, norm %.6f vs %.6f"
+          % (accum, eg, ep, got["norm"], ref_norm))
+    assert eg <= 1e-5, eg
+    # the first AdamW step is lr * g / (|g| + eps): where a gradient element is ~0 a 1e-7 difference moves the update by O(lr), so the
+    # parameters are compared at lr-scale resolution (lr = 1e-3, |p|max ~ 1); the gradient arena above is the contract
+    assert ep <= 1e-4, ep
+    assert abs(got["norm"] - ref_norm) <= 1e-5 * ref_norm
+
+
+def test_optimizer_refuses_unreduced_gradients(dev):
+    """A reducer that saw gradients but was never finalised (no autograd callback, no scaler call) must stop the optimizer."""
+    from ecamp_amd import optim
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.parallel import GradReducer
+    model = me.ecamp_tiny(compute_dtype=torch.float32).to(dev)
+    A = model.prepare()
+    opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-3)
+    A.reducer = GradReducer(A.flat_g, A.offsets, A.sizes, A.unused, force_comm=False)
+    A.reducer.mark_ready([0])          # outside a backward pass: no callback can be queued
+    with pytest.raises(RuntimeError, match="never"):
+        opt.step()
+    A.reducer.finalize()
+    opt.step()

@@ -133,11 +133,19 @@ def test_meters_accept_tensors_lazily():
 
 
 def test_run_sh_command_line_parses():
+    """The flags of the repo-root run.sh (the reference's run.sh:3-16, value for value) parse with the driver's argument parser."""
+    import os, re, shlex
     from ecamp_amd.main_pretrain import get_args_parser
-    argv = "--num_workers 16 --accum_iter 8 --batch_size 256 --model ecamp --norm_pix_loss --mask_ratio 0.75 --epochs 120 " \
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "run.sh")).read()
+    cmd = text[text.index("-m ecamp_amd.main_pretrain") + len("-m ecamp_amd.main_pretrain"):].replace("\\\n", " ")
+    argv = [t for t in shlex.split(cmd) if t != "$@"]
+    want = "--num_workers 16 --accum_iter 8 --batch_size 256 --model ecamp --norm_pix_loss --mask_ratio 0.75 --epochs 120 " \
            "--warmup_epochs 40 --lr 1.5e-4 --weight_decay 0.05 --resume ./dataset/mae_vit_base.pth --data_path ./dataset/ " \
-           "--output_dir ../output/ --description x".split()
+           "--output_dir ../output/ --description".split() + ["ECAMP pretraining"]
+    assert argv == want, argv
     a = argparse.ArgumentParser(parents=[get_args_parser()]).parse_args(argv)
+    assert not a.synthetic   # a missing CSV is an error unless --synthetic is given
     assert a.accum_iter == 8 and a.batch_size == 256 and a.lr == 1.5e-4 and a.max_epoch == 200 and a.norm_pix_loss
     assert "ecamp" in me.__dict__ and callable(me.__dict__[a.model])
 
@@ -162,3 +170,20 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert p.returncode != 0
     assert "no CPU fallback" in (p.stderr + p.stdout)
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    # --gpus 2 without RANK: bench.py launches its own two ranks (each of which stops for the same reason here)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=600, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert p.returncode != 0 and (p.stderr + p.stdout).count("no CPU fallback") == 2
+    # a launcher that provides a different world size is an error, not a silent single-GPU run
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_main_pretrain_needs_the_dataset_or_an_explicit_synthetic_flag(tmp_path):
+    """a mistyped --data_path must not silently train on noise."""
+    from ecamp_amd import main_pretrain
+    args = argparse.ArgumentParser(parents=[main_pretrain.get_args_parser()]).parse_args(
+        ["--lr", "1e-4", "--data_path", str(tmp_path), "--output_dir", str(tmp_path)])
+    with pytest.raises(FileNotFoundError, match="--synthetic"):
+        main_pretrain.main(args)

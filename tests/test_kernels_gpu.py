@@ -464,6 +464,27 @@ def test_weighted_cross_entropy(dev, dtype, M, V):
     check("d logits", ld, lr.grad, TOL[dtype] if dtype == torch.bfloat16 else 1e-5)
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_weighted_cross_entropy_ignore_index(dev, dtype):
+    """CrossEntropyLoss's ignore_index (-100, honoured by the reference's loss at bert_modeling.py:212): zero loss and a zero
+    gradient row, still counted in the mean's denominator; any label outside [0, V) is treated the same and never used as an index."""
+    o = ops()
+    M, V = 40, 30000
+    logits = rnd(gen(M, V, seed=1) * 3, dtype)
+    labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(2))
+    labels[::3] = -100
+    w = torch.rand(M, generator=torch.Generator().manual_seed(3)) * 2
+    lr = logits.clone().requires_grad_(True)
+    loss = (F.cross_entropy(lr, labels, reduction="none") * w).mean()
+    loss.backward()
+    ld = logits.to(dev, dtype)
+    s = torch.zeros(1, device=dev)
+    o.ce_fwd_bwd_(ld, labels.to(dev), w.to(dev), s)
+    check("mlm loss (ignored labels)", s / M, loss.view(1), 1e-5)
+    check("d logits (ignored labels)", ld, lr.grad, TOL[dtype] if dtype == torch.bfloat16 else 1e-5)
+    assert float(ld[::3].float().abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------ small ops / optimizer
 @pytest.mark.parametrize("dtype", DT)
 def test_small_ops(dev, dtype):
