@@ -353,12 +353,188 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // =============================================================================================
+// Long key ranges in the exact-f32 path (compute_dtype = float32 at ViT-L/16 448^2: the decoder attends over 785 tokens,
+// model_ecamp.py:240-264; timm Attention.forward).  The kernels above keep a query row's scores in accumulator registers
+// (<= 256 keys); past that the parity mode uses these plain-f32 kernels: one wave per row, keys (or queries) 64 at a time,
+// softmax in two passes over the keys (statistics, then probabilities from lse), FMA chains instead of MFMA.  Parity
+// infrastructure of the product (exactness first); the bf16 production path has its own key-tiled online-softmax kernels.
+// =============================================================================================
+template <int HD>
+__device__ __forceinline__ float dot_row(const float* __restrict__ a, const float* __restrict__ b) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) acc = fmaf(a[d], b[d], acc);
+    return acc;
+}
+template <int HD>
+__global__ __launch_bounds__(256) void attn_long_fwd_kernel(AttnArgs a) {
+    __shared__ float sq[4][HD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= (long)a.B * a.H * a.Tq) return;
+    const int i = (int)(row % a.Tq), h = (int)((row / a.Tq) % a.H), b = (int)(row / ((long)a.Tq * a.H));
+    const float* q = reinterpret_cast<const float*>(a.q) + b * a.q_sb + h * a.q_sh + (long)i * a.q_st;
+    const float* kb = reinterpret_cast<const float*>(a.k) + b * a.k_sb + h * a.k_sh;
+    const float* vb = reinterpret_cast<const float*>(a.v) + b * a.v_sb + h * a.v_sh;
+    float* o = reinterpret_cast<float*>(a.o) + b * a.o_sb + h * a.o_sh + (long)i * a.o_st;
+    for (int d = lane; d < HD; d += 64) sq[wave][d] = q[d] * a.scale;
+    __builtin_amdgcn_wave_barrier();
+    auto score = [&](int j) {
+        const bool ok = j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0);
+        return ok ? dot_row<HD>(sq[wave], kb + (long)j * a.k_st) : NEG_BIG;
+    };
+    float mx = NEG_BIG, sm = 0.f;
+    for (int j0 = 0; j0 < a.Tk; j0 += 64) {
+        const float sc = score(j0 + lane);
+        if (sc > 0.5f * NEG_BIG) {
+            const float m2 = fmaxf(mx, sc);
+            sm = sm * __expf(mx - m2) + __expf(sc - m2);
+            mx = m2;
+        }
+    }
+    const float wm = wave_max(mx);
+    sm = mx > 0.5f * NEG_BIG ? sm * __expf(mx - wm) : 0.f;
+    sm = wave_sum(sm);
+    const float lse = wm + __logf(sm);
+    if (lane == 0) a.lse[row] = lse;
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    float acc[(HD + 63) / 64];
+#pragma unroll
+    for (int t = 0; t < (HD + 63) / 64; ++t) acc[t] = 0.f;
+    for (int j0 = 0; j0 < a.Tk; j0 += 64) {
+        const int j = j0 + lane;
+        const float sc = score(j);
+        float p = sc > 0.5f * NEG_BIG ? __expf(sc - lse) : 0.f;
+        if (a.drop_p > 0.f && j < a.Tk) p *= dropout_scale(a.seed, a.offset, (uint64_t)row * (uint64_t)a.Tk + j, a.drop_p, inv_keep);
+        const int n = min(64, a.Tk - j0);
+        for (int jj = 0; jj < n; ++jj) {
+            const float pj = __shfl(p, jj, 64);
+#pragma unroll
+            for (int t = 0; t < (HD + 63) / 64; ++t) {
+                const int d = lane + 64 * t;
+                if (d < HD) acc[t] = fmaf(pj, vb[(long)(j0 + jj) * a.v_st + d], acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < (HD + 63) / 64; ++t) {
+        const int d = lane + 64 * t;
+        if (d < HD) o[d] = acc[t];
+    }
+}
+// dQ of one query row per wave (+ delta[row] = dO . O for the dK/dV kernel)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(AttnArgs a) {
+    __shared__ float sq[4][HD], sdo[4][HD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= (long)a.B * a.H * a.Tq) return;
+    const int i = (int)(row % a.Tq), h = (int)((row / a.Tq) % a.H), b = (int)(row / ((long)a.Tq * a.H));
+    const float* q = reinterpret_cast<const float*>(a.q) + b * a.q_sb + h * a.q_sh + (long)i * a.q_st;
+    const float* kb = reinterpret_cast<const float*>(a.k) + b * a.k_sb + h * a.k_sh;
+    const float* vb = reinterpret_cast<const float*>(a.v) + b * a.v_sb + h * a.v_sh;
+    const float* o = reinterpret_cast<const float*>(a.o) + b * a.o_sb + h * a.o_sh + (long)i * a.o_st;
+    const float* dO = reinterpret_cast<const float*>(a.dout) + b * a.do_sb + h * a.do_sh + (long)i * a.do_st;
+    float* dq = reinterpret_cast<float*>(a.dq) + b * a.dq_sb + h * a.dq_sh + (long)i * a.dq_st;
+    float part = 0.f;
+    for (int d = lane; d < HD; d += 64) {
+        sq[wave][d] = q[d] * a.scale;
+        sdo[wave][d] = dO[d];
+        part = fmaf(dO[d], o[d], part);
+    }
+    const float delta = wave_sum(part);
+    if (lane == 0) a.delta[row] = delta;
+    __builtin_amdgcn_wave_barrier();
+    const float lse = a.lse[row];
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    float acc[(HD + 63) / 64];
+#pragma unroll
+    for (int t = 0; t < (HD + 63) / 64; ++t) acc[t] = 0.f;
+    for (int j0 = 0; j0 < a.Tk; j0 += 64) {
+        const int j = j0 + lane;
+        float ds = 0.f;
+        if (j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0)) {
+            const float p = __expf(dot_row<HD>(sq[wave], kb + (long)j * a.k_st) - lse);
+            float dp = dot_row<HD>(sdo[wave], vb + (long)j * a.v_st);
+            if (a.drop_p > 0.f) dp *= dropout_scale(a.seed, a.offset, (uint64_t)row * (uint64_t)a.Tk + j, a.drop_p, inv_keep);
+            ds = p * (dp - delta);
+        }
+        const int n = min(64, a.Tk - j0);
+        for (int jj = 0; jj < n; ++jj) {
+            const float dj = __shfl(ds, jj, 64);
+#pragma unroll
+            for (int t = 0; t < (HD + 63) / 64; ++t) {
+                const int d = lane + 64 * t;
+                if (d < HD) acc[t] = fmaf(dj, kb[(long)(j0 + jj) * a.k_st + d], acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < (HD + 63) / 64; ++t) {
+        const int d = lane + 64 * t;
+        if (d < HD) dq[d] = acc[t] * a.scale;
+    }
+}
+// dK and dV of one key row per wave
+template <int HD>
+__global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ float sk[4][HD], sv[4][HD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long krow = (long)blockIdx.x * 4 + wave;
+    if (krow >= (long)a.B * a.H * a.Tk) return;
+    const int j = (int)(krow % a.Tk), h = (int)((krow / a.Tk) % a.H), b = (int)(krow / ((long)a.Tk * a.H));
+    const float* qb = reinterpret_cast<const float*>(a.q) + b * a.q_sb + h * a.q_sh;
+    const float* k = reinterpret_cast<const float*>(a.k) + b * a.k_sb + h * a.k_sh + (long)j * a.k_st;
+    const float* v = reinterpret_cast<const float*>(a.v) + b * a.v_sb + h * a.v_sh + (long)j * a.v_st;
+    const float* dOb = reinterpret_cast<const float*>(a.dout) + b * a.do_sb + h * a.do_sh;
+    float* dk = reinterpret_cast<float*>(a.dk) + b * a.dk_sb + h * a.dk_sh + (long)j * a.dk_st;
+    float* dv = reinterpret_cast<float*>(a.dv) + b * a.dv_sb + h * a.dv_sh + (long)j * a.dv_st;
+    for (int d = lane; d < HD; d += 64) { sk[wave][d] = k[d]; sv[wave][d] = v[d]; }
+    __builtin_amdgcn_wave_barrier();
+    const bool kok = a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0;
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    float ak[(HD + 63) / 64], av[(HD + 63) / 64];
+#pragma unroll
+    for (int t = 0; t < (HD + 63) / 64; ++t) { ak[t] = 0.f; av[t] = 0.f; }
+    const long r0 = ((long)b * a.H + h) * a.Tq;
+    for (int i0 = 0; i0 < a.Tq; i0 += 64) {
+        const int i = i0 + lane;
+        float ds = 0.f, pz = 0.f;
+        if (kok && i < a.Tq) {
+            const float* q = qb + (long)i * a.q_st;
+            const float p = __expf(dot_row<HD>(q, sk[wave]) * a.scale - a.lse[r0 + i]);
+            float z = 1.f;
+            if (a.drop_p > 0.f) z = dropout_scale(a.seed, a.offset, (uint64_t)(r0 + i) * (uint64_t)a.Tk + j, a.drop_p, inv_keep);
+            const float dp = dot_row<HD>(dOb + (long)i * a.do_st, sv[wave]) * z;
+            ds = p * (dp - a.delta[r0 + i]);
+            pz = p * z;
+        }
+        const int n = min(64, a.Tq - i0);
+        for (int ii = 0; ii < n; ++ii) {
+            const float di = __shfl(ds, ii, 64), pi = __shfl(pz, ii, 64);
+#pragma unroll
+            for (int t = 0; t < (HD + 63) / 64; ++t) {
+                const int d = lane + 64 * t;
+                if (d < HD) {
+                    ak[t] = fmaf(di, qb[(long)(i0 + ii) * a.q_st + d], ak[t]);
+                    av[t] = fmaf(pi, dOb[(long)(i0 + ii) * a.do_st + d], av[t]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < (HD + 63) / 64; ++t) {
+        const int d = lane + 64 * t;
+        if (d < HD) { dk[d] = ak[t] * a.scale; dv[d] = av[t]; }
+    }
+}
+
+// =============================================================================================
 // host entries
 // =============================================================================================
 static int attn_check(const AttnArgs& a, int hd, int dtype, bool bwd) {
     ECAMP_CHECK_ARG(hd == 32 || hd == 64 || hd == 128, "attention: head_dim %d not in {32,64,128}", hd);
     ECAMP_CHECK_ARG(a.Tk >= 1 && a.Tq >= 1, "attention: empty sequence");
-    ECAMP_CHECK_ARG(a.Tk <= 256 || dtype == ECAMP_BF16, "attention: Tk=%d > 256 is only built for the bf16 path (online-softmax kernel); the exact-f32 parity path holds all scores in registers", a.Tk);
     ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "attention: bad dtype");
     ECAMP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f, "attention: bad dropout p");
     const long m = dtype == ECAMP_BF16 ? 8 : 4;
@@ -385,6 +561,10 @@ static void allow_lds(K kern, size_t bytes) {
 
 template <typename T, int HD>
 static void fwd_dispatch(const AttnArgs& a, hipStream_t st) {
+    if (a.Tk > 256) {   // f32 only (the bf16 path never comes here): one wave per query row
+        hipLaunchKernelGGL((attn_long_fwd_kernel<HD>), dim3((unsigned)(((long)a.B * a.H * a.Tq + 3) / 4)), dim3(256), 0, st, a);
+        return;
+    }
     dim3 grid(ceil_div(a.Tq, 64), a.B * a.H), block(256);
     size_t shm = (size_t)(64 * (HD + 16) + 4 * 16 * PP) * sizeof(float);
     if (a.Tk <= 64) LAUNCH_LDS((attn_fwd_kernel<T, HD, 1>), grid, block, shm, st, a);
@@ -393,6 +573,11 @@ static void fwd_dispatch(const AttnArgs& a, hipStream_t st) {
 }
 template <typename T, int HD>
 static void bwd_dispatch(const AttnArgs& a, hipStream_t st) {
+    if (a.Tk > 256) {
+        hipLaunchKernelGGL((attn_long_bwd_dq_kernel<HD>), dim3((unsigned)(((long)a.B * a.H * a.Tq + 3) / 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_long_bwd_dkv_kernel<HD>), dim3((unsigned)(((long)a.B * a.H * a.Tk + 3) / 4)), dim3(256), 0, st, a);
+        return;
+    }
     dim3 grid(ceil_div(a.Tq, 64), a.B * a.H), block(256);
     size_t shm = (size_t)(2 * 64 * (HD + 2) + 4 * 16 * PP) * sizeof(float);
     if (a.Tk <= 64) LAUNCH_LDS((attn_bwd_dq_kernel<T, HD, 1>), grid, block, shm, st, a);

@@ -490,9 +490,12 @@ __device__ __forceinline__ void sr_conv_stage(float* dst, const float* src, cons
     }
 }
 
+// `sr_out` (optional, f32 [B,3,2R,2R]): the head's output image -- the reference's `self.super_res(pred_img)` (model_ecamp.py:28-46,
+// 285) -- for every tile, not only the loss window (parity checks / visualisation; the training step passes null and touches only
+// the window).  With `big` null only the image is produced.
 __global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
                                                            const long* __restrict__ column, const long* __restrict__ row, SrP P,
-                                                           float* __restrict__ loss_sum, long B, int R, int win) {
+                                                           float* __restrict__ loss_sum, long B, int R, int win, float* __restrict__ sr_out) {
     __shared__ SrW W;
     __shared__ float U[3 * 36 * 36];
     __shared__ float C1[3 * 34 * 34];
@@ -503,8 +506,12 @@ __global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restri
     for (long t = blockIdx.x; t < B * G * G; t += gridDim.x) {
         const long b = t / (G * G);
         const int ty = (int)((t / G) % G), tx = (int)(t % G);
-        const int c0 = (int)column[b], r0 = (int)row[b];
-        if (ty < c0 || ty >= c0 + win || tx < r0 || tx >= r0 + win) continue;  // block-uniform
+        bool in_win = false;
+        if (big) {
+            const int c0 = (int)column[b], r0 = (int)row[b];
+            in_win = !(ty < c0 || ty >= c0 + win || tx < r0 || tx >= r0 + win);
+        }
+        if (!in_win && !sr_out) continue;  // block-uniform
         const int Y0 = ty * SRT, X0 = tx * SRT;
         __syncthreads();
         sr_fill_u<2>(U, pred_img, b, Y0, X0, R);
@@ -527,13 +534,17 @@ __global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restri
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
                 float s = fmaxf(acc[o] + U[(o * 36 + y + 2) * 36 + x + 2], 0.f);
-                float d = s - big[((b * 3 + o) * (long)R2 + Y0 + y) * R2 + X0 + x];
-                part += d * d;
+                const long at = ((b * 3 + o) * (long)R2 + Y0 + y) * R2 + X0 + x;
+                if (sr_out) sr_out[at] = s;
+                if (in_win) {
+                    float d = s - big[at];
+                    part += d * d;
+                }
             }
         }
     }
     part = block_sum_256(part, sh);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, part);
+    if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, part);
 }
 
 // ---- bf16 matrix-core variant of the SR head (compute_dtype = bf16) ---------------------------------------------------------
@@ -1248,7 +1259,23 @@ extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64
                            (long)B, R, window);
     else
         hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
-                           (long)B, R, window);
+                           (long)B, R, window, (float*)nullptr);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// The SR head's output image itself (f32 stencils): sr [B,3,2R,2R] = relu(conv2(relu(conv1(up2(pred_img)))) + up2(pred_img)),
+// model_ecamp.py:28-46.  The training step never materialises it (ecamp_sr_fwd folds it into the loss); this entry serves the parity
+// checks against the reference's `super_res` output and visualisation.
+extern "C" int ecamp_sr_image(const float* pred_img, const float* w1, const float* b1, const float* w2, const float* b2, float* sr,
+                              int64_t B, int32_t R, hipStream_t stream) {
+    ECAMP_CHECK_ARG(pred_img && w1 && b1 && w2 && b2 && sr, "sr_image: null pointer");
+    ECAMP_CHECK_ARG((2 * R) % SRT == 0, "sr_image: 2R must be a multiple of 32");
+    SrP W = {w1, b1, w2, b2};
+    long tiles = B * (2 * R / SRT) * (2 * R / SRT);
+    int nb = (int)(tiles < 2048 ? tiles : 2048);
+    hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, (const float*)nullptr, (const long*)nullptr, (const long*)nullptr, W,
+                       (float*)nullptr, (long)B, R, 0, sr);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }

@@ -320,6 +320,14 @@ def sr_fwd(pred_img, big, column, row, w1, b1, w2, b2, loss_sum, super_patch, wi
          super_patch, window, int(mode), stream())
 
 
+def sr_image(pred_img, w1, b1, w2, b2):
+    """super_res(pred_img): f32 [B,3,2R,2R] (parity / visualisation; the training step never materialises it)."""
+    B, _, R, _ = pred_img.shape
+    out = torch.empty((B, 3, 2 * R, 2 * R), device=pred_img.device, dtype=torch.float32)
+    call("ecamp_sr_image", ptr(pred_img), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(out), B, R, stream())
+    return out
+
+
 def sr_bwd(pred_img, big, column, row, w1, b1, w2, b2, gw_ws, super_patch, window, mode=0):
     B, _, R, _ = pred_img.shape
     dsr = torch.empty((B, 3, R, R), device=pred_img.device, dtype=torch.float32)

@@ -31,8 +31,12 @@ class MultimodalBertModel(nn.Module):
         key_mask = attention_mask.to(torch.int32).contiguous()  # additive finfo.min mask of bert_modeling.py:92, as a predicate
         e = BertEmbedFn.apply(input_ids, token_type_ids, self.embeddings, owner, ph, self.embeddings.LayerNorm.weight)
         h = self.context_fusion_layer(e, latent, gap_token, owner, B, S, T, key_mask)
+        if getattr(owner, "keep_aux", False):   # parity checks: the fusion layer's and the encoder's outputs (bert_modeling.py:186-208)
+            owner._aux_text = {"fused": h.detach().clone().view(B, S, -1)}
         for layer in self.encoder.layer:
             h = BertLayerFn.apply(h, layer, owner, B, S, key_mask, pa, ph)
+        if getattr(owner, "keep_aux", False):
+            owner._aux_text["seq_out"] = h.detach().clone().view(B, S, -1)
         return h
 
 

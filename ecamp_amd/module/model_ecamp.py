@@ -332,7 +332,7 @@ class ECAMP(nn.Module):
         mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
         if self.keep_aux:
             self._aux = dict(self._aux or {}, imgs=imgs, mask=mask, ids_restore=ids_restore, ids_keep=ids_keep,
-                             latent=latent.view(B, T, -1), logits=self._aux_logits)
+                             latent=latent.view(B, T, -1), logits=self._aux_logits, **(getattr(self, "_aux_text", None) or {}))
         return img_losses[0], img_losses[1], mlm_loss
 
 

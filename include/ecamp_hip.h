@@ -137,6 +137,10 @@ int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column,
                  const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B, int32_t R, int32_t super_patch,
                  int32_t window, int32_t mode, ecampStream_t stream); /* model_ecamp.py:28-46,196-215,291-299; fused, LDS-resident.
                  mode 0: f32 VALU stencils (parity); mode 1: bf16 matrix cores (4x4x4 MFMA per tap), f32 accumulate / skip / loss */
+/* The SR head's output image itself, f32 [B,3,2R,2R] = super_res(pred_img) (model_ecamp.py:28-46,285): never materialised by the
+ * training step (ecamp_sr_fwd folds it into the loss); for parity checks against the reference's activation and visualisation. */
+int ecamp_sr_image(const float* pred_img, const float* w1, const float* b1, const float* w2, const float* b2, float* sr, int64_t B,
+                   int32_t R, ecampStream_t stream);
 int ecamp_sr_bwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
                  const float* b1, const float* w2, const float* b2, float* dsr, float* gw_ws, int64_t B, int32_t R,
                  int32_t super_patch, int32_t window, int32_t mode, ecampStream_t stream);

@@ -540,6 +540,29 @@ def test_adamw_and_gradnorm(dev):
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,hd,masked", [(1, 16, 785, 785, 32, False), (2, 4, 300, 300, 64, True), (1, 3, 70, 520, 128, False)])
+def test_attention_long_sequence_f32(dev, B, H, Tq, Tk, hd, masked):
+    """Tk > 256 in the exact-f32 parity path (attn_long_* kernels) against plain PyTorch fp32, forward and backward, with a key mask."""
+    o = ops()
+    D = H * hd
+    q, k, v, do = gen(B, Tq, D, seed=1), gen(B, Tk, D, seed=2), gen(B, Tk, D, seed=3), gen(B, Tq, D, seed=4)
+    km = (torch.arange(Tk)[None, :] < torch.tensor([Tk - 37, Tk][:B])[:, None]).int() if masked else None
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t, n: t.view(B, n, H, hd).permute(0, 2, 1, 3)
+    out = ref_attn(sp(qr, Tq), sp(kr, Tk), sp(vr, Tk), hd ** -0.5, km).permute(0, 2, 1, 3).reshape(B, Tq, D)
+    out.backward(do)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    kmd = km.to(dev) if km is not None else None
+    qs, ks = (Tq * D, D, hd), (Tk * D, D, hd)
+    og, lse = o.attn_fwd(qd, kd, vd, B, H, Tq, Tk, hd, qs, ks, ks, hd ** -0.5, key_mask=kmd)
+    check("long f32 attn out", og, out, 2e-5)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    o.attn_bwd(qd, kd, vd, og, do.to(dev), lse, dq, dk, dv, B, H, Tq, Tk, hd, qs, ks, ks, qs, ks, ks, hd ** -0.5, key_mask=kmd)
+    check("long f32 attn dq", dq, qr.grad, 5e-5)
+    check("long f32 attn dk", dk, kr.grad, 5e-5)
+    check("long f32 attn dv", dv, vr.grad, 5e-5)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,hd,masked", [(1, 16, 785, 785, 32, False), (2, 4, 300, 300, 64, True), (1, 3, 70, 520, 128, False)])
 def test_attention_long_sequence_bf16(dev, B, H, Tq, Tk, hd, masked):
     """Tk > 256 (ViT-L/16 at 448^2: decoder sequence 785) runs the online-softmax forward and the chunk-streaming backward."""
     o = ops()

@@ -57,8 +57,12 @@ def test_forward_backward_matches_reference_fp32(dev, name):
     assert (aux["ids_restore"].cpu().numpy() == g["ids_restore"]).all()
     assert (aux["mask"].cpu().numpy() == g["mask"]).all()
     L = cfg.num_patches
+    from ecamp_amd import hip_ops
+    sr = model.super_res
     acts = {"imgs": aux["imgs"], "latent": aux["latent"], "pred": aux["pred"].view(B, L + 1, -1)[:, 1:], "pred_img": aux["pred_img"],
-            "logits": aux["logits"].view(B, S, -1)}
+            # the SR head's output is never materialised by the training step: the same f32 stencils write it out here
+            "sr": hip_ops.sr_image(aux["pred_img"], sr.conv1.weight.data, sr.conv1.bias.data, sr.conv2.weight.data, sr.conv2.bias.data),
+            "fused": aux["fused"], "seq_out": aux["seq_out"], "logits": aux["logits"].view(B, S, -1)}
     for k, t in acts.items():
         nm, s = digest(t.float().cpu())
         e = max(rel(nm[0], g["act/%s/nm" % k][0]), rel(s, g["act/%s/s" % k]))
@@ -90,12 +94,24 @@ def test_forward_backward_bf16_within_tolerance(dev, name):
     from oracle import recipe
     g = _load(name)
     B, S = int(g["meta/B"]), int(g["meta/S"])
+    from oracle.make_golden import digest
     model, cfg = _build(name, torch.bfloat16, dev)
     model.eval()
+    model.keep_aux = True
     mim, res, mlm = model(recipe.recipe_batch(cfg, B, S, seed=0), mask_ratio=0.75, noise=recipe.recipe_noise(B, cfg.num_patches, seed=0))
     losses = np.array([mim.item(), res.item(), mlm.item()])
     print(name, "bf16 losses", losses, "golden", g["losses"], "rel", np.abs(losses - g["losses"]) / g["losses"])
     assert (np.abs(losses - g["losses"]) / g["losses"]).max() < 3e-2
+    # activations of the PRODUCTION kernels (bf16 GEMM / attention / LayerNorm) against the reference's own, at bf16 resolution: the
+    # norm of each tensor to 3e-2, its strided sample to 3e-2 of the tensor's largest sampled magnitude
+    aux, L = model._aux, cfg.num_patches
+    acts = {"latent": aux["latent"], "pred": aux["pred"].view(B, L + 1, -1)[:, 1:], "pred_img": aux["pred_img"], "fused": aux["fused"],
+            "seq_out": aux["seq_out"], "logits": aux["logits"].view(B, S, -1)}
+    for k, t in acts.items():
+        nm, s = digest(t.float().cpu())
+        e = max(rel(nm[0], g["act/%s/nm" % k][0]), rel(s, g["act/%s/s" % k]))
+        print("  bf16 act %-10s rel err %.2e" % (k, e))
+        assert e < 3e-2, (k, e)
     (mim + res + mlm).backward()
     names = list(g["grad/names"])
     params = dict(model.named_parameters())
@@ -103,7 +119,7 @@ def test_forward_backward_bf16_within_tolerance(dev, name):
     big = g["grad/norms"] > 1e-3 * g["grad/norms"].max()
     e = np.abs(norms - g["grad/norms"])[big] / g["grad/norms"][big]
     print("  bf16 grad-norm rel err: median %.2e max %.2e" % (np.median(e), e.max()))
-    assert np.median(e) < 3e-2 and e.max() < 0.25
+    assert np.median(e) < 1e-2 and e.max() < 6e-2   # measured: median 2e-3, worst tensor 2e-2
 
 
 def test_engine_step_matches_reference(dev):
@@ -215,6 +231,38 @@ def test_vit_large_448_bf16_matches_oracle(dev):
         if p.requires_grad:
             assert torch.isfinite(p.grad).all(), n
     assert model.decoder_blocks[0].attn.qkv.weight.grad.abs().sum().item() > 0
+
+
+def test_vit_large_448_fp32_matches_oracle(dev):
+    """configs[3] in the fp32 parity mode: the 785-token decoder attention runs the exact-f32 long-key kernels
+    (csrc/attention.hip attn_long_*).  Losses against the oracle to 2e-4 (north-star tolerance 1e-3), and the gradient of the
+    first decoder block's qkv weight -- which sits behind the long attention backward -- to 1e-3."""
+    from ecamp_amd.module import model_ecamp as me
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    torch.set_num_threads(16)
+    cfg = orc.cfg_large448()
+    B, S = 1, 64
+    state = recipe.recipe_state(cfg, seed=0)
+    batch = recipe.recipe_batch(cfg, B, S, seed=0)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=0)
+    P = orc.set_requires_grad(orc.load_state(orc.new_params(cfg), state), cfg)
+    ref = orc.forward(P, cfg, batch, 0.75, noise)
+    sum(ref).backward()
+    model = me.ecamp_large_448(compute_dtype=torch.float32)
+    model.load_state_dict(state, strict=True)
+    model.to(dev).eval()
+    out = model(batch, noise=noise)
+    got = np.array([t.item() for t in out])
+    want = np.array([t.item() for t in ref])
+    print("ViT-L/448 fp32", got, "oracle", want, "rel", np.abs(got - want) / want)
+    assert (np.abs(got - want) / want).max() < 2e-4
+    sum(out).backward()
+    for key, p in (("decoder_blocks.0.attn.qkv.weight", model.decoder_blocks[0].attn.qkv.weight), ("blocks.0.attn.qkv.weight", model.blocks[0].attn.qkv.weight)):
+        g, gr = p.grad.float().cpu(), P[key].grad
+        e = float((g - gr).norm() / gr.norm())
+        print("  grad(%s) rel err %.2e" % (key, e))
+        assert e < 1e-3, (key, e)
 
 
 @pytest.mark.parametrize("B,S,mask_ratio", [(1, 37, 0.75), (3, 200, 0.5), (2, 256, 0.9)])
