@@ -21,11 +21,11 @@ class EcampHipError(RuntimeError):
 
 
 def parse_header(path=HEADER):
-    """-> {name: (restype, [(ctype, argname), ...])} for every `int ecamp_*(...)` / `const char* ecamp_*` prototype."""
+    """-> {name: (restype, [(ctype, argname), ...])} for every `int ecamp_*(...)` / `int64_t ecamp_*` / `const char* ecamp_*` prototype."""
     txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(ecamp_\w+)\s*\(([^)]*)\)\s*;", txt):
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(ecamp_\w+)\s*\(([^)]*)\)\s*;", txt):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         argl = []
         for a in [x.strip() for x in args.split(",")]:
@@ -37,7 +37,7 @@ def parse_header(path=HEADER):
                 parts = a.split()
                 ct, an = _CT[parts[-2]], parts[-1]
             argl.append((ct, an))
-        protos[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int32, argl)
+        protos[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int64 if ret == "int64_t" else ctypes.c_int32, argl)
     return protos
 
 

@@ -617,6 +617,9 @@ extern "C" int ecamp_attn_fwd(const void* q, const void* k, const void* v, void*
     return 0;
 }
 
+// Workspace of ecamp_attn_bwd(..., delta_ws, ...): delta[b, h, i] = dO_i . O_i, one f32 per query row.
+extern "C" int64_t ecamp_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq) { return (int64_t)B * H * Tq * 4; }
+
 extern "C" int ecamp_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                               float* delta_ws, void* dq, void* dk, void* dv, const int32_t* key_mask, int32_t B, int32_t H,
                               int32_t Tq, int32_t Tk, int32_t hd, const int64_t* q_strides, const int64_t* k_strides,

@@ -990,6 +990,19 @@ extern "C" int ecamp_set_option(const char* name, int32_t value) {
     return ecamp_set_error(-1, "set_option: unknown option '%s'", name);
 }
 
+// the Q8 kernel is selected from this many 256^2 work items up (measured: 150 tiles on 256 CUs still beat the 128^2 kernel by 10-20 %)
+static long q8_min_items() {
+    static const long v = getenv("ECAMP_Q8_MIN_ITEMS") ? atol(getenv("ECAMP_Q8_MIN_ITEMS")) : (long)(0.5 * p8_num_cu());
+    return v;
+}
+// weight-gradient GEMMs: work items (tiles x split-K slices) the split is chosen for.  A slice costs an M x N f32 slab written and
+// re-read, so fewer, longer items are cheaper per FLOP; on the side stream the rest of the chip is busy with the data-gradient chain
+// anyway.  ECAMP_WGRAD_ITEMS overrides (development).
+static long wgrad_target_items(int ncu) {
+    static const long v = getenv("ECAMP_WGRAD_ITEMS") ? atol(getenv("ECAMP_WGRAD_ITEMS")) : 0;
+    return v > 0 ? v : ncu;
+}
+
 extern "C" int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype) {
     if (M <= 0 || N <= 0 || K <= 0) return 1;
     int ncu = p8_num_cu();
@@ -1004,17 +1017,26 @@ extern "C" int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_k
     // persistent 256^2 kernel: one workgroup per CU walks the work items; pick the split count whose item count fills whole
     // rounds of the chip, preferring fewer splits (each split writes and re-reads an M x N f32 slab)
     const long t8 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    const long tgt = (!a_kc && !b_kc) ? wgrad_target_items(ncu) : ncu;
     int best = 1;
     double best_score = -1.0;
     for (int sp = 1; sp <= 32; ++sp) {
         if (sp > 1 && K / sp < 512) break;
         const long items = t8 * sp;
-        const long rounds = (items + ncu - 1) / ncu;
-        const double score = (double)items / (double)(rounds * ncu) - 0.012 * (sp - 1);
+        const long rounds = (items + tgt - 1) / tgt;
+        const double score = (double)items / (double)(rounds * tgt) - 0.012 * (sp - 1);
         if (score > best_score + 1e-9) { best_score = score; best = sp; }
     }
+    if (q8_env() != 0 && t8 * best >= q8_min_items()) return best;
     if (!p8_selected(M, N, K, a_kc, b_kc, dtype, best)) return (int)s_old;
     return best;
+}
+
+// Workspace of ecamp_gemm(..., split_k, splitk_ws, ...): split_k stacked M x N f32 slabs (0 when split_k <= 1).  The split count is
+// the caller's (ecamp_gemm_suggest_split recommends one); the library only ever lowers it (whole K tiles per slice).
+extern "C" int64_t ecamp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int32_t split_k) {
+    (void)K;
+    return split_k > 1 && M > 0 && N > 0 ? (int64_t)split_k * M * N * 4 : 0;
 }
 
 extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda,
@@ -1062,8 +1084,7 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     {
         const int q8m = q8_env();
         const long items8 = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
-        static const long q8_min_items = getenv("ECAMP_Q8_MIN_ITEMS") ? atol(getenv("ECAMP_Q8_MIN_ITEMS")) : (long)(0.5 * p8_num_cu());   // measured: 150 tiles on 256 CUs still beat the 128^2 kernel by 10-20 %
-        if (q8m != 0 && (q8m == 2 || items8 >= q8_min_items) &&
+        if (q8m != 0 && (q8m == 2 || items8 >= q8_min_items()) &&
             q8_legal(A, B, C, M, N, K, a_kc, lda, b_kc, ldb, ldc, bias, residual, ldr, pre_out, ldp, gmul, ldg, act, dtype, g.out_f32, split_k, splitk_ws, rowsum)) {
             const int epi = q8_epi(bias, residual, pre_out, gmul, act, g.out_f32);
             const q8_fn fn = q8_pick(a_kc, b_kc, epi, rowsum != nullptr);

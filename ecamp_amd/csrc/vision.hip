@@ -1280,6 +1280,9 @@ extern "C" int ecamp_sr_image(const float* pred_img, const float* w1, const floa
     return 0;
 }
 
+// Workspace of ecamp_sr_bwd(..., gw_ws, ...): {dW1[81], db1[3], dW2[81], db2[3]} f32, zeroed by the caller.
+extern "C" int64_t ecamp_sr_bwd_workspace_bytes(void) { return 168 * 4; }
+
 // dsr: f32 [B,3,R,R] = d(0.5*res_sum)/d pred_img;  gw_ws[168] += {dW1[81], db1[3], dW2[81], db2[3]} (unscaled; the caller
 // folds g_res*2/N in when adding into the .grad views).
 extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,

@@ -38,7 +38,8 @@ def ptr(t):
 def gemm(A, B, C, M, N, K, a_kc, lda, b_kc, ldb, ldc, bias=None, residual=None, ldr=0, pre_out=None, ldp=0, gmul=None,
          ldg=0, act=0, alpha=1.0, alpha_dev=None, out_f32=False, accumulate=False, split_k=1, rowsum=None):
     _chk(A, B, C)
-    ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32) if split_k > 1 else None
+    nws = int(_lib.load().ecamp_gemm_workspace_bytes(M, N, K, int(split_k))) // 4
+    ws = torch.empty((nws,), device=A.device, dtype=torch.float32) if nws > 0 else None
     call("ecamp_gemm", ptr(A), ptr(B), ptr(C), M, N, K, int(a_kc), lda, int(b_kc), ldb, ldc, ptr(bias), ptr(residual), ldr,
          ptr(pre_out), ldp, ptr(gmul), ldg, int(act), float(alpha), ptr(alpha_dev), code(A.dtype), int(out_f32), int(accumulate), int(split_k),
          ptr(ws), ptr(rowsum), stream())

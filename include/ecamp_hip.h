@@ -47,6 +47,13 @@ int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int6
  * torch.autograd for nn.Linear, e.g. timm Mlp.fc1 at model_ecamp.py:233): it depends on which kernel the shape selects
  * (128^2 tiles, or the persistent 256^2 kernel whose work items should fill whole rounds of the chip).  Pure host arithmetic. */
 int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype);
+/* Workspace sizes (bytes) the caller allocates and passes in -- the library never allocates:
+ *   ecamp_gemm_workspace_bytes      `splitk_ws` of ecamp_gemm for this split count (0 when split_k <= 1)
+ *   ecamp_attn_bwd_workspace_bytes  `delta_ws` of ecamp_attn_bwd (one f32 per query row)
+ *   ecamp_sr_bwd_workspace_bytes    `gw_ws` of ecamp_sr_bwd (168 f32, zeroed by the caller) */
+int64_t ecamp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int32_t split_k);
+int64_t ecamp_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq);
+int64_t ecamp_sr_bwd_workspace_bytes(void);
 /* Process-wide switches with no reference counterpart.  "p8_mode": -1 automatic kernel selection (default), 0 never / 2 always the
  * persistent 256^2 kernel (overrides ECAMP_GEMM_P8; used by the tests to exercise both kernels on every shape).  "p8_wgrad" (default 1): 0 keeps weight-gradient GEMMs off the persistent
  * one-workgroup-per-CU kernel.  "p8_wgrad_reserve_cus" (default 0): launch that kernel with this many fewer workgroups than CUs --
