@@ -661,6 +661,315 @@ __global__ __launch_bounds__(256) void attn16r_fwd_kernel(AttnArgs a) {
     }
 }
 
+// =============================================================================================
+// "Head" kernels: one workgroup per (batch, head), everything the head needs staged ONCE, no workgroup barrier inside the tile
+// loops and NO LDS round trip for the probabilities.  Every attention of this model is short (50 / 128 / 197 tokens) and tiny in
+// FLOPs: the measured bounds of the 64-row streaming kernels above were the per-chunk barrier + global-latency chain, ~13 VALU
+// instructions per score element, and 256^2 scores computed for a 197^2 problem (profiles/r02_pmc_sq_attention.txt).
+//   * LDS images are unpadded, 16-B chunks XOR-swizzled by row (hswz), zero-filled up to a multiple of 32 rows.
+//   * S^T = K Q^T on v_mfma_f32_16x16x32_bf16 leaves lane (li, g) with scores of query li and keys 16t + 4g + r.  Two key tiles
+//     (t, t+1) of the SAME lane are exactly one B operand of the next MFMA if its contraction index is taken in the order
+//     kappa = 8g + e  <->  key 16(t + e/4) + 4g + e%4: the A operand (V^T, K^T, dO^T, Q^T via ds_read_b64_tr_b16) simply reads
+//     its two 4-row groups from rows 16t + 4g and 16(t+1) + 4g.  P / dS never leave the registers.
+//   * Scores are kept raw: max over raw scores (scale > 0), p = exp2(fma(s, scale*log2e, -max*scale*log2e)); masked / padded
+//     keys get an additive -1e30 only in tiles that contain one; normalisation is applied to O once.  ~4.5 VALU / element.
+//   * Tile loops run over the tiles that exist (13 x 13 for T = 197, not 16 x 16).
+//   * Backward is ONE kernel: phase 1 (K, V resident; a wave owns 16 queries) produces dQ and leaves lse / delta in LDS; phase 2
+//     (Q, dO staged over the same LDS; a wave owns 16 keys) produces dK and dV.  The operands a wave owns come straight from
+//     global memory as MFMA fragments (the second read of each tensor is an L2 hit: the same workgroup has just staged it).
+// compile-time loop: the score array must stay in registers (a `#pragma unroll` loop of 16 guarded bodies is left rolled by hipcc
+// and the array lands in scratch)
+template <int I, int N, typename F> __device__ __forceinline__ void head_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        head_static_for<I + 1, N>(f);
+    }
+}
+template <int HD> struct HeadCfg {
+    static constexpr int RB = HD * 2, CPR = HD / 8, RPW = 256 / RB;   // row bytes, 16-B chunks per row, rows per 256-B bank window
+};
+template <int HD> __device__ __forceinline__ int hswz(int row) { return (row / HeadCfg<HD>::RPW) & (HeadCfg<HD>::CPR - 1); }
+template <int HD> __device__ __forceinline__ unsigned haddr(int row, int chunk) {
+    return (unsigned)(row * HeadCfg<HD>::RB + ((chunk ^ hswz<HD>(row)) << 4));
+}
+// rows [0, nrows) of a (b, h) slice -> swizzled image of `prow` rows (zeros past nrows); four independent loads in flight per thread
+template <int HD>
+__device__ __forceinline__ void head_stage(unsigned char* img, const bf16_t* base, long st, int nrows, int prow, int tid, int nthr) {
+    constexpr int CPR = HeadCfg<HD>::CPR;
+    const int n = prow * CPR;
+    for (int i0 = tid; i0 < n; i0 += 4 * nthr) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i0 + u * nthr, row = idx / CPR, ch = idx % CPR;
+            v[u] = (idx < n && row < nrows) ? *reinterpret_cast<const uint4*>(base + (long)row * st + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i0 + u * nthr, row = idx / CPR, ch = idx % CPR;
+            if (idx < n) *reinterpret_cast<uint4*>(img + haddr<HD>(row, ch)) = v[u];
+        }
+    }
+}
+template <int HD> __device__ __forceinline__ bf16x8 hfrag(const unsigned char* img, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(img + haddr<HD>(row, chunk));
+}
+// transposed A operand for a contraction over 32 image ROWS taken as two groups of 16 (ra, rb): lane (i, g) ends up with
+// column o0 + i of rows ra + 4g .. +3 and rb + 4g .. +3
+template <int HD>
+__device__ __forceinline__ bf16x8 hfrag_tr(const unsigned char* img, int o0, int ra, int rb, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int cb = (o0 + (i & 3) * 4) * 2, ch = cb >> 4, in = cb & 15;
+    const int r0 = ra + 4 * g + (i >> 2), r1 = rb + 4 * g + (i >> 2);
+    v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(img + haddr<HD>(r0, ch) + in));
+    v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(img + haddr<HD>(r1, ch) + in));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 hpack8(const float (&v)[8]) {
+    const uint4 u = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    return __builtin_bit_cast(bf16x8, u);
+}
+// additive key bias (0 attend / -1e30 masked or padded) of `prow` keys, and the bit mask of 16-key tiles that hold a biased key
+__device__ __forceinline__ void head_key_bias(float* KB, const AttnArgs& a, int b, int prow, int tid, int nthr) {
+    for (int j = tid; j < prow; j += nthr)
+        KB[j] = (j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0)) ? 0.f : NEG_BIG;
+}
+__device__ __forceinline__ unsigned head_tile_mask(const float* KB, int nkt, int li) {
+    unsigned tm = 0;
+    for (int t = 0; t < nkt; ++t)
+        if (__ballot(KB[t * 16 + li] != 0.f) != 0ull) tm |= 1u << t;
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)tm);
+}
+
+// NT: score tiles (of 16 keys) a lane can hold, Tk <= 16 NT.  NW: waves.
+template <int HD, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_head_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RB = HeadCfg<HD>::RB, NTHR = NW * 64;
+    const int nkt = (a.Tk + 15) >> 4, prow = ((nkt + 1) >> 1) * 32;
+    unsigned char* KI = smem;
+    unsigned char* VI = smem + prow * RB;
+    float* KB = reinterpret_cast<float*>(smem + 2 * prow * RB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const long bh = blockIdx.x;
+    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
+    bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_sb + h * a.o_sh;
+    head_stage<HD>(KI, kb, a.k_st, a.Tk, prow, tid, NTHR);
+    head_stage<HD>(VI, vb, a.v_st, a.Tk, prow, tid, NTHR);
+    head_key_bias(KB, a, b, prow, tid, NTHR);
+    __syncthreads();
+    const unsigned tmask = head_tile_mask(KB, nkt, li);
+    const float sc2 = a.scale * ATTN_LOG2E;
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    for (int q0 = wave * 16; q0 < a.Tq; q0 += NW * 16) {
+        bf16x8 qf[HD / 32];
+        load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
+        f32x4 s[NT];
+        float mx = NEG_BIG;
+        head_static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if (t < nkt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) acc = MFMA(hfrag<HD>(KI, t * 16 + li, ks * 4 + g), qf[ks], acc);
+                if ((tmask >> t) & 1u) {
+                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += kb4[r];
+                }
+                mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+                s[t] = acc;
+            }
+        });
+        mx = red4_max(mx);
+        const float mxs = fmaxf(mx * sc2, -1e29f);   // a row with no valid key keeps every p at 0
+        const int qi = q0 + li;
+        float sum = 0.f;
+        f32x4 o[HD / 16];  // o[dt][r] = O[i = q0+li][d = dt*16 + 4g + r]
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        head_static_for<0, NT / 2>([&](auto pc) {
+            constexpr int pp = decltype(pc)::value;
+            if (2 * pp < nkt) {
+                float p[8];
+                head_static_for<0, 2>([&](auto hc) {
+                    constexpr int hf = decltype(hc)::value, t = 2 * pp + hf;
+                    if (t < nkt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            p[4 * hf + r] = attn_exp2(fmaf(s[t][r], sc2, -mxs));
+                            sum += p[4 * hf + r];
+                        }
+                        if (a.drop_p > 0.f) {
+                            float dm[4];
+                            attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) p[4 * hf + r] *= dm[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p[4 * hf + r] = 0.f;
+                    }
+                });
+                const bf16x8 pf = hpack8(p);
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt) o[dt] = MFMA(hfrag_tr<HD>(VI, dt * 16, pp * 32, pp * 32 + 16, lane), pf, o[dt]);
+            }
+        });
+        sum = red4_sum(sum);
+        if (qi < a.Tq) {
+            if (g == 0) a.lse[bh * a.Tq + qi] = (mxs + __log2f(sum)) * ATTN_LN2;
+            const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) store4(ob + (long)qi * a.o_st + dt * 16 + 4 * g, o[dt], inv);
+        }
+    }
+}
+
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_head_bwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RB = HeadCfg<HD>::RB, NTHR = NW * 64;
+    const int nkt = (a.Tk + 15) >> 4, nkp = (nkt + 1) >> 1, nqt = (a.Tq + 15) >> 4, nqp = (nqt + 1) >> 1;
+    const int prow = max(nkp, nqp) * 32;
+    unsigned char* XI = smem;                 // phase 1: K     phase 2: Q
+    unsigned char* YI = smem + prow * RB;     // phase 1: V     phase 2: dO
+    float* KB = reinterpret_cast<float*>(smem + 2 * prow * RB);   // key bias, prow entries
+    float* LS = KB + prow;                                        // lse in base-2 units (+1e30 past Tq: p = 0), prow entries
+    float* DL = LS + prow;                                        // delta = rowsum(dO * O)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const long bh = blockIdx.x;
+    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
+    const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.o) + b * a.o_sb + h * a.o_sh;
+    const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_sb + h * a.do_sh;
+    bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_sb + h * a.dq_sh;
+    bf16_t* dkb = reinterpret_cast<bf16_t*>(a.dk) + b * a.dk_sb + h * a.dk_sh;
+    bf16_t* dvb = reinterpret_cast<bf16_t*>(a.dv) + b * a.dv_sb + h * a.dv_sh;
+    const float sc2 = a.scale * ATTN_LOG2E;
+    const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+
+    // ---- phase 1: dQ (+ lse, delta -> LDS) -------------------------------------------------------------------------------------
+    head_stage<HD>(XI, kb, a.k_st, a.Tk, prow, tid, NTHR);
+    head_stage<HD>(YI, vb, a.v_st, a.Tk, prow, tid, NTHR);
+    head_key_bias(KB, a, b, prow, tid, NTHR);
+    for (int i = nqt * 16 + tid; i < prow; i += NTHR) { LS[i] = 1e30f; DL[i] = 0.f; }
+    __syncthreads();
+    for (int q0 = wave * 16; q0 < a.Tq; q0 += NW * 16) {
+        bf16x8 qf[HD / 32], gf[HD / 32];
+        float dl = 0.f;
+        {
+            bf16x8 of[HD / 32];
+            load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
+            load_row_frags<HD>(gf, gb, a.do_st, q0, a.Tq, lane);
+            load_row_frags<HD>(of, ob, a.o_st, q0, a.Tq, lane);
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)gf[ks][e]) * bf2f((bf16_t)of[ks][e]);
+        }
+        dl = red4_sum(dl);
+        const int qi = q0 + li;
+        const bool qok = qi < a.Tq;
+        const float lse2 = qok ? a.lse[bh * a.Tq + qi] * ATTN_LOG2E : 1e30f;
+        if (g == 0) {
+            LS[qi] = lse2;
+            DL[qi] = qok ? dl : 0.f;
+            if (qok && a.delta) a.delta[bh * a.Tq + qi] = dl;
+        }
+        f32x4 dq[HD / 16];  // dq[dt][r] = dQ[i = q0+li][d = dt*16 + 4g + r]
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int pp = 0; pp < nkp; ++pp) {
+            float ds[8];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int t = 2 * pp + hf;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) {
+                    s = MFMA(hfrag<HD>(XI, t * 16 + li, ks * 4 + g), qf[ks], s);
+                    dp = MFMA(hfrag<HD>(YI, t * 16 + li, ks * 4 + g), gf[ks], dp);
+                }
+                const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.drop_p > 0.f) attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = attn_exp2(fmaf(s[r] + kb4[r], sc2, -lse2));
+                    ds[4 * hf + r] = p * (dp[r] * dm[r] - dl);
+                }
+            }
+            const bf16x8 sf = hpack8(ds);
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = MFMA(hfrag_tr<HD>(XI, dt * 16, pp * 32, pp * 32 + 16, lane), sf, dq[dt]);
+        }
+        if (qok) {
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) store4(dqb + (long)qi * a.dq_st + dt * 16 + 4 * g, dq[dt], a.scale);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: dK, dV ---------------------------------------------------------------------------------------------------------
+    head_stage<HD>(XI, qb, a.q_st, a.Tq, prow, tid, NTHR);
+    head_stage<HD>(YI, gb, a.do_st, a.Tq, prow, tid, NTHR);
+    __syncthreads();
+    for (int j0 = wave * 16; j0 < a.Tk; j0 += NW * 16) {
+        bf16x8 kf[HD / 32], vf[HD / 32];
+        load_row_frags<HD>(kf, kb, a.k_st, j0, a.Tk, lane);
+        load_row_frags<HD>(vf, vb, a.v_st, j0, a.Tk, lane);
+        const int kj = j0 + li;
+        const bool jok = KB[kj] == 0.f;
+        f32x4 dk[HD / 16], dv[HD / 16];   // [dt][r] = dK / dV[j = j0+li][d = dt*16 + 4g + r]
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ip = 0; ip < nqp; ++ip) {
+            float pd[8], ds[8];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int it = 2 * ip + hf;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) {
+                    s = MFMA(hfrag<HD>(XI, it * 16 + li, ks * 4 + g), kf[ks], s);
+                    dp = MFMA(hfrag<HD>(YI, it * 16 + li, ks * 4 + g), vf[ks], dp);
+                }
+                const f32x4 lse4 = *reinterpret_cast<const f32x4*>(LS + it * 16 + 4 * g);
+                const f32x4 dl4 = *reinterpret_cast<const f32x4*>(DL + it * 16 + 4 * g);
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.drop_p > 0.f) attn_drop4_col(a, (uint64_t)bh * a.Tq + (it * 16 + 4 * g), kj, li, inv_keep, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = attn_exp2(fmaf(s[r], sc2, -lse4[r]));
+                    pd[4 * hf + r] = p * dm[r];
+                    ds[4 * hf + r] = p * (dp[r] * dm[r] - dl4[r]);
+                }
+            }
+            const bf16x8 pf = hpack8(pd), sf = hpack8(ds);
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) {
+                dv[dt] = MFMA(hfrag_tr<HD>(YI, dt * 16, ip * 32, ip * 32 + 16, lane), pf, dv[dt]);
+                dk[dt] = MFMA(hfrag_tr<HD>(XI, dt * 16, ip * 32, ip * 32 + 16, lane), sf, dk[dt]);
+            }
+        }
+        if (kj < a.Tk) {
+            const float mk = jok ? a.scale : 0.f, mv = jok ? 1.0f : 0.f;   // a masked key got probability 0 in the forward pass
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) {
+                store4(dkb + (long)kj * a.dk_st + dt * 16 + 4 * g, dk[dt], mk);
+                store4(dvb + (long)kj * a.dv_st + dt * 16 + 4 * g, dv[dt], mv);
+            }
+        }
+    }
+}
+
 template <typename K>
 static void lds_optin(K kern, size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -674,8 +983,46 @@ static void lds_optin(K kern, size_t bytes) {
 #define LDS_MAX (160 * 1024)
 
 // =============================================================================================
+#define LAUNCH_H(KERN, GRID, BLOCK, SHM, ST, ARGS)           \
+    do {                                                     \
+        static bool once_ = false;                           \
+        if (!once_) { lds_optin(KERN, SHM); once_ = true; }  \
+        hipLaunchKernelGGL(KERN, GRID, dim3(BLOCK), SHM, ST, ARGS); \
+    } while (0)
+// ECAMP_ATTN_HEAD=0 keeps the 64-row streaming kernels (A/B measurements)
+static bool head_enabled() {
+    static const int on = [] { const char* e = getenv("ECAMP_ATTN_HEAD"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+template <int HD>
+static bool head_fwd(const AttnArgs& a, hipStream_t st) {
+    if (!head_enabled() || a.Tk > 256) return false;
+    const int nkt = (a.Tk + 15) / 16, prow = ((nkt + 1) / 2) * 32;
+    const size_t shm = (size_t)2 * prow * HeadCfg<HD>::RB + (size_t)prow * sizeof(float);
+    const dim3 grid(a.B * a.H);
+    const bool small = a.Tq <= 64;   // at most four 16-row query tiles: four waves
+    if (nkt <= 4) {
+        if (small) LAUNCH_H((attn_head_fwd_kernel<HD, 4, 4>), grid, 256, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 4, 8>), grid, 512, shm, st, a);
+    } else if (nkt <= 8) {
+        if (small) LAUNCH_H((attn_head_fwd_kernel<HD, 8, 4>), grid, 256, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 8, 8>), grid, 512, shm, st, a);
+    } else {
+        if (small) LAUNCH_H((attn_head_fwd_kernel<HD, 16, 4>), grid, 256, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 16, 8>), grid, 512, shm, st, a);
+    }
+    return true;
+}
+template <int HD>
+static bool head_bwd(const AttnArgs& a, hipStream_t st) {
+    if (!head_enabled() || a.Tk > 256 || a.Tq > 256) return false;
+    const int nkp = ((a.Tk + 15) / 16 + 1) / 2, nqp = ((a.Tq + 15) / 16 + 1) / 2, prow = (nkp > nqp ? nkp : nqp) * 32;
+    const size_t shm = (size_t)2 * prow * HeadCfg<HD>::RB + (size_t)3 * prow * sizeof(float);
+    const dim3 grid(a.B * a.H);
+    if (a.Tq <= 64 && a.Tk <= 64) LAUNCH_H((attn_head_bwd_kernel<HD, 4>), grid, 256, shm, st, a);
+    else LAUNCH_H((attn_head_bwd_kernel<HD, 8>), grid, 512, shm, st, a);
+    return true;
+}
 template <int HD>
 static void fwd16(const AttnArgs& a, hipStream_t st) {
+    if (head_fwd<HD>(a, st)) return;
     // Tk > 128: the all-scores-in-registers kernels need 64 score registers per lane and spill (272 B/lane of scratch at 4 chunks);
     // the online-softmax kernel keeps one chunk of scores live and is faster from 129 keys up (decoder T=197, S=256, ViT-L T=785)
     if (a.Tk > 128) {
@@ -705,6 +1052,7 @@ static void bwd16(const AttnArgs& a, hipStream_t st) {
     // The backward kernels run as 64-row workgroups streaming 64-key (dQ) / 64-query (dK, dV) chunks.  "Resident" variants that
     // stage all of K/V (or Q/dO) once per (batch, head), like the forward above, were built and measured slower on MI355X: a quarter
     // of the workgroups and 2-3x the LDS footprint cost more occupancy than the saved barriers return (rejected).
+    if (head_bwd<HD>(a, st)) return;
     dim3 block(256);
     dim3 grid(ceil_div(a.Tq, 64), a.B * a.H);
     size_t shm = 2 * TileCfg<HD>::BYTES + 4 * 2048 + 64 * sizeof(int);
