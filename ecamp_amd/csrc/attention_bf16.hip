@@ -671,20 +671,12 @@ __global__ __launch_bounds__(256) void attn16r_fwd_kernel(AttnArgs a) {
 //     (t, t+1) of the SAME lane are exactly one B operand of the next MFMA if its contraction index is taken in the order
 //     kappa = 8g + e  <->  key 16(t + e/4) + 4g + e%4: the A operand (V^T, K^T, dO^T, Q^T via ds_read_b64_tr_b16) simply reads
 //     its two 4-row groups from rows 16t + 4g and 16(t+1) + 4g.  P / dS never leave the registers.
-//   * Scores are kept raw: max over raw scores (scale > 0), p = exp2(fma(s, scale*log2e, -max*scale*log2e)); masked / padded
-//     keys get an additive -1e30 only in tiles that contain one; normalisation is applied to O once.  ~4.5 VALU / element.
-//   * Tile loops run over the tiles that exist (13 x 13 for T = 197, not 16 x 16).
+//   * One multiply puts a score in base-2 units (an fma where a tile pair holds masked / padded keys: additive -1e30), then
+//     max / subtract, v_exp_f32, sum, pack; the normalisation is applied to O once.
+//   * Tile loops run over the 32-key pairs that exist (7 x 13 for T = 197, not 8 x 16).
 //   * Backward is ONE kernel: phase 1 (K, V resident; a wave owns 16 queries) produces dQ and leaves lse / delta in LDS; phase 2
 //     (Q, dO staged over the same LDS; a wave owns 16 keys) produces dK and dV.  The operands a wave owns come straight from
 //     global memory as MFMA fragments (the second read of each tensor is an L2 hit: the same workgroup has just staged it).
-// compile-time loop: the score array must stay in registers (a `#pragma unroll` loop of 16 guarded bodies is left rolled by hipcc
-// and the array lands in scratch)
-template <int I, int N, typename F> __device__ __forceinline__ void head_static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>());
-        head_static_for<I + 1, N>(f);
-    }
-}
 template <int HD> struct HeadCfg {
     static constexpr int RB = HD * 2, CPR = HD / 8, RPW = 256 / RB;   // row bytes, 16-B chunks per row, rows per 256-B bank window
 };
@@ -711,42 +703,53 @@ __device__ __forceinline__ void head_stage(unsigned char* img, const bf16_t* bas
         }
     }
 }
-template <int HD> __device__ __forceinline__ bf16x8 hfrag(const unsigned char* img, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8*>(img + haddr<HD>(row, chunk));
-}
-// transposed A operand for a contraction over 32 image ROWS taken as two groups of 16 (ra, rb): lane (i, g) ends up with
-// column o0 + i of rows ra + 4g .. +3 and rb + 4g .. +3
-template <int HD>
-__device__ __forceinline__ bf16x8 hfrag_tr(const unsigned char* img, int o0, int ra, int rb, int lane) {
-    const int i = lane & 15, g = lane >> 4;
-    const int cb = (o0 + (i & 3) * 4) * 2, ch = cb >> 4, in = cb & 15;
-    const int r0 = ra + 4 * g + (i >> 2), r1 = rb + 4 * g + (i >> 2);
-    v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(img + haddr<HD>(r0, ch) + in));
-    v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(img + haddr<HD>(r1, ch) + in));
-    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
 __device__ __forceinline__ bf16x8 hpack8(const float (&v)[8]) {
     const uint4 u = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
     return __builtin_bit_cast(bf16x8, u);
 }
-// additive key bias (0 attend / -1e30 masked or padded) of `prow` keys, and the bit mask of 16-key tiles that hold a biased key
+// additive key bias (0 attend / -1e30 masked or padded) of `prow` keys
 __device__ __forceinline__ void head_key_bias(float* KB, const AttnArgs& a, int b, int prow, int tid, int nthr) {
     for (int j = tid; j < prow; j += nthr)
         KB[j] = (j < a.Tk && (a.key_mask == nullptr || a.key_mask[(long)b * a.Tk + j] != 0)) ? 0.f : NEG_BIG;
 }
-__device__ __forceinline__ unsigned head_tile_mask(const float* KB, int nkt, int li) {
-    unsigned tm = 0;
-    for (int t = 0; t < nkt; ++t)
-        if (__ballot(KB[t * 16 + li] != 0.f) != 0ull) tm |= 1u << t;
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)tm);
+// Per-lane LDS byte offsets of the two fragment kinds for rows 0..15 of an image; a 16-row tile t adds t * 16 * RB (the swizzle has
+// a period of 16 rows), so the tile loops only add constants.
+template <int HD> struct HeadOff {
+    unsigned fr[HD / 32];   // ds_read_b128 of row li, 16-B chunk 4 ks + g
+    unsigned tr[HD / 16];   // ds_read_b64_tr_b16 of rows 4g + (li >> 2), columns 16 dt + 4 (li & 3)
+    __device__ __forceinline__ HeadOff(int li, int g) {
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) fr[ks] = haddr<HD>(li, ks * 4 + g);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+            const int cb = (dt * 16 + (li & 3) * 4) * 2;
+            tr[dt] = haddr<HD>(4 * g + (li >> 2), cb >> 4) + (cb & 15);
+        }
+    }
+};
+template <int HD> __device__ __forceinline__ bf16x8 hfr(const unsigned char* img, const HeadOff<HD>& o, int t, int ks) {
+    return *reinterpret_cast<const bf16x8*>(img + o.fr[ks] + t * (16 * HeadCfg<HD>::RB));
+}
+// transposed A operand over the 32 image rows of tile pair pp (see the k-order note above)
+template <int HD> __device__ __forceinline__ bf16x8 htr(const unsigned char* img, const HeadOff<HD>& o, int pp, int dt) {
+    const unsigned char* p = img + o.tr[dt] + pp * (32 * HeadCfg<HD>::RB);
+    v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p));
+    v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p + 16 * HeadCfg<HD>::RB));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// NT: score tiles (of 16 keys) a lane can hold, Tk <= 16 NT.  NW: waves.
-template <int HD, int NT, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_head_fwd_kernel(AttnArgs a) {
+// Forward, two passes over the resident keys: (1) row maximum, (2) scores again -> p -> O.  Recomputing a score tile costs HD/32
+// MFMAs and LDS reads; keeping all of them costs 4 * Tk/16 registers per lane and with them the occupancy, which is worth more
+// here (measured on T = 197: 89 VGPRs / 2 workgroups per CU 71 us, 154 VGPRs / 1 workgroup 98 us).
+// Tiles are walked in pairs (32 keys); key tiles below `nfull` hold only attended keys and skip the bias.
+// FLAGS 0: no key mask, no dropout (the image side).  FLAGS 1: key bias on every tile + dropout if drop_p > 0 (the report side).
+template <int HD, int FLAGS, bool PF>
+__global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RB = HeadCfg<HD>::RB, NTHR = NW * 64;
-    const int nkt = (a.Tk + 15) >> 4, prow = ((nkt + 1) >> 1) * 32;
+    constexpr int RB = HeadCfg<HD>::RB;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int nkp = (((a.Tk + 15) >> 4) + 1) >> 1, prow = nkp * 32;
+    const int pfull = FLAGS ? 0 : a.Tk >> 5;          // pairs of key tiles with no padded key
     unsigned char* KI = smem;
     unsigned char* VI = smem + prow * RB;
     float* KB = reinterpret_cast<float*>(smem + 2 * prow * RB);
@@ -757,68 +760,80 @@ __global__ __launch_bounds__(NW * 64) void attn_head_fwd_kernel(AttnArgs a) {
     const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
     const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
     bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_sb + h * a.o_sh;
-    head_stage<HD>(KI, kb, a.k_st, a.Tk, prow, tid, NTHR);
-    head_stage<HD>(VI, vb, a.v_st, a.Tk, prow, tid, NTHR);
-    head_key_bias(KB, a, b, prow, tid, NTHR);
+    // the fragments a wave owns come from global memory: the first block's are requested before the staging loads, the next
+    // block's while the current one is worked on (PF: the host sets it when a wave owns more than one block and hd <= 64 -- at
+    // hd = 128 the second set of registers costs the occupancy it would buy)
+    bf16x8 qf[HD / 32], qn[HD / 32];
+    if (wave * 16 < a.Tq) load_row_frags<HD>(qf, qb, a.q_st, wave * 16, a.Tq, lane);
+    head_stage<HD>(KI, kb, a.k_st, a.Tk, prow, tid, nthr);
+    head_stage<HD>(VI, vb, a.v_st, a.Tk, prow, tid, nthr);
+    head_key_bias(KB, a, b, prow, tid, nthr);
     __syncthreads();
-    const unsigned tmask = head_tile_mask(KB, nkt, li);
+    const HeadOff<HD> off(li, g);
     const float sc2 = a.scale * ATTN_LOG2E;
     const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    for (int q0 = wave * 16; q0 < a.Tq; q0 += NW * 16) {
-        bf16x8 qf[HD / 32];
-        load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
-        f32x4 s[NT];
-        float mx = NEG_BIG;
-        head_static_for<0, NT>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            if (t < nkt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int q0 = wave * 16; q0 < a.Tq; q0 += nw * 16) {
+        const bool more = q0 + nw * 16 < a.Tq;
+        if (PF && more) load_row_frags<HD>(qn, qb, a.q_st, q0 + nw * 16, a.Tq, lane);
+        // scores of key tile t in base-2 units (the product, not the raw MFMA result, is what fmaxf sees: no canonicalising v_max x, x)
+        auto scores = [&](int t, bool biased) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) acc = MFMA(hfrag<HD>(KI, t * 16 + li, ks * 4 + g), qf[ks], acc);
-                if ((tmask >> t) & 1u) {
-                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
+            for (int ks = 0; ks < HD / 32; ++ks) acc = MFMA(hfr<HD>(KI, off, t, ks), qf[ks], acc);
+            if (biased) {
+                const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] += kb4[r];
-                }
-                mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
-                s[t] = acc;
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(acc[r], sc2, kb4[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] *= sc2;
             }
-        });
+            return acc;
+        };
+        float mx = NEG_BIG;
+#pragma unroll 2
+        for (int pp = 0; pp < pfull; ++pp) {
+            const f32x4 s0 = scores(2 * pp, false), s1 = scores(2 * pp + 1, false);
+            mx = fmaxf(fmaxf(fmaxf(mx, fmaxf(s0[0], s0[1])), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        }
+#pragma unroll 1
+        for (int pp = pfull; pp < nkp; ++pp) {
+            const f32x4 s0 = scores(2 * pp, true), s1 = scores(2 * pp + 1, true);
+            mx = fmaxf(fmaxf(fmaxf(mx, fmaxf(s0[0], s0[1])), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        }
         mx = red4_max(mx);
-        const float mxs = fmaxf(mx * sc2, -1e29f);   // a row with no valid key keeps every p at 0
+        const float mxs = fmaxf(mx, -1e29f);   // a row with no valid key keeps every p at 0
         const int qi = q0 + li;
         float sum = 0.f;
         f32x4 o[HD / 16];  // o[dt][r] = O[i = q0+li][d = dt*16 + 4g + r]
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        head_static_for<0, NT / 2>([&](auto pc) {
-            constexpr int pp = decltype(pc)::value;
-            if (2 * pp < nkt) {
-                float p[8];
-                head_static_for<0, 2>([&](auto hc) {
-                    constexpr int hf = decltype(hc)::value, t = 2 * pp + hf;
-                    if (t < nkt) {
+        auto pair = [&](int pp, bool biased) {
+            const f32x4 s0 = scores(2 * pp, biased), s1 = scores(2 * pp + 1, biased);
+            float p[8];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            p[4 * hf + r] = attn_exp2(fmaf(s[t][r], sc2, -mxs));
-                            sum += p[4 * hf + r];
-                        }
-                        if (a.drop_p > 0.f) {
-                            float dm[4];
-                            attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) p[4 * hf + r] *= dm[r];
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) p[4 * hf + r] = 0.f;
-                    }
-                });
-                const bf16x8 pf = hpack8(p);
-#pragma unroll
-                for (int dt = 0; dt < HD / 16; ++dt) o[dt] = MFMA(hfrag_tr<HD>(VI, dt * 16, pp * 32, pp * 32 + 16, lane), pf, o[dt]);
+            for (int r = 0; r < 4; ++r) {
+                p[r] = attn_exp2(s0[r] - mxs);
+                p[4 + r] = attn_exp2(s1[r] - mxs);
+                sum += p[r] + p[4 + r];
             }
-        });
+            if (FLAGS && a.drop_p > 0.f) {
+                float dm[4];
+                attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 4 * g, inv_keep, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] *= dm[r];
+                attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 16 + 4 * g, inv_keep, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[4 + r] *= dm[r];
+            }
+            const bf16x8 pf = hpack8(p);
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) o[dt] = MFMA(htr<HD>(VI, off, pp, dt), pf, o[dt]);
+        };
+#pragma unroll 2
+        for (int pp = 0; pp < pfull; ++pp) pair(pp, false);
+#pragma unroll 1
+        for (int pp = pfull; pp < nkp; ++pp) pair(pp, true);
         sum = red4_sum(sum);
         if (qi < a.Tq) {
             if (g == 0) a.lse[bh * a.Tq + qi] = (mxs + __log2f(sum)) * ATTN_LN2;
@@ -826,19 +841,28 @@ __global__ __launch_bounds__(NW * 64) void attn_head_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int dt = 0; dt < HD / 16; ++dt) store4(ob + (long)qi * a.o_st + dt * 16 + 4 * g, o[dt], inv);
         }
+        if (more) {
+            if (PF) {
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = qn[ks];
+            } else {
+                load_row_frags<HD>(qf, qb, a.q_st, q0 + nw * 16, a.Tq, lane);
+            }
+        }
     }
 }
 
-template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_head_bwd_kernel(AttnArgs a) {
+template <int HD, int FLAGS, bool PF>
+__global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RB = HeadCfg<HD>::RB, NTHR = NW * 64;
-    const int nkt = (a.Tk + 15) >> 4, nkp = (nkt + 1) >> 1, nqt = (a.Tq + 15) >> 4, nqp = (nqt + 1) >> 1;
-    const int prow = max(nkp, nqp) * 32;
+    constexpr int RB = HeadCfg<HD>::RB;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int nkp = (((a.Tk + 15) >> 4) + 1) >> 1, nqp = (((a.Tq + 15) >> 4) + 1) >> 1, prow = max(nkp, nqp) * 32;
+    const int pfull = FLAGS ? 0 : a.Tk >> 5;          // pairs of key tiles with no padded key
     unsigned char* XI = smem;                 // phase 1: K     phase 2: Q
     unsigned char* YI = smem + prow * RB;     // phase 1: V     phase 2: dO
     float* KB = reinterpret_cast<float*>(smem + 2 * prow * RB);   // key bias, prow entries
-    float* LS = KB + prow;                                        // lse in base-2 units (+1e30 past Tq: p = 0), prow entries
+    float* LS = KB + prow;                                        // lse in base-2 units (+1e30 past Tq: p = 0)
     float* DL = LS + prow;                                        // delta = rowsum(dO * O)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -853,30 +877,38 @@ __global__ __launch_bounds__(NW * 64) void attn_head_bwd_kernel(AttnArgs a) {
     bf16_t* dvb = reinterpret_cast<bf16_t*>(a.dv) + b * a.dv_sb + h * a.dv_sh;
     const float sc2 = a.scale * ATTN_LOG2E;
     const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const HeadOff<HD> off(li, g);
 
     // ---- phase 1: dQ (+ lse, delta -> LDS) -------------------------------------------------------------------------------------
-    head_stage<HD>(XI, kb, a.k_st, a.Tk, prow, tid, NTHR);
-    head_stage<HD>(YI, vb, a.v_st, a.Tk, prow, tid, NTHR);
-    head_key_bias(KB, a, b, prow, tid, NTHR);
-    for (int i = nqt * 16 + tid; i < prow; i += NTHR) { LS[i] = 1e30f; DL[i] = 0.f; }
+    // the fragments a wave owns come from global memory: the first block's are requested before the staging loads, the next
+    // block's while the current one is worked on (PF: the host sets it when a wave owns more than one block and hd <= 64 -- at
+    // hd = 128 the second set of registers costs the occupancy it would buy)
+    bf16x8 qf[HD / 32], gf[HD / 32], of[HD / 32], qn[HD / 32], gn[HD / 32], on[HD / 32];
+    float lse_c = 0.f, lse_n = 0.f;
+    auto load_q = [&](int q0, bf16x8 (&q_)[HD / 32], bf16x8 (&g_)[HD / 32], bf16x8 (&o_)[HD / 32], float& l_) {
+        load_row_frags<HD>(q_, qb, a.q_st, q0, a.Tq, lane);
+        load_row_frags<HD>(g_, gb, a.do_st, q0, a.Tq, lane);
+        load_row_frags<HD>(o_, ob, a.o_st, q0, a.Tq, lane);
+        l_ = q0 + li < a.Tq ? a.lse[bh * a.Tq + q0 + li] : 0.f;
+    };
+    if (wave * 16 < a.Tq) load_q(wave * 16, qf, gf, of, lse_c);
+    head_stage<HD>(XI, kb, a.k_st, a.Tk, prow, tid, nthr);
+    head_stage<HD>(YI, vb, a.v_st, a.Tk, prow, tid, nthr);
+    head_key_bias(KB, a, b, prow, tid, nthr);
+    for (int i = ((a.Tq + 15) & ~15) + tid; i < prow; i += nthr) { LS[i] = 1e30f; DL[i] = 0.f; }
     __syncthreads();
-    for (int q0 = wave * 16; q0 < a.Tq; q0 += NW * 16) {
-        bf16x8 qf[HD / 32], gf[HD / 32];
+    for (int q0 = wave * 16; q0 < a.Tq; q0 += nw * 16) {
+        const bool more = q0 + nw * 16 < a.Tq;
+        if (PF && more) load_q(q0 + nw * 16, qn, gn, on, lse_n);
         float dl = 0.f;
-        {
-            bf16x8 of[HD / 32];
-            load_row_frags<HD>(qf, qb, a.q_st, q0, a.Tq, lane);
-            load_row_frags<HD>(gf, gb, a.do_st, q0, a.Tq, lane);
-            load_row_frags<HD>(of, ob, a.o_st, q0, a.Tq, lane);
 #pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks)
+        for (int ks = 0; ks < HD / 32; ++ks)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)gf[ks][e]) * bf2f((bf16_t)of[ks][e]);
-        }
+            for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)gf[ks][e]) * bf2f((bf16_t)of[ks][e]);
         dl = red4_sum(dl);
         const int qi = q0 + li;
         const bool qok = qi < a.Tq;
-        const float lse2 = qok ? a.lse[bh * a.Tq + qi] * ATTN_LOG2E : 1e30f;
+        const float lse2 = qok ? lse_c * ATTN_LOG2E : 1e30f;
         if (g == 0) {
             LS[qi] = lse2;
             DL[qi] = qok ? dl : 0.f;
@@ -885,45 +917,69 @@ __global__ __launch_bounds__(NW * 64) void attn_head_bwd_kernel(AttnArgs a) {
         f32x4 dq[HD / 16];  // dq[dt][r] = dQ[i = q0+li][d = dt*16 + 4g + r]
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int pp = 0; pp < nkp; ++pp) {
+        auto pair = [&](int pp, bool biased) {
             float ds[8];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int t = 2 * pp + hf;
+                const int t = 2 * pp + hf;   // (an odd tile count: the last tile is all padding -- zero rows, biased keys)
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < HD / 32; ++ks) {
-                    s = MFMA(hfrag<HD>(XI, t * 16 + li, ks * 4 + g), qf[ks], s);
-                    dp = MFMA(hfrag<HD>(YI, t * 16 + li, ks * 4 + g), gf[ks], dp);
+                    s = MFMA(hfr<HD>(XI, off, t, ks), qf[ks], s);
+                    dp = MFMA(hfr<HD>(YI, off, t, ks), gf[ks], dp);
                 }
-                const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
-                float dm[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.drop_p > 0.f) attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+                float e[4];
+                if (biased) {
+                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = attn_exp2(fmaf(s[r] + kb4[r], sc2, -lse2));
-                    ds[4 * hf + r] = p * (dp[r] * dm[r] - dl);
+                    for (int r = 0; r < 4; ++r) e[r] = fmaf(s[r], sc2, kb4[r]) - lse2;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[r] = fmaf(s[r], sc2, -lse2);
                 }
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (FLAGS && a.drop_p > 0.f) attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[4 * hf + r] = attn_exp2(e[r]) * ((FLAGS ? dp[r] * dm[r] : dp[r]) - dl);
             }
             const bf16x8 sf = hpack8(ds);
 #pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = MFMA(hfrag_tr<HD>(XI, dt * 16, pp * 32, pp * 32 + 16, lane), sf, dq[dt]);
-        }
+            for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = MFMA(htr<HD>(XI, off, pp, dt), sf, dq[dt]);
+        };
+#pragma unroll 1
+        for (int pp = 0; pp < pfull; ++pp) pair(pp, false);
+#pragma unroll 1
+        for (int pp = pfull; pp < nkp; ++pp) pair(pp, true);
         if (qok) {
 #pragma unroll
             for (int dt = 0; dt < HD / 16; ++dt) store4(dqb + (long)qi * a.dq_st + dt * 16 + 4 * g, dq[dt], a.scale);
         }
+        if (more) {
+            if (PF) {
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) { qf[ks] = qn[ks]; gf[ks] = gn[ks]; of[ks] = on[ks]; }
+                lse_c = lse_n;
+            } else {
+                load_q(q0 + nw * 16, qf, gf, of, lse_c);
+            }
+        }
+    }
+    // ---- phase 2: dK, dV ---------------------------------------------------------------------------------------------------------
+    bf16x8 kf[HD / 32], vf[HD / 32], kn[HD / 32], vn[HD / 32];
+    if (wave * 16 < a.Tk) {
+        load_row_frags<HD>(kf, kb, a.k_st, wave * 16, a.Tk, lane);
+        load_row_frags<HD>(vf, vb, a.v_st, wave * 16, a.Tk, lane);
     }
     __syncthreads();
-    // ---- phase 2: dK, dV ---------------------------------------------------------------------------------------------------------
-    head_stage<HD>(XI, qb, a.q_st, a.Tq, prow, tid, NTHR);
-    head_stage<HD>(YI, gb, a.do_st, a.Tq, prow, tid, NTHR);
+    head_stage<HD>(XI, qb, a.q_st, a.Tq, prow, tid, nthr);
+    head_stage<HD>(YI, gb, a.do_st, a.Tq, prow, tid, nthr);
     __syncthreads();
-    for (int j0 = wave * 16; j0 < a.Tk; j0 += NW * 16) {
-        bf16x8 kf[HD / 32], vf[HD / 32];
-        load_row_frags<HD>(kf, kb, a.k_st, j0, a.Tk, lane);
-        load_row_frags<HD>(vf, vb, a.v_st, j0, a.Tk, lane);
+    for (int j0 = wave * 16; j0 < a.Tk; j0 += nw * 16) {
+        const bool more = j0 + nw * 16 < a.Tk;
+        if (PF && more) {
+            load_row_frags<HD>(kn, kb, a.k_st, j0 + nw * 16, a.Tk, lane);
+            load_row_frags<HD>(vn, vb, a.v_st, j0 + nw * 16, a.Tk, lane);
+        }
         const int kj = j0 + li;
         const bool jok = KB[kj] == 0.f;
         f32x4 dk[HD / 16], dv[HD / 16];   // [dt][r] = dK / dV[j = j0+li][d = dt*16 + 4g + r]
@@ -934,29 +990,29 @@ __global__ __launch_bounds__(NW * 64) void attn_head_bwd_kernel(AttnArgs a) {
             float pd[8], ds[8];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int it = 2 * ip + hf;
+                const int it = 2 * ip + hf;   // (an odd tile count: the last tile is all padding -- zero rows, lse = +1e30)
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < HD / 32; ++ks) {
-                    s = MFMA(hfrag<HD>(XI, it * 16 + li, ks * 4 + g), kf[ks], s);
-                    dp = MFMA(hfrag<HD>(YI, it * 16 + li, ks * 4 + g), vf[ks], dp);
+                    s = MFMA(hfr<HD>(XI, off, it, ks), kf[ks], s);
+                    dp = MFMA(hfr<HD>(YI, off, it, ks), vf[ks], dp);
                 }
                 const f32x4 lse4 = *reinterpret_cast<const f32x4*>(LS + it * 16 + 4 * g);
                 const f32x4 dl4 = *reinterpret_cast<const f32x4*>(DL + it * 16 + 4 * g);
                 float dm[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.drop_p > 0.f) attn_drop4_col(a, (uint64_t)bh * a.Tq + (it * 16 + 4 * g), kj, li, inv_keep, dm);
+                if (FLAGS && a.drop_p > 0.f) attn_drop4_col(a, (uint64_t)bh * a.Tq + (it * 16 + 4 * g), kj, li, inv_keep, dm);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = attn_exp2(fmaf(s[r], sc2, -lse4[r]));
-                    pd[4 * hf + r] = p * dm[r];
-                    ds[4 * hf + r] = p * (dp[r] * dm[r] - dl4[r]);
+                    pd[4 * hf + r] = FLAGS ? p * dm[r] : p;
+                    ds[4 * hf + r] = p * ((FLAGS ? dp[r] * dm[r] : dp[r]) - dl4[r]);
                 }
             }
             const bf16x8 pf = hpack8(pd), sf = hpack8(ds);
 #pragma unroll
             for (int dt = 0; dt < HD / 16; ++dt) {
-                dv[dt] = MFMA(hfrag_tr<HD>(YI, dt * 16, ip * 32, ip * 32 + 16, lane), pf, dv[dt]);
-                dk[dt] = MFMA(hfrag_tr<HD>(XI, dt * 16, ip * 32, ip * 32 + 16, lane), sf, dk[dt]);
+                dv[dt] = MFMA(htr<HD>(YI, off, ip, dt), pf, dv[dt]);
+                dk[dt] = MFMA(htr<HD>(XI, off, ip, dt), sf, dk[dt]);
             }
         }
         if (kj < a.Tk) {
@@ -965,6 +1021,15 @@ __global__ __launch_bounds__(NW * 64) void attn_head_bwd_kernel(AttnArgs a) {
             for (int dt = 0; dt < HD / 16; ++dt) {
                 store4(dkb + (long)kj * a.dk_st + dt * 16 + 4 * g, dk[dt], mk);
                 store4(dvb + (long)kj * a.dv_st + dt * 16 + 4 * g, dv[dt], mv);
+            }
+        }
+        if (more) {
+            if (PF) {
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+            } else {
+                load_row_frags<HD>(kf, kb, a.k_st, j0 + nw * 16, a.Tk, lane);
+                load_row_frags<HD>(vf, vb, a.v_st, j0 + nw * 16, a.Tk, lane);
             }
         }
     }
@@ -980,7 +1045,6 @@ static void lds_optin(K kern, size_t bytes) {
         if (!once_) { lds_optin(KERN, SHM); once_ = true; }  \
         hipLaunchKernelGGL(KERN, GRID, dim3(256), SHM, ST, ARGS); \
     } while (0)
-#define LDS_MAX (160 * 1024)
 
 // =============================================================================================
 #define LAUNCH_H(KERN, GRID, BLOCK, SHM, ST, ARGS)           \
@@ -989,35 +1053,42 @@ static void lds_optin(K kern, size_t bytes) {
         if (!once_) { lds_optin(KERN, SHM); once_ = true; }  \
         hipLaunchKernelGGL(KERN, GRID, dim3(BLOCK), SHM, ST, ARGS); \
     } while (0)
+#define LDS_MAX (160 * 1024)
 // ECAMP_ATTN_HEAD=0 keeps the 64-row streaming kernels (A/B measurements)
 static bool head_enabled() {
     static const int on = [] { const char* e = getenv("ECAMP_ATTN_HEAD"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
+// workgroup size: one wave per 16-row tile up to `cap` waves (ECAMP_ATTN_WAVES overrides the cap: tuning)
+static int head_waves(int tiles, int cap) {
+    static const int env = [] { const char* e = getenv("ECAMP_ATTN_WAVES"); return e ? atoi(e) : 0; }();
+    if (env > 0) cap = env;
+    return tiles < cap ? tiles : cap;
+}
 template <int HD>
 static bool head_fwd(const AttnArgs& a, hipStream_t st) {
-    if (!head_enabled() || a.Tk > 256) return false;
-    const int nkt = (a.Tk + 15) / 16, prow = ((nkt + 1) / 2) * 32;
+    const int nkp = ((a.Tk + 15) / 16 + 1) / 2, prow = nkp * 32;
     const size_t shm = (size_t)2 * prow * HeadCfg<HD>::RB + (size_t)prow * sizeof(float);
+    if (!head_enabled() || shm > LDS_MAX) return false;
     const dim3 grid(a.B * a.H);
-    const bool small = a.Tq <= 64;   // at most four 16-row query tiles: four waves
-    if (nkt <= 4) {
-        if (small) LAUNCH_H((attn_head_fwd_kernel<HD, 4, 4>), grid, 256, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 4, 8>), grid, 512, shm, st, a);
-    } else if (nkt <= 8) {
-        if (small) LAUNCH_H((attn_head_fwd_kernel<HD, 8, 4>), grid, 256, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 8, 8>), grid, 512, shm, st, a);
-    } else {
-        if (small) LAUNCH_H((attn_head_fwd_kernel<HD, 16, 4>), grid, 256, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 16, 8>), grid, 512, shm, st, a);
-    }
+    const int nqt = (a.Tq + 15) / 16, nw = head_waves(nqt, 8);
+    const bool flags = a.key_mask != nullptr || a.drop_p > 0.f, pf = HD <= 64 && nqt > nw;
+    if (flags) { if (pf) LAUNCH_H((attn_head_fwd_kernel<HD, 1, true>), grid, nw * 64, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 1, false>), grid, nw * 64, shm, st, a); }
+    else       { if (pf) LAUNCH_H((attn_head_fwd_kernel<HD, 0, true>), grid, nw * 64, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 0, false>), grid, nw * 64, shm, st, a); }
     return true;
 }
 template <int HD>
 static bool head_bwd(const AttnArgs& a, hipStream_t st) {
-    if (!head_enabled() || a.Tk > 256 || a.Tq > 256) return false;
-    const int nkp = ((a.Tk + 15) / 16 + 1) / 2, nqp = ((a.Tq + 15) / 16 + 1) / 2, prow = (nkp > nqp ? nkp : nqp) * 32;
+    const int nkt = (a.Tk + 15) / 16, nqt = (a.Tq + 15) / 16, nkp = (nkt + 1) / 2, nqp = (nqt + 1) / 2, prow = (nkp > nqp ? nkp : nqp) * 32;
     const size_t shm = (size_t)2 * prow * HeadCfg<HD>::RB + (size_t)3 * prow * sizeof(float);
+    if (!head_enabled() || shm > LDS_MAX) return false;
     const dim3 grid(a.B * a.H);
-    if (a.Tq <= 64 && a.Tk <= 64) LAUNCH_H((attn_head_bwd_kernel<HD, 4>), grid, 256, shm, st, a);
-    else LAUNCH_H((attn_head_bwd_kernel<HD, 8>), grid, 512, shm, st, a);
+    // four waves: two (hd = 128: the register file) to five workgroups share a CU and one's staging overlaps another's tile loops
+    // (T = 197, hd = 32: 230 us against 260 us with eight; T = 128, hd = 128: 147 against 161)
+    const int nt = nkt > nqt ? nkt : nqt, nw = head_waves(nt, 4);
+    const bool flags = a.key_mask != nullptr || a.drop_p > 0.f, pf = HD <= 64 && nt > nw;
+    if (flags) { if (pf) LAUNCH_H((attn_head_bwd_kernel<HD, 1, true>), grid, nw * 64, shm, st, a); else LAUNCH_H((attn_head_bwd_kernel<HD, 1, false>), grid, nw * 64, shm, st, a); }
+    else       { if (pf) LAUNCH_H((attn_head_bwd_kernel<HD, 0, true>), grid, nw * 64, shm, st, a); else LAUNCH_H((attn_head_bwd_kernel<HD, 0, false>), grid, nw * 64, shm, st, a); }
     return true;
 }
 template <int HD>
