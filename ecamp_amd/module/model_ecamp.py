@@ -325,11 +325,28 @@ class ECAMP(nn.Module):
         for blk in self.blocks:
             x = VitBlockFn.apply(x, blk, self, B, T, self.num_heads)
         latent = NormFn.apply(x, self.norm, self)
-        xd = DecStemFn.apply(latent, ids_restore, ids_keep, self, B)
-        for blk in self.decoder_blocks:
-            xd = VitBlockFn.apply(xd, blk, self, B, self.num_patches + 1, self.decoder_num_heads)
-        img_losses = ImgLossFn.apply(xd, imgs, big, mask, column, row, self, B)
-        mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
+        def image_decoder():
+            xd = DecStemFn.apply(latent, ids_restore, ids_keep, self, B)
+            for blk in self.decoder_blocks:
+                xd = VitBlockFn.apply(xd, blk, self, B, self.num_patches + 1, self.decoder_num_heads)
+            return ImgLossFn.apply(xd, imgs, big, mask, column, row, self, B)
+
+        from .. import hip_ops as ops
+        if ops.OVERLAP_BRANCHES and latent.is_cuda:
+            # the two consumers of `latent` on two streams (see hip_ops.branch_stream)
+            main, bs = torch.cuda.current_stream(dev), ops.branch_stream(dev)
+            bs.wait_stream(main)
+            with torch.cuda.stream(bs):
+                img_losses = image_decoder()
+            for t in (latent, imgs, big, mask, ids_restore, ids_keep, column, row):
+                t.record_stream(bs)
+            mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
+            main.wait_stream(bs)
+            for t in img_losses:
+                t.record_stream(main)
+        else:
+            img_losses = image_decoder()
+            mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
         if self.keep_aux:
             self._aux = dict(self._aux or {}, imgs=imgs, mask=mask, ids_restore=ids_restore, ids_keep=ids_keep,
                              latent=latent.view(B, T, -1), logits=self._aux_logits, **(getattr(self, "_aux_text", None) or {}))

@@ -63,8 +63,7 @@ class GradReducer:
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         if self.host_staged:
             from . import hip_ops
-            wst = hip_ops._side.get(self.flat_g.device)
-            if wst is not None:
+            for wst in hip_ops.side_streams(self.flat_g.device):
                 torch.cuda.current_stream().wait_stream(wst)
             host = buf.cpu()
             dist.all_reduce(host, op=op, group=self.group)
@@ -75,9 +74,8 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
-            from . import hip_ops  # weight gradients may still be running on the wgrad side stream
-            wst = hip_ops._side.get(self.flat_g.device)
-            if wst is not None:
+            from . import hip_ops  # gradients of this bucket may still be running on the wgrad side stream or the branch stream
+            for wst in hip_ops.side_streams(self.flat_g.device):
                 self.side.wait_stream(wst)
             with torch.cuda.stream(self.side):
                 w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
