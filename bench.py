@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--only-value", action="store_true", help="time the K steps of `value` and nothing else (kernel traces of the production step)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -200,6 +201,14 @@ def main():
         run_inclusive(args.warmup)   # untimed warm-up on the SAME path: the caching allocator settles on its staging blocks
     lib = _lib.load()
     dt = timed(run_inclusive, args.steps)          # THE metric: K steps, host batch -> HBM inside
+    if args.only_value:
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": round(args.batch * world * args.steps / dt, 2), "unit": "pairs/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                              "note": "--only-value: side measurements, roofline pass and CPU baseline skipped"}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     def run_resident(n):
         for _ in range(n):

@@ -38,8 +38,25 @@ def main():
             gem[g][1] += (e - s) / 1e3
     wall = (rows[-1][2] - rows[0][1]) / 1e3
     busy = sum(v[1] for v in tot.values())
+    # time with at least one kernel resident (union of the dispatch intervals) and the gaps between them
+    union, gaps, cur_e = 0.0, [], None
+    for r in rows:
+        s_, e_ = r[1], r[2]
+        if cur_e is None:
+            cur_s, cur_e = s_, e_
+        elif s_ <= cur_e:
+            cur_e = max(cur_e, e_)
+        else:
+            union += cur_e - cur_s
+            gaps.append(s_ - cur_e)
+            cur_s, cur_e = s_, e_
+    union += cur_e - cur_s
+    gaps.sort()
     print("# %s  (dispatches after the first %.0f%% of the trace)" % (db, 100 * skip))
     print("# wall %.1f ms, sum of kernel durations %.1f ms, %d dispatches" % (wall / 1e3, busy / 1e3, len(rows)))
+    if gaps:
+        print("# device busy (union of dispatch intervals) %.1f ms = %.1f%% of wall; %d idle gaps: total %.1f ms, median %.2f us, p90 %.2f us, max %.1f us"
+              % (union / 1e6, 100 * union / 1e3 / wall, len(gaps), sum(gaps) / 1e6, gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * 0.9)] / 1e3, gaps[-1] / 1e3))
     print("%-112s %7s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
     for k, (n, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
         print("%-112s %7d %12.1f %10.2f %6.2f" % (k, n, us, us / n, 100 * us / busy))
