@@ -708,6 +708,11 @@ __device__ __forceinline__ void head_stage(unsigned char* img, const bf16_t* bas
         }
     }
 }
+// packed f32 pairs: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 cost one VALU slot for two lanes' worth of work
+// (tools/probes/valu_rate_probe.hip: same issue rate as v_fma_f32; v_exp_f32 1.5x)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 hexp2(f32x2 x) { return (f32x2){attn_exp2(x[0]), attn_exp2(x[1])}; }
+__device__ __forceinline__ uint32_t hpk(f32x2 v) { return pack_bf16x2(v[0], v[1]); }
 __device__ __forceinline__ bf16x8 hpack8(const float (&v)[8]) {
     const uint4 u = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
     return __builtin_bit_cast(bf16x8, u);
@@ -923,7 +928,7 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         auto pair = [&](int pp, bool biased) {
-            float ds[8];
+            uint32_t dsp[4];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int t = 2 * pp + hf;   // (an odd tile count: the last tile is all padding -- zero rows, biased keys)
@@ -933,25 +938,31 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
                     s = MFMA(hfr<HD>(XI, off, t, ks), qf[ks], s);
                     dp = MFMA(hfr<HD>(YI, off, t, ks), gf[ks], dp);
                 }
-                float e[4];
+                // e = s * scale*log2e (+ key bias) - lse;  ds = 2^e * (dp (* dropout) - delta), two scores per VALU instruction
+                f32x2 e0 = {s[0], s[1]}, e1 = {s[2], s[3]}, d0 = {dp[0], dp[1]}, d1 = {dp[2], dp[3]};
+                const f32x2 sc = {sc2, sc2}, nl = {-lse2, -lse2}, dlv = {dl, dl};
                 if (biased) {
                     const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) e[r] = fmaf(s[r], sc2, kb4[r]) - lse2;
+                    e0 = e0 * sc + ((f32x2){kb4[0], kb4[1]} + nl);
+                    e1 = e1 * sc + ((f32x2){kb4[2], kb4[3]} + nl);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) e[r] = fmaf(s[r], sc2, -lse2);
+                    e0 = e0 * sc + nl;
+                    e1 = e1 * sc + nl;
                 }
-                float dm[4] = {1.f, 1.f, 1.f, 1.f};
-                if (FLAGS && a.drop_p > 0.f) attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ds[4 * hf + r] = attn_exp2(e[r]) * ((FLAGS ? dp[r] * dm[r] : dp[r]) - dl);
+                if (FLAGS && a.drop_p > 0.f) {
+                    float dm[4];
+                    attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+                    d0 *= (f32x2){dm[0], dm[1]};
+                    d1 *= (f32x2){dm[2], dm[3]};
+                }
+                dsp[2 * hf] = hpk(hexp2(e0) * (d0 - dlv));
+                dsp[2 * hf + 1] = hpk(hexp2(e1) * (d1 - dlv));
             }
-            const bf16x8 sf = hpack8(ds);
+            const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(dsp[0], dsp[1], dsp[2], dsp[3]));
 #pragma unroll
             for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = MFMA(htr<HD>(XI, off, pp, dt), sf, dq[dt]);
         };
-#pragma unroll 1
+#pragma unroll 2
         for (int pp = 0; pp < pfull; ++pp) pair(pp, false);
 #pragma unroll 1
         for (int pp = pfull; pp < nkp; ++pp) pair(pp, true);
@@ -990,9 +1001,9 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
         f32x4 dk[HD / 16], dv[HD / 16];   // [dt][r] = dK / dV[j = j0+li][d = dt*16 + 4g + r]
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll 2
         for (int ip = 0; ip < nqp; ++ip) {
-            float pd[8], ds[8];
+            uint32_t pdp[4], dsp[4];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int it = 2 * ip + hf;   // (an odd tile count: the last tile is all padding -- zero rows, lse = +1e30)
@@ -1004,16 +1015,26 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
                 }
                 const f32x4 lse4 = *reinterpret_cast<const f32x4*>(LS + it * 16 + 4 * g);
                 const f32x4 dl4 = *reinterpret_cast<const f32x4*>(DL + it * 16 + 4 * g);
-                float dm[4] = {1.f, 1.f, 1.f, 1.f};
-                if (FLAGS && a.drop_p > 0.f) attn_drop4_col(a, (uint64_t)bh * a.Tq + (it * 16 + 4 * g), kj, li, inv_keep, dm);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = attn_exp2(fmaf(s[r], sc2, -lse4[r]));
-                    pd[4 * hf + r] = FLAGS ? p * dm[r] : p;
-                    ds[4 * hf + r] = p * ((FLAGS ? dp[r] * dm[r] : dp[r]) - dl4[r]);
+                const f32x2 sc = {sc2, sc2};
+                f32x2 d0 = {dp[0], dp[1]}, d1 = {dp[2], dp[3]};
+                f32x2 p0 = hexp2((f32x2){s[0], s[1]} * sc - (f32x2){lse4[0], lse4[1]});
+                f32x2 p1 = hexp2((f32x2){s[2], s[3]} * sc - (f32x2){lse4[2], lse4[3]});
+                if (FLAGS && a.drop_p > 0.f) {
+                    float dm[4];
+                    attn_drop4_col(a, (uint64_t)bh * a.Tq + (it * 16 + 4 * g), kj, li, inv_keep, dm);
+                    const f32x2 m0 = {dm[0], dm[1]}, m1 = {dm[2], dm[3]};
+                    d0 *= m0; d1 *= m1;
+                    pdp[2 * hf] = hpk(p0 * m0);
+                    pdp[2 * hf + 1] = hpk(p1 * m1);
+                } else {
+                    pdp[2 * hf] = hpk(p0);
+                    pdp[2 * hf + 1] = hpk(p1);
                 }
+                dsp[2 * hf] = hpk(p0 * (d0 - (f32x2){dl4[0], dl4[1]}));
+                dsp[2 * hf + 1] = hpk(p1 * (d1 - (f32x2){dl4[2], dl4[3]}));
             }
-            const bf16x8 pf = hpack8(pd), sf = hpack8(ds);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pdp[0], pdp[1], pdp[2], pdp[3]));
+            const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(dsp[0], dsp[1], dsp[2], dsp[3]));
 #pragma unroll
             for (int dt = 0; dt < HD / 16; ++dt) {
                 dv[dt] = MFMA(htr<HD>(YI, off, ip, dt), pf, dv[dt]);
