@@ -17,4 +17,5 @@ struct AttnArgs {
 #define NEG_BIG (-1.0e30f)
 
 void attn_bf16_fwd(const AttnArgs& a, int hd, hipStream_t st);
+void attn_set_head_mode(int on);   // ecamp_set_option("attn_head", ...): -1 back to the environment's choice
 void attn_bf16_bwd(const AttnArgs& a, int hd, hipStream_t st);

@@ -1081,9 +1081,11 @@ static void lds_optin(K kern, size_t bytes) {
     } while (0)
 #define LDS_MAX (160 * 1024)
 // ECAMP_ATTN_HEAD=0 keeps the 64-row streaming kernels (A/B measurements)
+static int g_head_mode = -1;   // ecamp_set_option("attn_head", v): -1 = the environment decides
+void attn_set_head_mode(int on) { g_head_mode = on < 0 ? -1 : (on ? 1 : 0); }
 static bool head_enabled() {
-    static const int on = [] { const char* e = getenv("ECAMP_ATTN_HEAD"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    static const int env = [] { const char* e = getenv("ECAMP_ATTN_HEAD"); return e ? atoi(e) : 1; }();
+    return (g_head_mode >= 0 ? g_head_mode : env) != 0;
 }
 // workgroup size: one wave per 16-row tile up to `cap` waves (ECAMP_ATTN_WAVES overrides the cap: tuning)
 static int head_waves(int tiles, int cap) {

@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "gemm_args.h"
+void attn_set_head_mode(int on);   // attention_bf16.hip
 #include "gemm_q8.h"
 
 // =============================================================================================
@@ -987,6 +988,7 @@ extern "C" int ecamp_set_option(const char* name, int32_t value) {
     if (strcmp(name, "q8_mode") == 0) { g_q8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 whenever legal
     if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
+    if (strcmp(name, "attn_head") == 0) { attn_set_head_mode(value); return 0; }   // attention_bf16.hip: 1 head kernels (default), 0 streaming kernels
     return ecamp_set_error(-1, "set_option: unknown option '%s'", name);
 }
 

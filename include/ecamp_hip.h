@@ -62,6 +62,8 @@ int ecamp_set_option(const char* name, int32_t value);
 /* "q8_mode" (ecamp_set_option): -1 automatic (default), 0 never, 2 whenever its alignment / size conditions hold -- the round-2
  * persistent 256x256x64 kernel (csrc/gemm_q8.h) that serves the forward, data-gradient and weight-gradient forms.
  * Development aid: number of GEMM calls the library has routed to that kernel so far (tests assert that it really ran). */
+/* "attn_head" (ecamp_set_option): 1 (default; env ECAMP_ATTN_HEAD) one workgroup per (batch, head) with everything resident in LDS
+ * for sequences that fit (<= 256 tokens here), 0 the 64-row streaming kernels for every length, -1 back to the environment's choice */
 int64_t ecamp_gemm_q8_launches(void);
 
 /* ---- fp8 forward (BASELINE.json configs[4]: "fp8 MFMA forward (bf16 grads) for QKV/MLP GEMMs"; no reference counterpart -- the

@@ -249,6 +249,49 @@ def test_attention_dropout_statistics(dev):
     assert abs(dv.sum().item() / o1.sum().item() - 1.0) < 1e-3
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,hd,masked,p", [(2, 6, 128, 128, 128, True, 0.1), (2, 6, 128, 49, 128, False, 0.1), (3, 16, 197, 197, 32, False, 0.0),
+                                                   (2, 12, 50, 50, 64, False, 0.2), (1, 4, 250, 256, 64, True, 0.1), (2, 3, 33, 17, 32, True, 0.3)])
+def test_attention_head_kernels_match_streaming_kernels(dev, B, H, Tq, Tk, hd, masked, p):
+    """The head-resident kernels (one workgroup per (batch, head), P kept in registers, one fused backward kernel) and the 64-row
+    streaming kernels implement the same function with the same Philox dropout mask: same seed/offset -> same dropped entries, outputs
+    and gradients equal to bf16 rounding.  Covers key masks, cross attention with an odd key count (per-element mask path) and
+    sequences that do not fill the last 32-key pair."""
+    o = ops()
+    D = H * hd
+    dt = torch.bfloat16
+    q = rnd(gen(B, Tq, D, seed=11), dt).to(dev, dt)
+    k = rnd(gen(B, Tk, D, seed=12), dt).to(dev, dt)
+    v = rnd(gen(B, Tk, D, seed=13), dt).to(dev, dt)
+    do = rnd(gen(B, Tq, D, seed=14), dt).to(dev, dt)
+    km = None
+    if masked:
+        lens = torch.randint(max(1, Tk // 3), Tk + 1, (B,), generator=torch.Generator().manual_seed(5))
+        km = (torch.arange(Tk)[None, :] < lens[:, None]).int().to(dev)
+    qs, ks = (Tq * D, D, hd), (Tk * D, D, hd)
+    res = []
+    try:
+        for mode in (1, 0):
+            o.set_option("attn_head", mode)
+            out, lse = o.attn_fwd(q, k, v, B, H, Tq, Tk, hd, qs, ks, ks, hd ** -0.5, km, p, 77, 5)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            o.attn_bwd(q, k, v, out, do, lse, dq, dk, dv, B, H, Tq, Tk, hd, qs, ks, ks, qs, ks, ks, hd ** -0.5, km, p, 77, 5)
+            res.append((out.float().cpu(), lse.float().cpu(), dq.float().cpu(), dk.float().cpu(), dv.float().cpu()))
+    finally:
+        o.set_option("attn_head", -1)
+    for name, a, b in zip(("out", "lse", "dq", "dk", "dv"), res[0], res[1]):
+        assert torch.isfinite(a).all(), name
+        tol = 1e-5 if name == "lse" else 2e-2   # two bf16 roundings of P / dS taken in different summation orders
+        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
+        assert err <= tol, "%s: head vs streaming rel err %.3e" % (name, err)
+    if p > 0:   # dropout really happened and hit the same entries: dv = P_dropped^T dO differs from the undropped run
+        o.set_option("attn_head", 1)
+        try:
+            out0, _ = o.attn_fwd(q, k, v, B, H, Tq, Tk, hd, qs, ks, ks, hd ** -0.5, km, 0.0, 77, 5)
+        finally:
+            o.set_option("attn_head", -1)
+        assert (out0.float().cpu() - res[0][0]).abs().max().item() > 1e-3
+
+
 # ------------------------------------------------------------------------------------------------ image side
 def test_bicubic(dev):
     o = ops()
