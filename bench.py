@@ -9,7 +9,8 @@ head + reference BERT (6L/6H/1536, vocab 30000) with context fusion, B=256 pairs
 images resized on device), reports of S=128 tokens, bf16 activations / f32 master weights, train mode (dropout
 active), host->HBM copy of the batch + forward + backward + grad all-reduce (N>1) + grad-norm + fused AdamW + zero_grad
 (accum_iter=1).  The batch starts in pinned HOST memory (what a DataLoader with pin_memory hands over) and crosses PCIe inside
-the timed region, one step ahead on a copy stream (ecamp_amd.data.DevicePrefetcher): `value` is the PCIe-inclusive rate;
+the timed region, one step ahead on a copy stream (ecamp_amd.data.DevicePrefetcher; the pipeline runs through warm-up and timed steps
+alike, so each timed step issues one batch copy and consumes the one issued a step earlier): `value` is the PCIe-inclusive rate;
 `resident_pairs_per_s` (inputs already in HBM), forward-only and forward+backward-only rates are reported beside it.
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment launches its own N ranks (one child process per GPU,
@@ -191,10 +192,15 @@ def main():
             dist.barrier()
         return time.perf_counter() - t0
 
+    # ONE prefetch pipeline across warm-up and timed steps, as in a training run: taking batch i out of it issues the copy of batch
+    # i+1, so each of the K timed steps carries exactly one host->HBM batch copy (the copy of the first timed batch was issued by the
+    # last warm-up step, the last timed step issues one for a batch that is never consumed: K copies inside the region either way).
+    pipeline = iter(DevicePrefetcher([host_batch] * (args.warmup + args.steps + 1), dev))
+
     def run_inclusive(n):
         nonlocal out
-        for b in DevicePrefetcher([host_batch] * n, dev):
-            out = step(b)
+        for _ in range(n):
+            out = step(next(pipeline))
 
     out = None
     if args.warmup > 0:
@@ -269,7 +275,8 @@ def main():
                           "pairs_per_gpu": args.batch, "global_batch": args.batch * world, "image": "448^2 -> 224^2 encoder input",
                           "seq_len": args.seq, "mask_ratio": 0.75, "accum_iter": 1, "parallelism": "dp%d" % world,
                           "last_losses_mim_res_mlm": [round(x, 5) for x in losses]},
-               "input": "pinned host memory -> HBM inside the timed region (prefetched one step ahead on a copy stream)",
+               "input": "pinned host memory -> HBM inside the timed region: every timed step issues the copy of the next batch on a copy "
+                        "stream (steady-state pipeline, primed by the warm-up steps)",
                "resident_pairs_per_s": round(args.batch * world / dt_res, 2), "resident_ms_per_step": round(1e3 * dt_res, 3),
                "fwd_only_ms": round(1e3 * dt_fwd, 3), "fwd_only_pairs_per_s": round(args.batch * world / dt_fwd, 2),
                "fwd_bwd_ms": round(1e3 * dt_fb, 3), "fwd_bwd_pairs_per_s": round(args.batch * world / dt_fb, 2)}
