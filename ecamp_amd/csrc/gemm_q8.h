@@ -142,7 +142,8 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
 }
 
 // DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 8 = no s_setprio, 16 = no barrier in the
-// loop, 32 = no fragment reads, 64 = every DMA re-reads the tile's first K tile (timing decomposition only: 16, 32, 64 give wrong results)
+// loop, 32 = no fragment reads, 64 = every DMA re-reads the tile's first K tile (timing decomposition only: 16, 32, 64 give wrong results),
+// 128 / 256 = nt / sc1 output stores, 512 = workgroups start in four phases 9 us apart (lock-step epilogue bursts: the stagger costs what it saves)
 // ROWSUM (weight-gradient form only): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient -- summed on the VALU from the M-side
 // fragments by the first wave column of the tiles in the first N-tile column, added with 4 buffer atomics per wave and tile.
 template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false>
@@ -496,6 +497,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
     } while (0)
 
+    if (DBG & 512) {   // probe: workgroups start in four phases ~9 us apart (are the lock-step epilogue bursts of a round the cost?)
+        const long long t0 = wall_clock64();   // 100 MHz
+        const long long d = (long long)(blockIdx.x & 3) * 900;
+        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
     // prologue: K tiles 0 and 1 issued, K tile 0 landed and published, its first group requested
     Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
     Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
