@@ -1073,10 +1073,11 @@ static void lds_optin(K kern, size_t bytes) {
     } while (0)
 
 // =============================================================================================
+// (the opt-in is for the largest size any later call of the same instantiation may ask for, not for this call's)
 #define LAUNCH_H(KERN, GRID, BLOCK, SHM, ST, ARGS)           \
     do {                                                     \
         static bool once_ = false;                           \
-        if (!once_) { lds_optin(KERN, SHM); once_ = true; }  \
+        if (!once_) { lds_optin(KERN, LDS_MAX); once_ = true; }  \
         hipLaunchKernelGGL(KERN, GRID, dim3(BLOCK), SHM, ST, ARGS); \
     } while (0)
 #define LDS_MAX (160 * 1024)

@@ -250,7 +250,9 @@ def test_attention_dropout_statistics(dev):
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,hd,masked,p", [(2, 6, 128, 128, 128, True, 0.1), (2, 6, 128, 49, 128, False, 0.1), (3, 16, 197, 197, 32, False, 0.0),
-                                                   (2, 12, 50, 50, 64, False, 0.2), (1, 4, 250, 256, 64, True, 0.1), (2, 3, 33, 17, 32, True, 0.3)])
+                                                   (2, 12, 50, 50, 64, False, 0.2), (1, 4, 250, 256, 64, True, 0.1), (2, 3, 33, 17, 32, True, 0.3),
+                                                   # the same kernel instantiation first below, then above the 48 KB LDS opt-in threshold
+                                                   (1, 2, 70, 70, 64, False, 0.0), (1, 2, 200, 200, 64, False, 0.0)])
 def test_attention_head_kernels_match_streaming_kernels(dev, B, H, Tq, Tk, hd, masked, p):
     """The head-resident kernels (one workgroup per (batch, head), P kept in registers, one fused backward kernel) and the 64-row
     streaming kernels implement the same function with the same Philox dropout mask: same seed/offset -> same dropped entries, outputs
