@@ -753,7 +753,7 @@ template <int HD> __device__ __forceinline__ bf16x8 htr(const unsigned char* img
 // here (measured on T = 197: 89 VGPRs / 2 workgroups per CU 71 us, 154 VGPRs / 1 workgroup 98 us).
 // Tiles are walked in pairs (32 keys); key tiles below `nfull` hold only attended keys and skip the bias.
 // FLAGS 0: no key mask, no dropout (the image side).  FLAGS 1: key bias on every tile + dropout if drop_p > 0 (the report side).
-template <int HD, int FLAGS, bool PF>
+template <int HD, int FLAGS>
 __global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RB = HeadCfg<HD>::RB;
@@ -770,10 +770,9 @@ __global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
     const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
     const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
     bf16_t* ob = reinterpret_cast<bf16_t*>(a.o) + b * a.o_sb + h * a.o_sh;
-    // the fragments a wave owns come from global memory: the first block's are requested before the staging loads, the next
-    // block's while the current one is worked on (PF: the host sets it when a wave owns more than one block and hd <= 64 -- at
-    // hd = 128 the second set of registers costs the occupancy it would buy)
-    bf16x8 qf[HD / 32], qn[HD / 32];
+    // the fragments a wave owns come from global memory; the first block's are requested before the staging loads (requesting the
+    // next block's a block ahead, into a second register set, measured the same: 228 vs 230 us on the T = 197 backward)
+    bf16x8 qf[HD / 32];
     if (wave * 16 < a.Tq) load_row_frags<HD>(qf, qb, a.q_st, wave * 16, a.Tq, lane);
     head_stage<HD>(KI, kb, a.k_st, a.Tk, prow, tid, nthr);
     head_stage<HD>(VI, vb, a.v_st, a.Tk, prow, tid, nthr);
@@ -783,8 +782,6 @@ __global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
     const float sc2 = a.scale * ATTN_LOG2E;
     const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     for (int q0 = wave * 16; q0 < a.Tq; q0 += nw * 16) {
-        const bool more = q0 + nw * 16 < a.Tq;
-        if (PF && more) load_row_frags<HD>(qn, qb, a.q_st, q0 + nw * 16, a.Tq, lane);
         // scores of key tile t in base-2 units (the product, not the raw MFMA result, is what fmaxf sees: no canonicalising v_max x, x)
         auto scores = [&](int t, bool biased) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -851,19 +848,12 @@ __global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int dt = 0; dt < HD / 16; ++dt) store4(ob + (long)qi * a.o_st + dt * 16 + 4 * g, o[dt], inv);
         }
-        if (more) {
-            if (PF) {
-#pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = qn[ks];
-            } else {
-                load_row_frags<HD>(qf, qb, a.q_st, q0 + nw * 16, a.Tq, lane);
-            }
-        }
+        if (q0 + nw * 16 < a.Tq) load_row_frags<HD>(qf, qb, a.q_st, q0 + nw * 16, a.Tq, lane);
     }
 }
 
-template <int HD, int FLAGS, bool PF>
-__global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
+template <int HD, int FLAGS>
+__global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && HD == 64) ? 4 : 1) void attn_head_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RB = HeadCfg<HD>::RB;
     const int nthr = blockDim.x, nw = nthr >> 6;
@@ -890,11 +880,9 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
     const HeadOff<HD> off(li, g);
 
     // ---- phase 1: dQ (+ lse, delta -> LDS) -------------------------------------------------------------------------------------
-    // the fragments a wave owns come from global memory: the first block's are requested before the staging loads, the next
-    // block's while the current one is worked on (PF: the host sets it when a wave owns more than one block and hd <= 64 -- at
-    // hd = 128 the second set of registers costs the occupancy it would buy)
-    bf16x8 qf[HD / 32], gf[HD / 32], of[HD / 32], qn[HD / 32], gn[HD / 32], on[HD / 32];
-    float lse_c = 0.f, lse_n = 0.f;
+    // the fragments a wave owns come from global memory; the first block's are requested before the staging loads
+    bf16x8 qf[HD / 32], gf[HD / 32], of[HD / 32];
+    float lse_c = 0.f;
     auto load_q = [&](int q0, bf16x8 (&q_)[HD / 32], bf16x8 (&g_)[HD / 32], bf16x8 (&o_)[HD / 32], float& l_) {
         load_row_frags<HD>(q_, qb, a.q_st, q0, a.Tq, lane);
         load_row_frags<HD>(g_, gb, a.do_st, q0, a.Tq, lane);
@@ -908,8 +896,6 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
     for (int i = ((a.Tq + 15) & ~15) + tid; i < prow; i += nthr) { LS[i] = 1e30f; DL[i] = 0.f; }
     __syncthreads();
     for (int q0 = wave * 16; q0 < a.Tq; q0 += nw * 16) {
-        const bool more = q0 + nw * 16 < a.Tq;
-        if (PF && more) load_q(q0 + nw * 16, qn, gn, on, lse_n);
         float dl = 0.f;
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks)
@@ -970,18 +956,10 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int dt = 0; dt < HD / 16; ++dt) store4(dqb + (long)qi * a.dq_st + dt * 16 + 4 * g, dq[dt], a.scale);
         }
-        if (more) {
-            if (PF) {
-#pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) { qf[ks] = qn[ks]; gf[ks] = gn[ks]; of[ks] = on[ks]; }
-                lse_c = lse_n;
-            } else {
-                load_q(q0 + nw * 16, qf, gf, of, lse_c);
-            }
-        }
+        if (q0 + nw * 16 < a.Tq) load_q(q0 + nw * 16, qf, gf, of, lse_c);
     }
     // ---- phase 2: dK, dV ---------------------------------------------------------------------------------------------------------
-    bf16x8 kf[HD / 32], vf[HD / 32], kn[HD / 32], vn[HD / 32];
+    bf16x8 kf[HD / 32], vf[HD / 32];
     if (wave * 16 < a.Tk) {
         load_row_frags<HD>(kf, kb, a.k_st, wave * 16, a.Tk, lane);
         load_row_frags<HD>(vf, vb, a.v_st, wave * 16, a.Tk, lane);
@@ -991,11 +969,6 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
     head_stage<HD>(YI, gb, a.do_st, a.Tq, prow, tid, nthr);
     __syncthreads();
     for (int j0 = wave * 16; j0 < a.Tk; j0 += nw * 16) {
-        const bool more = j0 + nw * 16 < a.Tk;
-        if (PF && more) {
-            load_row_frags<HD>(kn, kb, a.k_st, j0 + nw * 16, a.Tk, lane);
-            load_row_frags<HD>(vn, vb, a.v_st, j0 + nw * 16, a.Tk, lane);
-        }
         const int kj = j0 + li;
         const bool jok = KB[kj] == 0.f;
         f32x4 dk[HD / 16], dv[HD / 16];   // [dt][r] = dK / dV[j = j0+li][d = dt*16 + 4g + r]
@@ -1049,14 +1022,9 @@ __global__ __launch_bounds__(512) void attn_head_bwd_kernel(AttnArgs a) {
                 store4(dvb + (long)kj * a.dv_st + dt * 16 + 4 * g, dv[dt], mv);
             }
         }
-        if (more) {
-            if (PF) {
-#pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
-            } else {
-                load_row_frags<HD>(kf, kb, a.k_st, j0 + nw * 16, a.Tk, lane);
-                load_row_frags<HD>(vf, vb, a.v_st, j0 + nw * 16, a.Tk, lane);
-            }
+        if (j0 + nw * 16 < a.Tk) {
+            load_row_frags<HD>(kf, kb, a.k_st, j0 + nw * 16, a.Tk, lane);
+            load_row_frags<HD>(vf, vb, a.v_st, j0 + nw * 16, a.Tk, lane);
         }
     }
 }
@@ -1100,10 +1068,9 @@ static bool head_fwd(const AttnArgs& a, hipStream_t st) {
     const size_t shm = (size_t)2 * prow * HeadCfg<HD>::RB + (size_t)prow * sizeof(float);
     if (!head_enabled() || shm > LDS_MAX) return false;
     const dim3 grid(a.B * a.H);
-    const int nqt = (a.Tq + 15) / 16, nw = head_waves(nqt, 8);
-    const bool flags = a.key_mask != nullptr || a.drop_p > 0.f, pf = HD <= 64 && nqt > nw;
-    if (flags) { if (pf) LAUNCH_H((attn_head_fwd_kernel<HD, 1, true>), grid, nw * 64, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 1, false>), grid, nw * 64, shm, st, a); }
-    else       { if (pf) LAUNCH_H((attn_head_fwd_kernel<HD, 0, true>), grid, nw * 64, shm, st, a); else LAUNCH_H((attn_head_fwd_kernel<HD, 0, false>), grid, nw * 64, shm, st, a); }
+    const int nw = head_waves((a.Tq + 15) / 16, 8);
+    if (a.key_mask != nullptr || a.drop_p > 0.f) LAUNCH_H((attn_head_fwd_kernel<HD, 1>), grid, nw * 64, shm, st, a);
+    else LAUNCH_H((attn_head_fwd_kernel<HD, 0>), grid, nw * 64, shm, st, a);
     return true;
 }
 template <int HD>
@@ -1114,10 +1081,9 @@ static bool head_bwd(const AttnArgs& a, hipStream_t st) {
     const dim3 grid(a.B * a.H);
     // four waves: two (hd = 128: the register file) to five workgroups share a CU and one's staging overlaps another's tile loops
     // (T = 197, hd = 32: 230 us against 260 us with eight; T = 128, hd = 128: 147 against 161)
-    const int nt = nkt > nqt ? nkt : nqt, nw = head_waves(nt, 4);
-    const bool flags = a.key_mask != nullptr || a.drop_p > 0.f, pf = HD <= 64 && nt > nw;
-    if (flags) { if (pf) LAUNCH_H((attn_head_bwd_kernel<HD, 1, true>), grid, nw * 64, shm, st, a); else LAUNCH_H((attn_head_bwd_kernel<HD, 1, false>), grid, nw * 64, shm, st, a); }
-    else       { if (pf) LAUNCH_H((attn_head_bwd_kernel<HD, 0, true>), grid, nw * 64, shm, st, a); else LAUNCH_H((attn_head_bwd_kernel<HD, 0, false>), grid, nw * 64, shm, st, a); }
+    const int nw = head_waves(nkt > nqt ? nkt : nqt, 4);
+    if (a.key_mask != nullptr || a.drop_p > 0.f) LAUNCH_H((attn_head_bwd_kernel<HD, 1>), grid, nw * 64, shm, st, a);
+    else LAUNCH_H((attn_head_bwd_kernel<HD, 0>), grid, nw * 64, shm, st, a);
     return true;
 }
 template <int HD>
