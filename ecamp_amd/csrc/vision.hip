@@ -1245,6 +1245,366 @@ __global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __rest
     }
 }
 
+// ---- backward on the matrix cores, pixel-PAIR form (the production kernel of compute_dtype = bf16) ---------------------------------
+// Same eight stages as sr_mfma_bwd_kernel; what changed is what a lane does per instruction:
+//  * a lane convolves TWO horizontally adjacent pixels: the 4 x 3 input pixels they share are six 16-B LDS reads (48 B per output
+//    pixel instead of 72, a third of the read instructions).  For the reads to be 16-B aligned the tiles alternate their column
+//    origin: u at -6 (even), c1 at -5 (pairs start on odd columns), ds at -4, dc1 at -3, du at -2 -- every stage computes one spare
+//    column on each side.
+//  * u comes from 2 x 2 blocks (the x2 bilinear filter has two phases: .25/.75 and .75/.25 on a 3 x 3 patch of pred_img).
+//  * weight gradients run on the matrix cores too: ds_read_b64_tr_b16 turns the channel-interleaved pixels of 4 lanes into
+//    "4 pixels of one channel" per lane, which is exactly a row of A (ds[o][4 pixels]) and a column of B (c1[i][the 4 pixels, shifted
+//    by the tap]) of v_mfma_f32_4x4x4: D[o][i] accumulates the tap's 3 x 3 channel block over pixels, 16 blocks per wave; one MFMA
+//    against a vector of ones gives the bias gradient.  2 + 18 transpose reads and 20 MFMAs per 64 pixels replace ~90 VALU
+//    instructions per 64 pixels and wave of the tap-split f32 form.
+//  * the 168 gradient sums leave the workgroup once, reduced through LDS, as three wave-wide atomics (the per-wave single-lane
+//    atomics of the older kernels serialise on three cache lines).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ bf16x4_t sr_px(unsigned a, unsigned b) { return __builtin_bit_cast(bf16x4_t, (u32x2_t){a, b}); }
+__device__ __forceinline__ bf16x4_t sr_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4_t __attribute__((address_space(3)))*)p);
+}
+// 3x3 stencils of the pixel pair at columns 1 and 2 of the 3 x 4 input window at p (tile edge ES pixels); two MFMA chains per pixel
+template <int ES, bool FLIP>
+__device__ __forceinline__ void sr_pair_conv(const unsigned char* p, const bf16x4_t (&a)[9], const f32x4_t init, f32x4_t& oA, f32x4_t& oB) {
+    f32x4_t a0 = init, b0 = init, a1 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(p + r * ES * 8);
+        const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(p + r * ES * 8 + 16);
+        const bf16x4_t px[4] = {sr_px(lo[0], lo[1]), sr_px(lo[2], lo[3]), sr_px(hi[0], hi[1]), sr_px(hi[2], hi[3])};
+        const int ky = FLIP ? 2 - r : r;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int kx = FLIP ? 2 - j : j;
+            if ((r * 3 + j) & 1) {
+                a1 = MFMA4(a[ky * 3 + kx], px[j], a1);
+                b1 = MFMA4(a[ky * 3 + kx], px[j + 1], b1);
+            } else {
+                a0 = MFMA4(a[ky * 3 + kx], px[j], a0);
+                b0 = MFMA4(a[ky * 3 + kx], px[j + 1], b0);
+            }
+        }
+    }
+    oA = a0 + a1;
+    oB = b0 + b1;
+}
+#define SRP_LDS_BYTES (44 * 44 * 8 + 40 * 42 * 8 + 38 * 40 * 8 + 36 * 38 * 8 + 3 * 34 * 36 * 4 + 4 * 9 * 4 * 8)
+__global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+                                                             const long* __restrict__ column, const long* __restrict__ row, SrP P,
+                                                             float* __restrict__ dsr, float* __restrict__ gw, long B, int R, int win) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];   // the only LDS object (16-B aligned carve)
+    unsigned char* U16 = smem8;                          // rows -6..37 x cols -6..37   (44 x 44 px of 8 B)
+    unsigned char* C16 = U16 + 44 * 44 * 8;              // rows -4..35 x cols -5..36   (40 x 42)
+    unsigned char* DS16 = C16 + 40 * 42 * 8;             // rows -3..34 x cols -4..35   (38 x 40)
+    unsigned char* DC16 = DS16 + 38 * 40 * 8;            // rows -2..33 x cols -3..34   (36 x 38)
+    float* DU = reinterpret_cast<float*>(DC16 + 36 * 38 * 8);   // [3] x rows -1..32 x cols -2..33 (34 x 36 f32); first the 3 x 24 x 24 pred_img patch
+    float* PP = DU;
+    bf16x4_t(*TAPS)[9][4] = reinterpret_cast<bf16x4_t(*)[9][4]>(reinterpret_cast<unsigned char*>(DU) + 3 * 34 * 36 * 4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 144) {
+        const int c = threadIdx.x / 36, t = (threadIdx.x / 4) % 9, i = threadIdx.x & 3;
+        const float* w = (c == 0 || c == 3) ? P.w1 : P.w2;
+        const bool trans = c >= 2;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (i < 3) {
+            for (int kk = 0; kk < 3; ++kk) v[kk] = trans ? w[(kk * 3 + i) * 9 + t] : w[(i * 3 + kk) * 9 + t];
+        }
+        TAPS[c][t][i] = sr_pack4(v[0], v[1], v[2]);
+    }
+#define SR_TAPS(NAME, C)                                                     \
+    bf16x4_t NAME[9];                                                        \
+    _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) NAME[t_] = TAPS[(C)][t_][lane & 3]
+    const f32x4_t bias1 = {P.b1[0], P.b1[1], P.b1[2], 0.f}, bias2 = {P.b2[0], P.b2[1], P.b2[2], 0.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bf16x4_t ones = {(short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80};
+    const int R2 = 2 * R, G = R2 / SRT, PT = SRT / 2;
+    const long T = B * G * G;
+    f32x4_t G1[9], G2[9], gb1 = zero4, gb2 = zero4;   // [tap][o] of input channel lane & 3, summed over this lane's block's pixels
+#pragma unroll
+    for (int q = 0; q < 9; ++q) G1[q] = G2[q] = zero4;
+    const int py = threadIdx.x / PT, px = threadIdx.x % PT;  // this thread's pred_img pixel of a 16x16 tile
+
+    auto advance = [&](long t) {   // next reachable tile at or after t; tiles with no window pixel within reach get a zero gradient
+        for (; t < T; t += gridDim.x) {
+            const long b = t / (G * G);
+            const int ty = (int)((t / G) % G), tx = (int)(t % G);
+            const int c0 = (int)column[b], r0 = (int)row[b];
+            if (!(ty < c0 - 1 || ty > c0 + win || tx < r0 - 1 || tx > r0 + win)) break;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dsr[((b * 3 + c) * (long)R + ty * PT + py) * R + tx * PT + px] = 0.f;
+        }
+        return t;
+    };
+    float pp[7], bigv[3][3][2];
+    bool inw[3];
+    auto fetch_patch = [&](long t) {
+        const long b = t / (G * G);
+        const int ylo = (int)((t / G) % G) * (SRT / 2) - 4, xlo = (int)(t % G) * (SRT / 2) - 4;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            const int c = idx / 576, yy = (idx / 24) % 24, xx = idx % 24;
+            const int y = min(max(ylo + yy, 0), R - 1), x = min(max(xlo + xx, 0), R - 1);
+            pp[k] = idx < 3 * 576 ? pred_img[((b * 3 + c) * (long)R + y) * R + x] : 0.f;
+        }
+    };
+    auto fetch_big = [&](long t) {   // the targets of pixel pair (wave + 4j)*64 + lane of the 38 x 20 pairs of the ds stage
+        const long b = t / (G * G);
+        const int Y0 = (int)((t / G) % G) * SRT, X0 = (int)(t % G) * SRT;
+        const int c0 = (int)column[b], r0 = (int)row[b];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = (wave + 4 * j) * 64 + lane;
+            const int y = p / 20, xq = p - y * 20;
+            const int Y = Y0 - 3 + y, X = X0 - 4 + 2 * xq;
+            bool in = p < 38 * 20 && Y >= 0 && Y < R2 && X >= 0 && X < R2;
+            if (in) {
+                const int gy = Y / SRT, gx = X / SRT;
+                in = gy >= c0 && gy < c0 + win && gx >= r0 && gx < r0 + win;
+            }
+            inw[j] = in;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float2 v = in ? *reinterpret_cast<const float2*>(big + ((b * 3 + o) * (long)R2 + Y) * R2 + X) : make_float2(0.f, 0.f);
+                bigv[j][o][0] = v.x;
+                bigv[j][o][1] = v.y;
+            }
+        }
+    };
+    long t = advance(blockIdx.x);
+    if (t < T) {
+        fetch_patch(t);
+        fetch_big(t);
+    }
+    while (t < T) {
+        const long b = t / (G * G);
+        const int ty = (int)((t / G) % G), tx = (int)(t % G);
+        const int Y0 = ty * SRT, X0 = tx * SRT;
+        __syncthreads();   // the previous tile's stage 8 is done with DU (= the patch buffer)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            if (idx < 3 * 576) PP[idx] = pp[k];
+        }
+        const long tn = advance(t + gridDim.x);
+        if (tn < T) fetch_patch(tn);          // in flight until the next iteration
+        __syncthreads();
+        // (2) u on rows / cols -6..37 in 2 x 2 blocks: even outputs .25 p[y-1] + .75 p[y], odd ones .75 p[y] + .25 p[y+1]
+        for (int id = threadIdx.x; id < 22 * 22; id += 256) {
+            const int by = id / 22, bx = id - by * 22;
+            float o[3][2][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* pl = PP + c * 576 + by * 24 + bx;
+                float he[3], ho[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float v0 = pl[r * 24], v1 = pl[r * 24 + 1], v2 = pl[r * 24 + 2];
+                    he[r] = 0.25f * v0 + 0.75f * v1;
+                    ho[r] = 0.75f * v1 + 0.25f * v2;
+                }
+                o[c][0][0] = 0.25f * he[0] + 0.75f * he[1];
+                o[c][0][1] = 0.25f * ho[0] + 0.75f * ho[1];
+                o[c][1][0] = 0.75f * he[1] + 0.25f * he[2];
+                o[c][1][1] = 0.75f * ho[1] + 0.25f * ho[2];
+            }
+            const int Y = Y0 - 6 + 2 * by, X = X0 - 6 + 2 * bx;       // both even: a block is inside or outside the image as a whole
+            const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                u32x4_t q;
+                q[0] = in ? pack_bf16x2(o[0][e][0], o[1][e][0]) : 0u;
+                q[1] = in ? pack_bf16x2(o[2][e][0], 0.f) : 0u;
+                q[2] = in ? pack_bf16x2(o[0][e][1], o[1][e][1]) : 0u;
+                q[3] = in ? pack_bf16x2(o[2][e][1], 0.f) : 0u;
+                *reinterpret_cast<u32x4_t*>(U16 + ((2 * by + e) * 44 + 2 * bx) * 8) = q;
+            }
+        }
+        __syncthreads();
+        // (3) c1 = relu(conv1(u) + b1) on rows -4..35, column pairs from -5; 0 outside the image
+        {
+            SR_TAPS(a1, 0);
+            for (int g = wave; g < (40 * 21 + 63) / 64; g += 4) {
+                const int p = g * 64 + lane, pc = min(p, 40 * 21 - 1);
+                const int y = pc / 21, xq = pc - y * 21;
+                f32x4_t oA, oB;
+                sr_pair_conv<44, false>(U16 + ((y + 1) * 44 + 2 * xq) * 8, a1, bias1, oA, oB);
+                const int Y = Y0 - 4 + y, X = X0 - 5 + 2 * xq;
+                const bool iy = Y >= 0 && Y < R2, inA = iy && X >= 0 && X < R2, inB = iy && X + 1 >= 0 && X + 1 < R2;
+                u32x4_t q;
+                q[0] = inA ? pack_bf16x2(fmaxf(oA[0], 0.f), fmaxf(oA[1], 0.f)) : 0u;
+                q[1] = inA ? pack_bf16x2(fmaxf(oA[2], 0.f), 0.f) : 0u;
+                q[2] = inB ? pack_bf16x2(fmaxf(oB[0], 0.f), fmaxf(oB[1], 0.f)) : 0u;
+                q[3] = inB ? pack_bf16x2(fmaxf(oB[2], 0.f), 0.f) : 0u;
+                if (p < 40 * 21) *reinterpret_cast<u32x4_t*>(C16 + (y * 42 + 2 * xq) * 8) = q;
+            }
+        }
+        __syncthreads();
+        // (4) ds = [pixel in window] * (s - big) * [s > 0], s = relu(conv2(c1) + b2 + u), on rows -3..34, column pairs from -4
+        {
+            SR_TAPS(a2, 1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int g = wave + 4 * j;
+                const int p = g * 64 + lane, pc = min(p, 38 * 20 - 1);
+                const int y = pc / 20, xq = pc - y * 20;
+                f32x4_t oA, oB;
+                sr_pair_conv<42, false>(C16 + (y * 42 + 2 * xq) * 8, a2, bias2, oA, oB);
+                float dA[3] = {0.f, 0.f, 0.f}, dB[3] = {0.f, 0.f, 0.f};
+                if (inw[j]) {
+                    const u32x4_t uu = *reinterpret_cast<const u32x4_t*>(U16 + ((y + 3) * 44 + 2 * xq + 2) * 8);
+                    float uA[3], uB[3];
+                    sr_unpack3(make_uint2(uu[0], uu[1]), uA);
+                    sr_unpack3(make_uint2(uu[2], uu[3]), uB);
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const float sA = fmaxf(oA[o] + uA[o], 0.f), sB = fmaxf(oB[o] + uB[o], 0.f);
+                        dA[o] = sA > 0.f ? sA - bigv[j][o][0] : 0.f;
+                        dB[o] = sB > 0.f ? sB - bigv[j][o][1] : 0.f;
+                    }
+                }
+                if (p < 38 * 20)
+                    *reinterpret_cast<u32x4_t*>(DS16 + (y * 40 + 2 * xq) * 8) =
+                        (u32x4_t){pack_bf16x2(dA[0], dA[1]), pack_bf16x2(dA[2], 0.f), pack_bf16x2(dB[0], dB[1]), pack_bf16x2(dB[2], 0.f)};
+            }
+        }
+        if (tn < T) fetch_big(tn);            // bigv / inw are free again: request the next tile's targets
+        __syncthreads();
+        // (5) dc1 = [c1 > 0] * conv2^T(ds) on rows -2..33, column pairs from -3 (c1 is 0 outside the image, so is dc1)
+        {
+            SR_TAPS(a2t, 2);
+            for (int g = wave; g < (36 * 19 + 63) / 64; g += 4) {
+                const int p = g * 64 + lane, pc = min(p, 36 * 19 - 1);
+                const int y = pc / 19, xq = pc - y * 19;
+                f32x4_t oA, oB;
+                sr_pair_conv<40, true>(DS16 + (y * 40 + 2 * xq) * 8, a2t, zero4, oA, oB);
+                const u32x4_t cc = *reinterpret_cast<const u32x4_t*>(C16 + ((y + 2) * 42 + 2 * xq + 2) * 8);
+                float cA[3], cB[3];
+                sr_unpack3(make_uint2(cc[0], cc[1]), cA);
+                sr_unpack3(make_uint2(cc[2], cc[3]), cB);
+                float dA[3], dB[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    dA[i] = cA[i] > 0.f ? oA[i] : 0.f;
+                    dB[i] = cB[i] > 0.f ? oB[i] : 0.f;
+                }
+                if (p < 36 * 19)
+                    *reinterpret_cast<u32x4_t*>(DC16 + (y * 38 + 2 * xq) * 8) =
+                        (u32x4_t){pack_bf16x2(dA[0], dA[1]), pack_bf16x2(dA[2], 0.f), pack_bf16x2(dB[0], dB[1]), pack_bf16x2(dB[2], 0.f)};
+            }
+        }
+        __syncthreads();
+        // (6) weight gradients over the 32 x 32 centre: conv2 from (ds, c1), conv1 from (dc1, u).  Lane l of a group of 64 pixels
+        // (two rows) names pixel l; after the transpose read lane (block, ch) holds channel ch of the block's four pixels.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = 2 * (wave * 4 + j) + (lane >> 5), x = lane & 31;
+            const bf16x4_t A2 = sr_tr(DS16 + ((y + 3) * 40 + x + 4) * 8);
+            const bf16x4_t A1 = sr_tr(DC16 + ((y + 2) * 38 + x + 3) * 8);
+            gb2 = MFMA4(A2, ones, gb2);
+            gb1 = MFMA4(A1, ones, gb1);
+            const unsigned char* cb = C16 + ((y + 3) * 42 + x + 4) * 8;   // tap (ky, kx) reads centre + (ky - 1, kx - 1)
+            const unsigned char* ub = U16 + ((y + 5) * 44 + x + 5) * 8;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int ky = q / 3, kx = q % 3;
+                G2[q] = MFMA4(A2, sr_tr(cb + (ky * 42 + kx) * 8), G2[q]);
+                G1[q] = MFMA4(A1, sr_tr(ub + (ky * 44 + kx) * 8), G1[q]);
+            }
+        }
+        // (7) du (f32, planar) = ds + conv1^T(dc1) on rows -1..32, column pairs from -2; 0 outside the image
+        {
+            SR_TAPS(a1t, 3);
+            for (int g = wave; g < (34 * 18 + 63) / 64; g += 4) {
+                const int p = g * 64 + lane, pc = min(p, 34 * 18 - 1);
+                const int y = pc / 18, xq = pc - y * 18;
+                f32x4_t oA, oB;
+                sr_pair_conv<38, true>(DC16 + (y * 38 + 2 * xq) * 8, a1t, zero4, oA, oB);
+                const u32x4_t dd = *reinterpret_cast<const u32x4_t*>(DS16 + ((y + 2) * 40 + 2 * xq + 2) * 8);
+                float dA[3], dB[3];
+                sr_unpack3(make_uint2(dd[0], dd[1]), dA);
+                sr_unpack3(make_uint2(dd[2], dd[3]), dB);
+                const int Y = Y0 - 1 + y, X = X0 - 2 + 2 * xq;     // X even: the pair is inside or outside as a whole
+                const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+                if (p < 34 * 18) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        *reinterpret_cast<float2*>(DU + (i * 34 + y) * 36 + 2 * xq) = in ? make_float2(oA[i] + dA[i], oB[i] + dB[i]) : make_float2(0.f, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        // (8) transpose of the bilinear x2: each pred_img pixel gathers the <= 4x4 du values whose footprint touches it; the
+        // 4 + 4 row / column weights do not depend on the channel
+        {
+            const int y = ty * PT + py, x = tx * PT + px;
+            float wyv[4], wxv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int Y = 2 * y - 1 + k, X = 2 * x - 1 + k;
+                int q0, q1;
+                float w0, w1;
+                wyv[k] = 0.f;
+                wxv[k] = 0.f;
+                if (Y >= 0 && Y < R2) {
+                    up2_taps(Y, R, q0, q1, w0, w1);
+                    wyv[k] = (q0 == y ? w0 : 0.f) + (q1 == y ? w1 : 0.f);
+                }
+                if (X >= 0 && X < R2) {
+                    up2_taps(X, R, q0, q1, w0, w1);
+                    wxv[k] = (q0 == x ? w0 : 0.f) + (q1 == x ? w1 : 0.f);
+                }
+            }
+            const int yb = 2 * py, xb = 2 * px + 1;   // DU coordinates of (2y-1, 2x-1): (Y - Y0 + 1, X - X0 + 2)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    float rowv = 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) rowv += wxv[kx] * DU[(c * 34 + yb + ky) * 36 + xb + kx];
+                    acc += wyv[ky] * rowv;
+                }
+                dsr[((b * 3 + c) * (long)R + y) * R + x] = acc;
+            }
+        }
+        t = tn;
+    }
+#undef SR_TAPS
+    // the workgroup's 168 sums: blocks of a wave by shuffles (lanes with the same lane & 3), waves through LDS, then one atomic per
+    // value: gw = {dW1[81], db1[3], dW2[81], db2[3]}, dW[o][i][ky][kx] at o*27 + i*9 + tap
+    __syncthreads();
+    float* RED = reinterpret_cast<float*>(U16);   // [4 waves][168]
+    auto blocks_sum = [&](float v) {
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    const int ic = lane & 3;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float s1 = blocks_sum(G1[q][o]), s2 = blocks_sum(G2[q][o]);
+            if (lane < 3) {
+                RED[wave * 168 + o * 27 + ic * 9 + q] = s1;
+                RED[wave * 168 + 84 + o * 27 + ic * 9 + q] = s2;
+            }
+        }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float s1 = blocks_sum(gb1[o]), s2 = blocks_sum(gb2[o]);
+        if (lane == 0) {
+            RED[wave * 168 + 81 + o] = s1;
+            RED[wave * 168 + 165 + o] = s2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 168) atomicAdd(gw + threadIdx.x, RED[threadIdx.x] + RED[168 + threadIdx.x] + RED[336 + threadIdx.x] + RED[504 + threadIdx.x]);
+}
+
 extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B, int32_t R,
                             int32_t super_patch, int32_t window, int32_t mode, hipStream_t stream) {
@@ -1301,6 +1661,21 @@ extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64
         once = true;
     }
     if (mode == 1) {
+        static int variant = -1, nbp = 0;   // ECAMP_SR_BWD=old selects the single-pixel kernel (A/B runs); ECAMP_SR_BLOCKS overrides the grid
+        if (variant < 0) {
+            const char* e = getenv("ECAMP_SR_BWD");
+            variant = (e && !strcmp(e, "old")) ? 0 : 1;
+            const char* nbe = getenv("ECAMP_SR_BLOCKS");
+            nbp = nbe ? atoi(nbe) : 512;            // two resident workgroups per CU
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sr_pair_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SRP_LDS_BYTES);
+        }
+        if (variant == 1) {
+            const int nb2 = (int)(tiles < nbp ? tiles : nbp);
+            hipLaunchKernelGGL(sr_pair_bwd_kernel, dim3(nb2), dim3(256), SRP_LDS_BYTES, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr,
+                               gw_ws, (long)B, R, window);
+            ECAMP_LAUNCH_CHECK();
+            return 0;
+        }
         const size_t shm8 = (size_t)(42 * 42 + 40 * 40 + 38 * 38 + 36 * 36) * 8 + (size_t)3 * 34 * 34 * sizeof(float);
         static bool once8 = false;
         if (!once8) {
