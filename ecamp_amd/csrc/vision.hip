@@ -1325,22 +1325,33 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
     for (int q = 0; q < 9; ++q) G1[q] = G2[q] = zero4;
     const int py = threadIdx.x / PT, px = threadIdx.x % PT;  // this thread's pred_img pixel of a 16x16 tile
 
-    auto advance = [&](long t) {   // next reachable tile at or after t; tiles with no window pixel within reach get a zero gradient
-        for (; t < T; t += gridDim.x) {
-            const long b = t / (G * G);
-            const int ty = (int)((t / G) % G), tx = (int)(t % G);
-            const int c0 = (int)column[b], r0 = (int)row[b];
-            if (!(ty < c0 - 1 || ty > c0 + win || tx < r0 - 1 || tx > r0 + win)) break;
+    // tile cursor: (b, ty, tx) of tile t, stepped by the grid size without divisions (all wave-uniform, 32-bit: B*G*G < 2^31, host-checked)
+    struct Cur { int t, b, ty, tx; };
+    const int GG = G * G, NT = (int)T;
+    const int step_b = (int)gridDim.x / GG, step_r = (int)gridDim.x - step_b * GG, step_y = step_r / G, step_x = step_r - step_y * G;
+    auto step = [&](Cur c) {
+        c.t += (int)gridDim.x;
+        c.tx += step_x;
+        if (c.tx >= G) { c.tx -= G; ++c.ty; }
+        c.ty += step_y;
+        if (c.ty >= G) { c.ty -= G; ++c.b; }
+        c.b += step_b;
+        return c;
+    };
+    auto advance = [&](Cur c) {   // next reachable tile at or after c; tiles with no window pixel within reach get a zero gradient
+        for (; c.t < NT; c = step(c)) {
+            const int c0 = (int)column[c.b], r0 = (int)row[c.b];
+            if (!(c.ty < c0 - 1 || c.ty > c0 + win || c.tx < r0 - 1 || c.tx > r0 + win)) break;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dsr[((b * 3 + c) * (long)R + ty * PT + py) * R + tx * PT + px] = 0.f;
+            for (int ch = 0; ch < 3; ++ch) dsr[((c.b * 3 + ch) * (long)R + c.ty * PT + py) * R + c.tx * PT + px] = 0.f;
         }
-        return t;
+        return c;
     };
     float pp[7], bigv[3][3][2];
     bool inw[3];
-    auto fetch_patch = [&](long t) {
-        const long b = t / (G * G);
-        const int ylo = (int)((t / G) % G) * (SRT / 2) - 4, xlo = (int)(t % G) * (SRT / 2) - 4;
+    auto fetch_patch = [&](const Cur& cu) {
+        const long b = cu.b;
+        const int ylo = cu.ty * (SRT / 2) - 4, xlo = cu.tx * (SRT / 2) - 4;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int idx = threadIdx.x + 256 * k;
@@ -1349,9 +1360,9 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
             pp[k] = idx < 3 * 576 ? pred_img[((b * 3 + c) * (long)R + y) * R + x] : 0.f;
         }
     };
-    auto fetch_big = [&](long t) {   // the targets of pixel pair (wave + 4j)*64 + lane of the 38 x 20 pairs of the ds stage
-        const long b = t / (G * G);
-        const int Y0 = (int)((t / G) % G) * SRT, X0 = (int)(t % G) * SRT;
+    auto fetch_big = [&](const Cur& cu) {   // the targets of pixel pair (wave + 4j)*64 + lane of the 38 x 20 pairs of the ds stage
+        const long b = cu.b;
+        const int Y0 = cu.ty * SRT, X0 = cu.tx * SRT;
         const int c0 = (int)column[b], r0 = (int)row[b];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -1372,14 +1383,16 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
             }
         }
     };
-    long t = advance(blockIdx.x);
-    if (t < T) {
-        fetch_patch(t);
-        fetch_big(t);
+    Cur cur;
+    cur.t = (int)blockIdx.x; cur.b = cur.t / GG; cur.ty = (cur.t - cur.b * GG) / G; cur.tx = cur.t - cur.b * GG - cur.ty * G;
+    cur = advance(cur);
+    if (cur.t < NT) {
+        fetch_patch(cur);
+        fetch_big(cur);
     }
-    while (t < T) {
-        const long b = t / (G * G);
-        const int ty = (int)((t / G) % G), tx = (int)(t % G);
+    while (cur.t < NT) {
+        const long b = cur.b;
+        const int ty = cur.ty, tx = cur.tx;
         const int Y0 = ty * SRT, X0 = tx * SRT;
         __syncthreads();   // the previous tile's stage 8 is done with DU (= the patch buffer)
 #pragma unroll
@@ -1387,8 +1400,8 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
             const int idx = threadIdx.x + 256 * k;
             if (idx < 3 * 576) PP[idx] = pp[k];
         }
-        const long tn = advance(t + gridDim.x);
-        if (tn < T) fetch_patch(tn);          // in flight until the next iteration
+        const Cur nxt = advance(step(cur));
+        if (nxt.t < NT) fetch_patch(nxt);     // in flight until the next iteration
         __syncthreads();
         // (2) u on rows / cols -6..37 in 2 x 2 blocks: even outputs .25 p[y-1] + .75 p[y], odd ones .75 p[y] + .25 p[y+1]
         for (int id = threadIdx.x; id < 22 * 22; id += 256) {
@@ -1469,7 +1482,7 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
                         (u32x4_t){pack_bf16x2(dA[0], dA[1]), pack_bf16x2(dA[2], 0.f), pack_bf16x2(dB[0], dB[1]), pack_bf16x2(dB[2], 0.f)};
             }
         }
-        if (tn < T) fetch_big(tn);            // bigv / inw are free again: request the next tile's targets
+        if (nxt.t < NT) fetch_big(nxt);       // bigv / inw are free again: request the next tile's targets
         __syncthreads();
         // (5) dc1 = [c1 > 0] * conv2^T(ds) on rows -2..33, column pairs from -3 (c1 is 0 outside the image, so is dc1)
         {
@@ -1513,11 +1526,15 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
                 G1[q] = MFMA4(A1, sr_tr(ub + (ky * 44 + kx) * 8), G1[q]);
             }
         }
-        // (7) du (f32, planar) = ds + conv1^T(dc1) on rows -1..32, column pairs from -2; 0 outside the image
+        // (7) du = ds + conv1^T(dc1) on rows -1..32, column pairs from -2 (0 outside the image), and at once the horizontal half of
+        // the transposed x2 bilinear filter: pred column x' gathers .25 du[2x'-1] + wa du[2x'] + wb du[2x'+1] + .25 du[2x'+2] with
+        // wa = .75 (1 at x' = 0), wb = .75 (1 at x' = R-1); pair xq = x' + 1 of a row holds du[2x'], du[2x'+1], its lane neighbours
+        // the other two (pairs 0 and 17 only serve as neighbours).  H: [3] x rows -1..32 x 16 columns, row pitch 24 floats.
         {
             SR_TAPS(a1t, 3);
-            for (int g = wave; g < (34 * 18 + 63) / 64; g += 4) {
-                const int p = g * 64 + lane, pc = min(p, 34 * 18 - 1);
+            // groups of 62 pairs: lanes 0 and 63 recompute the neighbours' pairs so that every lane in between finds both in the wave
+            for (int g = wave; g < (34 * 18 + 61) / 62; g += 4) {
+                const int p = g * 62 - 1 + lane, pc = min(max(p, 0), 34 * 18 - 1);
                 const int y = pc / 18, xq = pc - y * 18;
                 f32x4_t oA, oB;
                 sr_pair_conv<38, true>(DC16 + (y * 38 + 2 * xq) * 8, a1t, zero4, oA, oB);
@@ -1527,50 +1544,28 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
                 sr_unpack3(make_uint2(dd[2], dd[3]), dB);
                 const int Y = Y0 - 1 + y, X = X0 - 2 + 2 * xq;     // X even: the pair is inside or outside as a whole
                 const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
-                if (p < 34 * 18) {
+                const float wa = X == 0 ? 1.0f : 0.75f, wb = X == R2 - 2 ? 1.0f : 0.75f;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        *reinterpret_cast<float2*>(DU + (i * 34 + y) * 36 + 2 * xq) = in ? make_float2(oA[i] + dA[i], oB[i] + dB[i]) : make_float2(0.f, 0.f);
+                for (int i = 0; i < 3; ++i) {
+                    const float va = in ? oA[i] + dA[i] : 0.f, vb = in ? oB[i] + dB[i] : 0.f;
+                    const float left = __shfl_up(vb, 1, 64), right = __shfl_down(va, 1, 64);
+                    const float h = wa * va + wb * vb + 0.25f * (left + right);
+                    if (lane >= 1 && lane <= 62 && p < 34 * 18 && xq >= 1 && xq <= 16) DU[(i * 34 + y) * 24 + xq - 1] = h;
                 }
             }
         }
         __syncthreads();
-        // (8) transpose of the bilinear x2: each pred_img pixel gathers the <= 4x4 du values whose footprint touches it; the
-        // 4 + 4 row / column weights do not depend on the channel
+        // (8) the vertical half: pred row y' gathers .25 H[2y'-1] + wa H[2y'] + wb H[2y'+1] + .25 H[2y'+2] (rows outside the image hold 0)
         {
             const int y = ty * PT + py, x = tx * PT + px;
-            float wyv[4], wxv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int Y = 2 * y - 1 + k, X = 2 * x - 1 + k;
-                int q0, q1;
-                float w0, w1;
-                wyv[k] = 0.f;
-                wxv[k] = 0.f;
-                if (Y >= 0 && Y < R2) {
-                    up2_taps(Y, R, q0, q1, w0, w1);
-                    wyv[k] = (q0 == y ? w0 : 0.f) + (q1 == y ? w1 : 0.f);
-                }
-                if (X >= 0 && X < R2) {
-                    up2_taps(X, R, q0, q1, w0, w1);
-                    wxv[k] = (q0 == x ? w0 : 0.f) + (q1 == x ? w1 : 0.f);
-                }
-            }
-            const int yb = 2 * py, xb = 2 * px + 1;   // DU coordinates of (2y-1, 2x-1): (Y - Y0 + 1, X - X0 + 2)
+            const float wa = y == 0 ? 1.0f : 0.75f, wb = y == R - 1 ? 1.0f : 0.75f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float acc = 0.f;
-#pragma unroll
-                for (int ky = 0; ky < 4; ++ky) {
-                    float rowv = 0.f;
-#pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) rowv += wxv[kx] * DU[(c * 34 + yb + ky) * 36 + xb + kx];
-                    acc += wyv[ky] * rowv;
-                }
-                dsr[((b * 3 + c) * (long)R + y) * R + x] = acc;
+                const float* h = DU + (c * 34 + 2 * py) * 24 + px;   // H row of hi-res row 2y'-1
+                dsr[((b * 3 + c) * (long)R + y) * R + x] = 0.25f * (h[0] + h[72]) + wa * h[24] + wb * h[48];
             }
         }
-        t = tn;
+        cur = nxt;
     }
 #undef SR_TAPS
     // the workgroup's 168 sums: blocks of a wave by shuffles (lanes with the same lane & 3), waves through LDS, then one atomic per
@@ -1653,6 +1648,7 @@ extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64
     ECAMP_CHECK_ARG(mode == 0 || mode == 1, "sr_bwd: mode must be 0 (f32 VALU) or 1 (bf16 matrix cores)");
     SrP W = {w1, b1, w2, b2};
     long tiles = B * (2 * R / SRT) * (2 * R / SRT);
+    ECAMP_CHECK_ARG(tiles < (1L << 30), "sr_bwd: too many tiles");
     int nb = (int)(tiles < 1024 ? tiles : 1024);
     size_t shm = (size_t)(3 * (42 * 42 + 40 * 40 + 38 * 38 + 36 * 36)) * sizeof(float);
     static bool once = false;
