@@ -1510,20 +1510,27 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
         __syncthreads();
         // (6) weight gradients over the 32 x 32 centre: conv2 from (ds, c1), conv1 from (dc1, u).  Lane l of a group of 64 pixels
         // (two rows) names pixel l; after the transpose read lane (block, ch) holds channel ch of the block's four pixels.
+        // A wave's four groups are stacked (rows 8w .. 8w+7): the operands of kernel row 2 of one group are those of kernel row 0 of the next
+        {
+            bf16x4_t k2[3], k1[3];   // kernel-row-0 operands of the coming group (c1 / u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int y = 2 * (wave * 4 + j) + (lane >> 5), x = lane & 31;
-            const bf16x4_t A2 = sr_tr(DS16 + ((y + 3) * 40 + x + 4) * 8);
-            const bf16x4_t A1 = sr_tr(DC16 + ((y + 2) * 38 + x + 3) * 8);
-            gb2 = MFMA4(A2, ones, gb2);
-            gb1 = MFMA4(A1, ones, gb1);
-            const unsigned char* cb = C16 + ((y + 3) * 42 + x + 4) * 8;   // tap (ky, kx) reads centre + (ky - 1, kx - 1)
-            const unsigned char* ub = U16 + ((y + 5) * 44 + x + 5) * 8;
+            for (int j = 0; j < 4; ++j) {
+                const int y = 2 * (wave * 4 + j) + (lane >> 5), x = lane & 31;
+                const bf16x4_t A2 = sr_tr(DS16 + ((y + 3) * 40 + x + 4) * 8);
+                const bf16x4_t A1 = sr_tr(DC16 + ((y + 2) * 38 + x + 3) * 8);
+                gb2 = MFMA4(A2, ones, gb2);
+                gb1 = MFMA4(A1, ones, gb1);
+                const unsigned char* cb = C16 + ((y + 3) * 42 + x + 4) * 8;   // tap (ky, kx) reads centre + (ky - 1, kx - 1)
+                const unsigned char* ub = U16 + ((y + 5) * 44 + x + 5) * 8;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const int ky = q / 3, kx = q % 3;
-                G2[q] = MFMA4(A2, sr_tr(cb + (ky * 42 + kx) * 8), G2[q]);
-                G1[q] = MFMA4(A1, sr_tr(ub + (ky * 44 + kx) * 8), G1[q]);
+                for (int q = 0; q < 9; ++q) {
+                    const int ky = q / 3, kx = q % 3;
+                    const bf16x4_t B2 = (ky == 0 && j > 0) ? k2[kx] : sr_tr(cb + (ky * 42 + kx) * 8);
+                    const bf16x4_t B1 = (ky == 0 && j > 0) ? k1[kx] : sr_tr(ub + (ky * 44 + kx) * 8);
+                    G2[q] = MFMA4(A2, B2, G2[q]);
+                    G1[q] = MFMA4(A1, B1, G1[q]);
+                    if (ky == 2) { k2[kx] = B2; k1[kx] = B1; }
+                }
             }
         }
         // (7) du = ds + conv1^T(dc1) on rows -1..32, column pairs from -2 (0 outside the image), and at once the horizontal half of
