@@ -577,101 +577,6 @@ __device__ __forceinline__ void sr_load_taps(const float* __restrict__ w, int la
         a[t] = sr_pack4(v[0], v[1], v[2]);
     }
 }
-// 3x3 stencil of one pixel per lane over a channel-interleaved tile of edge ES; FLIP reads (y+2-ky, x+2-kx) (transposed conv)
-template <int ES, bool FLIP>
-__device__ __forceinline__ f32x4_t sr_mfma_conv(const unsigned char* tile, int y, int x, const bf16x4_t (&a)[9]) {
-    f32x4_t acc[3];   // one accumulator per kernel row: three independent MFMA chains instead of one of nine
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        acc[ky] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int yy = FLIP ? y + 2 - ky : y + ky, xx = FLIP ? x + 2 - kx : x + kx;
-            const bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(tile + (yy * ES + xx) * 8);
-            acc[ky] = MFMA4(a[ky * 3 + kx], b, acc[ky]);
-        }
-    }
-    return acc[0] + acc[1] + acc[2];
-}
-
-__global__ __launch_bounds__(256) void sr_mfma_fwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
-                                                          const long* __restrict__ column, const long* __restrict__ row, SrP P,
-                                                          float* __restrict__ loss_sum, long B, int R, int win) {
-    __shared__ __attribute__((aligned(16))) unsigned char U16[36 * 36 * 8];   // u, halo 2
-    __shared__ __attribute__((aligned(16))) unsigned char C16[34 * 34 * 8];   // c1, halo 1
-    __shared__ float PP[3 * 20 * 20];                                          // pred_img patch (rows/cols Y0/2-2 .. Y0/2+17, clamped)
-    __shared__ float UC[3 * 32 * 32];                                          // u on the tile itself in f32 (skip connection)
-    __shared__ float sh[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bf16x4_t a1[9], a2[9];
-    sr_load_taps<false>(P.w1, lane, a1);
-    sr_load_taps<false>(P.w2, lane, a2);
-    const float b1[3] = {P.b1[0], P.b1[1], P.b1[2]}, b2[3] = {P.b2[0], P.b2[1], P.b2[2]};
-    const int R2 = 2 * R, G = R2 / SRT;
-    float part = 0.f;
-    for (long t = blockIdx.x; t < B * G * G; t += gridDim.x) {
-        const long b = t / (G * G);
-        const int ty = (int)((t / G) % G), tx = (int)(t % G);
-        const int c0 = (int)column[b], r0 = (int)row[b];
-        if (ty < c0 || ty >= c0 + win || tx < r0 || tx >= r0 + win) continue;  // block-uniform
-        const int Y0 = ty * SRT, X0 = tx * SRT;
-        const int ylo = Y0 / 2 - 2, xlo = X0 / 2 - 2;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 3 * 400; idx += 256) {
-            int c = idx / 400, yy = (idx / 20) % 20, xx = idx % 20;
-            int y = min(max(ylo + yy, 0), R - 1), x = min(max(xlo + xx, 0), R - 1);
-            PP[idx] = pred_img[((b * 3 + c) * (long)R + y) * R + x];
-        }
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 36 * 36; idx += 256) {       // u on halo 2 from the patch
-            const int y = idx / 36, x = idx % 36;
-            const int Y = Y0 - 2 + y, X = X0 - 2 + x;
-            float u[3] = {0.f, 0.f, 0.f};
-            if (Y >= 0 && Y < R2 && X >= 0 && X < R2) {
-                int y0, y1, x0, x1;
-                float wy0, wy1, wx0, wx1;
-                up2_taps(Y, R, y0, y1, wy0, wy1);
-                up2_taps(X, R, x0, x1, wx0, wx1);
-                y0 -= ylo; y1 -= ylo; x0 -= xlo; x1 -= xlo;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float* pl = PP + c * 400;
-                    u[c] = wy0 * (wx0 * pl[y0 * 20 + x0] + wx1 * pl[y0 * 20 + x1]) + wy1 * (wx0 * pl[y1 * 20 + x0] + wx1 * pl[y1 * 20 + x1]);
-                }
-            }
-            *reinterpret_cast<bf16x4_t*>(U16 + idx * 8) = sr_pack4(u[0], u[1], u[2]);
-            if (y >= 2 && y < 34 && x >= 2 && x < 34) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) UC[(c * 32 + y - 2) * 32 + x - 2] = u[c];
-            }
-        }
-        __syncthreads();
-        for (int g = wave; g < (34 * 34 + 63) / 64; g += 4) {             // c1 = relu(conv1(u) + b1) on halo 1, 0 outside the image
-            const int p = g * 64 + lane, pc = min(p, 34 * 34 - 1);
-            const int y = pc / 34, x = pc % 34;
-            const f32x4_t acc = sr_mfma_conv<36, false>(U16, y, x, a1);
-            const int Y = Y0 - 1 + y, X = X0 - 1 + x;
-            const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
-            if (p < 34 * 34)
-                *reinterpret_cast<bf16x4_t*>(C16 + p * 8) = in ? sr_pack4(fmaxf(acc[0] + b1[0], 0.f), fmaxf(acc[1] + b1[1], 0.f), fmaxf(acc[2] + b1[2], 0.f))
-                                                               : sr_pack4(0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-        for (int g = wave; g < 16; g += 4) {                               // s = relu(conv2(c1) + b2 + u); loss
-            const int p = g * 64 + lane, y = p >> 5, x = p & 31;
-            const f32x4_t acc = sr_mfma_conv<34, false>(C16, y, x, a2);
-#pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                float sv = fmaxf(acc[o] + b2[o] + UC[(o * 32 + y) * 32 + x], 0.f);
-                float d = sv - big[((b * 3 + o) * (long)R2 + Y0 + y) * R2 + X0 + x];
-                part += d * d;
-            }
-        }
-    }
-    part = block_sum_256(part, sh);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, part);
-}
-
 // block-level reduction of NV per-thread partials into global f32 (one atomic per value per block)
 template <int NV>
 __device__ __forceinline__ void reduce_to_global(float (&v)[NV], float* __restrict__ out, float* sh /* [4][NV] */) {
@@ -931,322 +836,14 @@ __global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __res
     }
 }
 
-// backward on the matrix cores: the four stencils (conv1, conv2, conv2^T, conv1^T) as in sr_mfma_fwd_kernel; the weight-gradient
-// stage keeps the tap-split f32 accumulation of sr_fused_bwd_kernel, reading the bf16 tiles.  ds / dc1 are rounded to bf16.
 __device__ __forceinline__ void sr_unpack3(uint2 q, float (&v)[3]) {   // the three channels of an interleaved bf16 pixel as f32
     v[0] = __uint_as_float(q.x << 16);
     v[1] = __uint_as_float(q.x & 0xffff0000u);
     v[2] = __uint_as_float(q.y << 16);
 }
-__global__ __launch_bounds__(256, 2) void sr_mfma_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
-                                                             const long* __restrict__ column, const long* __restrict__ row, SrP P,
-                                                             float* __restrict__ dsr, float* __restrict__ gw, long B, int R, int win) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
-    unsigned char* U16 = smem8;                          // 42 x 42 x 8 B  (halo 5)
-    unsigned char* C16 = U16 + 42 * 42 * 8;              // 40 x 40 x 8 B  (halo 4)
-    unsigned char* DS16 = C16 + 40 * 40 * 8;             // 38 x 38 x 8 B  (halo 3)
-    unsigned char* DC16 = DS16 + 38 * 38 * 8;            // 36 x 36 x 8 B  (halo 2)
-    float* DU = reinterpret_cast<float*>(DC16 + 36 * 36 * 8);   // 3 x 34 x 34 f32 (halo 1); first holds the 3 x 24 x 24 pred_img patch
-    float* PP = DU;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // the four tap sets (conv1, conv2, conv2^T, conv1^T) x 9 taps x 4 operand rows live in LDS and are fetched per stage: holding
-    // all of them in registers (72 VGPRs) next to the 42 weight-gradient accumulators spilled
-    __shared__ bf16x4_t TAPS[4][9][4];
-    if (threadIdx.x < 144) {
-        const int c = threadIdx.x / 36, t = (threadIdx.x / 4) % 9, i = threadIdx.x & 3;
-        const float* w = (c == 0 || c == 3) ? P.w1 : P.w2;
-        const bool trans = c >= 2;
-        float v[3] = {0.f, 0.f, 0.f};
-        if (i < 3) {
-            for (int kk = 0; kk < 3; ++kk) v[kk] = trans ? w[(kk * 3 + i) * 9 + t] : w[(i * 3 + kk) * 9 + t];
-        }
-        TAPS[c][t][i] = sr_pack4(v[0], v[1], v[2]);
-    }
-#define SR_TAPS(NAME, C)                                                     \
-    bf16x4_t NAME[9];                                                        \
-    _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) NAME[t_] = TAPS[(C)][t_][lane & 3]
-    const float b1[3] = {P.b1[0], P.b1[1], P.b1[2]}, b2[3] = {P.b2[0], P.b2[1], P.b2[2]};
-    const int R2 = 2 * R, G = R2 / SRT, PT = SRT / 2;
-    const long T = B * G * G;
-    // weight gradients: a wave owns 2-3 of the 9 stencil positions q = ky*3+kx with all 3 input channels of each, so that one 8-B
-    // LDS read (an interleaved pixel) feeds 3 taps x 3 outputs (per-tap 2-B reads made this stage a third of the kernel)
-    const int q0 = wave == 0 ? 0 : 1 + 2 * wave, npos = wave == 0 ? 3 : 2;
-    int offu[3], offc[3];   // byte offsets of position q0+k relative to the tap-(0,0) pixel in the U (42-wide) / C1 (40-wide) tiles
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int q = min(q0 + k, 8), ky = q / 3, kx = q % 3;
-        offu[k] = (ky * 42 + kx) * 8;
-        offc[k] = (ky * 40 + kx) * 8;
-    }
-    float g1[3][3][3], g2[3][3][3], bb1[3], bb2[3];   // [position][input channel][output channel]
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int o = 0; o < 3; ++o) g1[k][i][o] = g2[k][i][o] = 0.f;
-#pragma unroll
-    for (int o = 0; o < 3; ++o) bb1[o] = bb2[o] = 0.f;
-    const int py = threadIdx.x / PT, px = threadIdx.x % PT;  // this thread's pred_img pixel of a 16x16 tile
-
-    // Tiles are software-pipelined: the pred_img patch and the `big` values of the NEXT reachable tile are requested while the
-    // current one is computed (a tile is otherwise two dependent global round trips at 2 workgroups per CU: 0.9 of 3.2 ms).
-    // next reachable tile at or after t; tiles with no window pixel within reach get a zero gradient on the way
-    auto advance = [&](long t) {
-        for (; t < T; t += gridDim.x) {
-            const long b = t / (G * G);
-            const int ty = (int)((t / G) % G), tx = (int)(t % G);
-            const int c0 = (int)column[b], r0 = (int)row[b];
-            if (!(ty < c0 - 1 || ty > c0 + win || tx < r0 - 1 || tx > r0 + win)) break;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dsr[((b * 3 + c) * (long)R + ty * PT + py) * R + tx * PT + px] = 0.f;
-        }
-        return t;
-    };
-    float pp[7], bigv[6][3];
-    bool inw[6];
-    auto fetch_patch = [&](long t) {
-        const long b = t / (G * G);
-        const int ylo = (int)((t / G) % G) * (SRT / 2) - 4, xlo = (int)(t % G) * (SRT / 2) - 4;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int idx = threadIdx.x + 256 * k;
-            const int c = idx / 576, yy = (idx / 24) % 24, xx = idx % 24;
-            const int y = min(max(ylo + yy, 0), R - 1), x = min(max(xlo + xx, 0), R - 1);
-            pp[k] = idx < 3 * 576 ? pred_img[((b * 3 + c) * (long)R + y) * R + x] : 0.f;
-        }
-    };
-    auto fetch_big = [&](long t) {   // pixel (wave + 4j)*64 + lane of the 38 x 38 halo-3 region
-        const long b = t / (G * G);
-        const int Y0 = (int)((t / G) % G) * SRT, X0 = (int)(t % G) * SRT;
-        const int c0 = (int)column[b], r0 = (int)row[b];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int p = (wave + 4 * j) * 64 + lane;
-            const int y = p / 38, x = p % 38;
-            const int Y = Y0 - 3 + y, X = X0 - 3 + x;
-            bool in = p < 38 * 38 && Y >= 0 && Y < R2 && X >= 0 && X < R2;
-            if (in) {
-                int gy = Y / SRT, gx = X / SRT;
-                in = gy >= c0 && gy < c0 + win && gx >= r0 && gx < r0 + win;
-            }
-            inw[j] = in;
-#pragma unroll
-            for (int o = 0; o < 3; ++o) bigv[j][o] = in ? big[((b * 3 + o) * (long)R2 + Y) * R2 + X] : 0.f;
-        }
-    };
-    long t = advance(blockIdx.x);
-    if (t < T) {
-        fetch_patch(t);
-        fetch_big(t);
-    }
-    while (t < T) {
-        const long b = t / (G * G);
-        const int ty = (int)((t / G) % G), tx = (int)(t % G);
-        const int Y0 = ty * SRT, X0 = tx * SRT;
-        const int ylo = Y0 / 2 - 4, xlo = X0 / 2 - 4;
-        __syncthreads();   // the previous tile's stage 8 is done with DU (= the patch buffer)
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int idx = threadIdx.x + 256 * k;
-            if (idx < 3 * 576) PP[idx] = pp[k];
-        }
-        const long tn = advance(t + gridDim.x);
-        if (tn < T) fetch_patch(tn);          // in flight until the next iteration
-        __syncthreads();
-        // (2) u on halo 5
-        for (int idx = threadIdx.x; idx < 42 * 42; idx += 256) {
-            const int y = idx / 42, x = idx % 42;
-            const int Y = Y0 - 5 + y, X = X0 - 5 + x;
-            float u[3] = {0.f, 0.f, 0.f};
-            if (Y >= 0 && Y < R2 && X >= 0 && X < R2) {
-                int y0, y1, x0, x1;
-                float wy0, wy1, wx0, wx1;
-                up2_taps(Y, R, y0, y1, wy0, wy1);
-                up2_taps(X, R, x0, x1, wx0, wx1);
-                y0 -= ylo; y1 -= ylo; x0 -= xlo; x1 -= xlo;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float* pl = PP + c * 576;
-                    u[c] = wy0 * (wx0 * pl[y0 * 24 + x0] + wx1 * pl[y0 * 24 + x1]) + wy1 * (wx0 * pl[y1 * 24 + x0] + wx1 * pl[y1 * 24 + x1]);
-                }
-            }
-            *reinterpret_cast<bf16x4_t*>(U16 + idx * 8) = sr_pack4(u[0], u[1], u[2]);
-        }
-        __syncthreads();
-        // (3) c1 on halo 4
-        {
-            SR_TAPS(a1, 0);
-            for (int g = wave; g < (40 * 40 + 63) / 64; g += 4) {
-                const int p = g * 64 + lane, pc = min(p, 40 * 40 - 1);
-                const int y = pc / 40, x = pc % 40;
-                const f32x4_t acc = sr_mfma_conv<42, false>(U16, y, x, a1);
-                const int Y = Y0 - 4 + y, X = X0 - 4 + x;
-                const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
-                if (p < 40 * 40)
-                    *reinterpret_cast<bf16x4_t*>(C16 + p * 8) = in ? sr_pack4(fmaxf(acc[0] + b1[0], 0.f), fmaxf(acc[1] + b1[1], 0.f), fmaxf(acc[2] + b1[2], 0.f))
-                                                                   : sr_pack4(0.f, 0.f, 0.f);
-            }
-        }
-        __syncthreads();
-        // (4) ds on halo 3: [pixel in window] * (s - big) * [s > 0]
-        {
-            SR_TAPS(a2, 1);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int g = wave + 4 * j;
-                if (g < (38 * 38 + 63) / 64) {   // wave-uniform
-                    const int p = g * 64 + lane, pc = min(p, 38 * 38 - 1);
-                    const int y = pc / 38, x = pc % 38;
-                    const f32x4_t acc = sr_mfma_conv<40, false>(C16, y, x, a2);
-                    float d[3] = {0.f, 0.f, 0.f};
-                    if (inw[j]) {
-                        float uu[3];
-                        sr_unpack3(*reinterpret_cast<const uint2*>(U16 + ((y + 2) * 42 + x + 2) * 8), uu);
-#pragma unroll
-                        for (int o = 0; o < 3; ++o) {
-                            float sv = fmaxf(acc[o] + b2[o] + uu[o], 0.f);
-                            d[o] = sv > 0.f ? sv - bigv[j][o] : 0.f;
-                        }
-                    }
-                    if (p < 38 * 38) *reinterpret_cast<bf16x4_t*>(DS16 + p * 8) = sr_pack4(d[0], d[1], d[2]);
-                }
-            }
-        }
-        if (tn < T) fetch_big(tn);            // bigv / inw are free again: request the next tile's targets
-        __syncthreads();
-        // (5) dc1 on halo 2 = [c1 > 0] * conv2^T(ds)
-        {
-            SR_TAPS(a2t, 2);
-            for (int g = wave; g < (36 * 36 + 63) / 64; g += 4) {
-                const int p = g * 64 + lane, pc = min(p, 36 * 36 - 1);
-                const int y = pc / 36, x = pc % 36;
-                const f32x4_t acc = sr_mfma_conv<38, true>(DS16, y, x, a2t);
-                const int Y = Y0 - 2 + y, X = X0 - 2 + x;
-                const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
-                float d[3], cc[3];
-                sr_unpack3(*reinterpret_cast<const uint2*>(C16 + ((y + 2) * 40 + x + 2) * 8), cc);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) d[i] = (in && cc[i] > 0.f) ? acc[i] : 0.f;
-                if (p < 36 * 36) *reinterpret_cast<bf16x4_t*>(DC16 + p * 8) = sr_pack4(d[0], d[1], d[2]);
-            }
-        }
-        __syncthreads();
-        // (6) weight gradients over the 32x32 centre: conv2 from (ds, c1), conv1 from (dc1, u)
-#pragma unroll 2
-        for (int j = 0; j < 16; ++j) {
-            const int idx = lane + 64 * j;
-            const int y = idx >> 5, x = idx & 31;
-            float d2[3], d1[3];
-            sr_unpack3(*reinterpret_cast<const uint2*>(DS16 + ((y + 3) * 38 + x + 3) * 8), d2);
-            sr_unpack3(*reinterpret_cast<const uint2*>(DC16 + ((y + 2) * 36 + x + 2) * 8), d1);
-            const unsigned char* c1p = C16 + ((y + 3) * 40 + x + 3) * 8;   // position (ky,kx) reads centre + (ky-1, kx-1)
-            const unsigned char* up = U16 + ((y + 4) * 42 + x + 4) * 8;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (k < npos) {   // wave-uniform
-                    float v2[3], v1[3];
-                    sr_unpack3(*reinterpret_cast<const uint2*>(c1p + offc[k]), v2);
-                    sr_unpack3(*reinterpret_cast<const uint2*>(up + offu[k]), v1);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int o = 0; o < 3; ++o) {
-                            g2[k][i][o] += d2[o] * v2[i];
-                            g1[k][i][o] += d1[o] * v1[i];
-                        }
-                }
-            }
-            if (wave == 3) {
-#pragma unroll
-                for (int o = 0; o < 3; ++o) {
-                    bb2[o] += d2[o];
-                    bb1[o] += d1[o];
-                }
-            }
-        }
-        __syncthreads();
-        // (7) du on halo 1 (f32, planar) = ds + conv1^T(dc1)
-        {
-            SR_TAPS(a1t, 3);
-            for (int g = wave; g < (34 * 34 + 63) / 64; g += 4) {
-                const int p = g * 64 + lane, pc = min(p, 34 * 34 - 1);
-                const int y = pc / 34, x = pc % 34;
-                const f32x4_t acc = sr_mfma_conv<36, true>(DC16, y, x, a1t);
-                const int Y = Y0 - 1 + y, X = X0 - 1 + x;
-                const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
-                if (p < 34 * 34) {
-                    float dd[3];
-                    sr_unpack3(*reinterpret_cast<const uint2*>(DS16 + ((y + 2) * 38 + x + 2) * 8), dd);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) DU[(i * 34 + y) * 34 + x] = in ? acc[i] + dd[i] : 0.f;
-                }
-            }
-        }
-        __syncthreads();
-        // (8) transpose of the bilinear x2: each pred_img pixel gathers the <= 4x4 du values whose footprint touches it; the
-        // 4 + 4 row / column weights do not depend on the channel
-        {
-            const int y = ty * PT + py, x = tx * PT + px;
-            float wyv[4], wxv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int Y = 2 * y - 1 + k, X = 2 * x - 1 + k;
-                int q0, q1;
-                float w0, w1;
-                wyv[k] = 0.f;
-                wxv[k] = 0.f;
-                if (Y >= 0 && Y < R2) {
-                    up2_taps(Y, R, q0, q1, w0, w1);
-                    wyv[k] = (q0 == y ? w0 : 0.f) + (q1 == y ? w1 : 0.f);
-                }
-                if (X >= 0 && X < R2) {
-                    up2_taps(X, R, q0, q1, w0, w1);
-                    wxv[k] = (q0 == x ? w0 : 0.f) + (q1 == x ? w1 : 0.f);
-                }
-            }
-            const int yb = 2 * py, xb = 2 * px;   // DU coordinates of (2y-1, 2x-1): (Y - Y0 + 1, X - X0 + 1)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float acc = 0.f;
-#pragma unroll
-                for (int ky = 0; ky < 4; ++ky) {
-                    float rowv = 0.f;
-#pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) rowv += wxv[kx] * DU[(c * 34 + yb + ky) * 34 + xb + kx];
-                    acc += wyv[ky] * rowv;
-                }
-                dsr[((b * 3 + c) * (long)R + y) * R + x] = acc;
-            }
-        }
-        t = tn;
-    }
-#undef SR_TAPS
-    // one cross-lane reduction per kernel: gw layout {dW1[81], db1[3], dW2[81], db2[3]}, dW[o][i][ky][kx] = index o*27 + tap
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                float s1 = wave_sum(g1[k][i][o]), s2 = wave_sum(g2[k][i][o]);
-                if (lane == 0 && k < npos) {
-                    atomicAdd(gw + o * 27 + i * 9 + q0 + k, s1);
-                    atomicAdd(gw + 84 + o * 27 + i * 9 + q0 + k, s2);
-                }
-            }
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        float s1 = wave_sum(bb1[o]), s2 = wave_sum(bb2[o]);
-        if (lane == 0 && wave == 3) {
-            atomicAdd(gw + 81 + o, s1);
-            atomicAdd(gw + 84 + 81 + o, s2);
-        }
-    }
-}
 
 // ---- backward on the matrix cores, pixel-PAIR form (the production kernel of compute_dtype = bf16) ---------------------------------
-// Same eight stages as sr_mfma_bwd_kernel; what changed is what a lane does per instruction:
+// The eight stages of sr_fused_bwd_kernel on bf16 tiles; what a lane does per instruction:
 //  * a lane convolves TWO horizontally adjacent pixels: the 4 x 3 input pixels they share are six 16-B LDS reads (48 B per output
 //    pixel instead of 72, a third of the read instructions).  For the reads to be 16-B aligned the tiles alternate their column
 //    origin: u at -6 (even), c1 at -5 (pairs start on odd columns), ds at -4, dc1 at -3, du at -2 -- every stage computes one spare
@@ -1290,6 +887,109 @@ __device__ __forceinline__ void sr_pair_conv(const unsigned char* p, const bf16x
     oA = a0 + a1;
     oB = b0 + b1;
 }
+// forward in the same pixel-pair form: u on rows / cols -2..33 from 2 x 2 blocks, c1 on rows -1..32 with column pairs from -1,
+// s on the tile with column pairs from 0.  The skip connection and the loss stay f32.
+__global__ __launch_bounds__(256) void sr_pair_fwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+                                                          const long* __restrict__ column, const long* __restrict__ row, SrP P,
+                                                          float* __restrict__ loss_sum, long B, int R, int win) {
+    __shared__ __attribute__((aligned(16))) unsigned char U16[36 * 36 * 8];   // u, rows / cols -2..33
+    __shared__ __attribute__((aligned(16))) unsigned char C16[34 * 34 * 8];   // c1, rows / cols -1..32
+    __shared__ __attribute__((aligned(16))) float UC[3 * 32 * 32];            // u on the tile itself in f32 (skip connection)
+    __shared__ float PP[3 * 20 * 20];                                          // pred_img patch (rows/cols Y0/2-2 .. Y0/2+17, clamped)
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16x4_t a1[9], a2[9];
+    sr_load_taps<false>(P.w1, lane, a1);
+    sr_load_taps<false>(P.w2, lane, a2);
+    const f32x4_t bias1 = {P.b1[0], P.b1[1], P.b1[2], 0.f}, bias2 = {P.b2[0], P.b2[1], P.b2[2], 0.f};
+    const int R2 = 2 * R, G = R2 / SRT, GG = G * G, NT = (int)(B * GG);
+    float part = 0.f;
+    for (int t = blockIdx.x; t < NT; t += gridDim.x) {
+        const int b = t / GG, ty = (t - b * GG) / G, tx = t - b * GG - ty * G;
+        const int c0 = (int)column[b], r0 = (int)row[b];
+        if (ty < c0 || ty >= c0 + win || tx < r0 || tx >= r0 + win) continue;  // block-uniform
+        const int Y0 = ty * SRT, X0 = tx * SRT;
+        const int ylo = Y0 / 2 - 2, xlo = X0 / 2 - 2;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 3 * 400; idx += 256) {
+            const int c = idx / 400, yy = (idx / 20) % 20, xx = idx % 20;
+            const int y = min(max(ylo + yy, 0), R - 1), x = min(max(xlo + xx, 0), R - 1);
+            PP[idx] = pred_img[((b * 3 + c) * (long)R + y) * R + x];
+        }
+        __syncthreads();
+        for (int id = threadIdx.x; id < 18 * 18; id += 256) {       // u in 2 x 2 blocks (see sr_pair_bwd_kernel)
+            const int by = id / 18, bx = id - by * 18;
+            float o[3][2][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* pl = PP + c * 400 + by * 20 + bx;
+                float he[3], ho[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float v0 = pl[r * 20], v1 = pl[r * 20 + 1], v2 = pl[r * 20 + 2];
+                    he[r] = 0.25f * v0 + 0.75f * v1;
+                    ho[r] = 0.75f * v1 + 0.25f * v2;
+                }
+                o[c][0][0] = 0.25f * he[0] + 0.75f * he[1];
+                o[c][0][1] = 0.25f * ho[0] + 0.75f * ho[1];
+                o[c][1][0] = 0.75f * he[1] + 0.25f * he[2];
+                o[c][1][1] = 0.75f * ho[1] + 0.25f * ho[2];
+            }
+            const int Y = Y0 - 2 + 2 * by, X = X0 - 2 + 2 * bx;       // both even: a block is inside or outside the image as a whole
+            const bool in = Y >= 0 && Y < R2 && X >= 0 && X < R2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                u32x4_t q;
+                q[0] = in ? pack_bf16x2(o[0][e][0], o[1][e][0]) : 0u;
+                q[1] = in ? pack_bf16x2(o[2][e][0], 0.f) : 0u;
+                q[2] = in ? pack_bf16x2(o[0][e][1], o[1][e][1]) : 0u;
+                q[3] = in ? pack_bf16x2(o[2][e][1], 0.f) : 0u;
+                *reinterpret_cast<u32x4_t*>(U16 + ((2 * by + e) * 36 + 2 * bx) * 8) = q;
+            }
+            if (by >= 1 && by <= 16 && bx >= 1 && bx <= 16) {       // the tile itself (always inside the image)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        *reinterpret_cast<float2*>(UC + (c * 32 + 2 * by - 2 + e) * 32 + 2 * bx - 2) = make_float2(o[c][e][0], o[c][e][1]);
+            }
+        }
+        __syncthreads();
+        for (int g = wave; g < (34 * 17 + 63) / 64; g += 4) {         // c1 = relu(conv1(u) + b1), 0 outside the image
+            const int p = g * 64 + lane, pc = min(p, 34 * 17 - 1);
+            const int y = pc / 17, xq = pc - y * 17;
+            f32x4_t oA, oB;
+            sr_pair_conv<36, false>(U16 + (y * 36 + 2 * xq) * 8, a1, bias1, oA, oB);
+            const int Y = Y0 - 1 + y, X = X0 - 1 + 2 * xq;
+            const bool iy = Y >= 0 && Y < R2, inA = iy && X >= 0 && X < R2, inB = iy && X + 1 >= 0 && X + 1 < R2;
+            u32x4_t q;
+            q[0] = inA ? pack_bf16x2(fmaxf(oA[0], 0.f), fmaxf(oA[1], 0.f)) : 0u;
+            q[1] = inA ? pack_bf16x2(fmaxf(oA[2], 0.f), 0.f) : 0u;
+            q[2] = inB ? pack_bf16x2(fmaxf(oB[0], 0.f), fmaxf(oB[1], 0.f)) : 0u;
+            q[3] = inB ? pack_bf16x2(fmaxf(oB[2], 0.f), 0.f) : 0u;
+            if (p < 34 * 17) *reinterpret_cast<u32x4_t*>(C16 + (y * 34 + 2 * xq) * 8) = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                                  // s = relu(conv2(c1) + b2 + u); loss
+            const int p = (wave + 4 * j) * 64 + lane, y = p >> 4, xq = p & 15;
+            float2 bg[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) bg[o] = *reinterpret_cast<const float2*>(big + ((b * 3 + o) * (long)R2 + Y0 + y) * R2 + X0 + 2 * xq);
+            f32x4_t oA, oB;
+            sr_pair_conv<34, false>(C16 + (y * 34 + 2 * xq) * 8, a2, bias2, oA, oB);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float2 uu = *reinterpret_cast<const float2*>(UC + (o * 32 + y) * 32 + 2 * xq);
+                const float dA = fmaxf(oA[o] + uu.x, 0.f) - bg[o].x, dB = fmaxf(oB[o] + uu.y, 0.f) - bg[o].y;
+                part += dA * dA + dB * dB;
+            }
+        }
+    }
+    part = block_sum_256(part, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, part);
+}
+
 #define SRP_LDS_BYTES (44 * 44 * 8 + 40 * 42 * 8 + 38 * 40 * 8 + 36 * 38 * 8 + 3 * 34 * 36 * 4 + 4 * 9 * 4 * 8)
 __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
                                                              const long* __restrict__ column, const long* __restrict__ row, SrP P,
@@ -1617,7 +1317,7 @@ extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64
     long tiles = B * (2 * R / SRT) * (2 * R / SRT);
     int nb = (int)(tiles < 2048 ? tiles : 2048);
     if (mode == 1)
-        hipLaunchKernelGGL(sr_mfma_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
+        hipLaunchKernelGGL(sr_pair_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
                            (long)B, R, window);
     else
         hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
@@ -1664,29 +1364,15 @@ extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64
         once = true;
     }
     if (mode == 1) {
-        static int variant = -1, nbp = 0;   // ECAMP_SR_BWD=old selects the single-pixel kernel (A/B runs); ECAMP_SR_BLOCKS overrides the grid
-        if (variant < 0) {
-            const char* e = getenv("ECAMP_SR_BWD");
-            variant = (e && !strcmp(e, "old")) ? 0 : 1;
-            const char* nbe = getenv("ECAMP_SR_BLOCKS");
-            nbp = nbe ? atoi(nbe) : 512;            // two resident workgroups per CU
+        static int nbp = 0;
+        if (nbp == 0) {
+            const char* nbe = getenv("ECAMP_SR_BLOCKS");   // development: grid override
+            nbp = nbe && atoi(nbe) > 0 ? atoi(nbe) : 512;  // two resident workgroups per CU
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sr_pair_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SRP_LDS_BYTES);
         }
-        if (variant == 1) {
-            const int nb2 = (int)(tiles < nbp ? tiles : nbp);
-            hipLaunchKernelGGL(sr_pair_bwd_kernel, dim3(nb2), dim3(256), SRP_LDS_BYTES, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr,
-                               gw_ws, (long)B, R, window);
-            ECAMP_LAUNCH_CHECK();
-            return 0;
-        }
-        const size_t shm8 = (size_t)(42 * 42 + 40 * 40 + 38 * 38 + 36 * 36) * 8 + (size_t)3 * 34 * 34 * sizeof(float);
-        static bool once8 = false;
-        if (!once8) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sr_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
-            once8 = true;
-        }
-        hipLaunchKernelGGL(sr_mfma_bwd_kernel, dim3(nb), dim3(256), shm8, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr, gw_ws,
-                           (long)B, R, window);
+        const int nb2 = (int)(tiles < nbp ? tiles : nbp);
+        hipLaunchKernelGGL(sr_pair_bwd_kernel, dim3(nb2), dim3(256), SRP_LDS_BYTES, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr,
+                           gw_ws, (long)B, R, window);
         ECAMP_LAUNCH_CHECK();
         return 0;
     }
