@@ -45,6 +45,7 @@ static __device__ __attribute__((aligned(16))) unsigned int q8_zero16[4] = {0u, 
 struct Q8Item {
     int m0, n0, kbeg, kend, nt, z, ncol;
 };
+template <int MT = 4>
 __device__ __forceinline__ Q8Item q8_decode(const GemmArgs& g, int v, int total) {
     const unsigned f = (unsigned)xcd_remap(v, total), ntile = (unsigned)(g.nbm * g.nbn);
     // grouped order inside a split: 8 M-blocks are walked for one N-block before the next N-block, so the ~32 tiles an XCD works
@@ -54,7 +55,7 @@ __device__ __forceinline__ Q8Item q8_decode(const GemmArgs& g, int v, int total)
     const unsigned gsz = min(8u, (unsigned)g.nbm - first);
     const unsigned nb = in / gsz, mb = first + (in - nb * gsz);
     Q8Item it;
-    it.m0 = (int)mb * 256; it.n0 = (int)nb * 256; it.z = (int)z; it.ncol = (int)nb;
+    it.m0 = (int)mb * (64 * MT); it.n0 = (int)nb * 256; it.z = (int)z; it.ncol = (int)nb;
     it.kbeg = (int)z * g.k_per_split;
     it.kend = min(g.K, it.kbeg + g.k_per_split);
     it.nt = (it.kend - it.kbeg + 63) >> 6;
@@ -146,8 +147,14 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
 // 128 / 256 = nt / sc1 output stores, 512 = workgroups start in four phases 9 us apart (lock-step epilogue bursts: the stagger costs what it saves)
 // ROWSUM (weight-gradient form only): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient -- summed on the VALU from the M-side
 // fragments by the first wave column of the tiles in the first N-tile column, added with 4 buffer atomics per wave and tile.
-template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false>
+// MT: 32-row blocks per wave on the M side.  4: the 256 x 256 tile.  3: a 192 x 256 tile for shapes whose 256-row tiling fills a
+// fraction of a round (12800 x 768: 150 tiles on 256 CUs; 201 tiles of 3/4 the work take 3/4 of the time).  The LDS image, the DMA
+// and the rings do not change: an A half-tile still brings 128 rows, of which a wave row uses the first 96 (half-tile 1 starts
+// 96 rows in; the 32 surplus rows are rows of the other half / the next tile / zeros past M).
+template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false, int MT = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
+    static_assert(MT == 3 || MT == 4, "tile heights: 192 or 256 rows");
+    static_assert(MT == 4 || (A_KC && !ROWSUM), "the 192-row tile is built for contraction-contiguous M-side operands (forward / data-gradient forms)");
     static_assert(!ROWSUM || (!A_KC && !B_KC && EPI == 4), "rowsum is built for the weight-gradient form");
     constexpr int NST = (DBG & 4) ? 0 : Q8Epi<EPI>::NST;   // stores per quadrant (none in the no-epilogue timing variant)
     constexpr int NSLOT = 5;                          // half-tile slots per operand ring
@@ -199,11 +206,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     bool pdone = pv >= total;
     const unsigned char *sa_base, *sb_base;
     int sa_rec, sb_rec, p_krem;
-    const int a_half = A_KC ? (int)g.lda * 256 : 256, a_step = A_KC ? 128 : (int)g.lda * 128;
+    const int a_half = A_KC ? (int)g.lda * (64 * MT) : 64 * MT, a_step = A_KC ? 128 : (int)g.lda * 128;
+    // 192-row tile: an A half-tile's second piece of a wave holds rows 64 + 8*wave ..: only those of waves 0-3 (rows < 96) are used, so
+    // wave row 1 does not request it -- one DMA instruction fewer per A half-tile, which every counted wait of these waves allows for
+    const bool A96 = MT == 3 && wr == 1;
     const int b_half = B_KC ? (int)g.ldb * 256 : 256, b_step = B_KC ? 128 : (int)g.ldb * 128;
 #define Q8_NEXT_ITEM()                                                                                                   \
     do {                                                                                                                 \
-        const Q8Item n_ = q8_decode(g, pv, total);                                                                       \
+        const Q8Item n_ = q8_decode<MT>(g, pv, total);                                                                       \
         p_krem = n_.kend - n_.kbeg;                                                                                      \
         if (A_KC) { sa_base = (const unsigned char*)(A + ((long)n_.m0 * g.lda + n_.kbeg)); sa_rec = (int)((((long)(g.M - n_.m0)) * g.lda - n_.kbeg) * 2); } \
         else      { sa_base = (const unsigned char*)(A + ((long)n_.kbeg * g.lda + n_.m0)); sa_rec = (int)(((long)p_krem * g.lda - n_.m0) * 2); }             \
@@ -221,9 +231,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     do {                                                                                                                 \
         if (!pdone) {                                                                                                    \
             if (!(DBG & 2)) {                                                                                            \
-                if ((PART) == 0) q8_stage_half<A_KC, (PCS)>(sa_base, sa_rec, p_krem, lds + wA * Q8_HALF, voffA, wave, lane);                       \
+                if ((PART) == 0) { if (A96) q8_stage_half<A_KC, (PCS) & 1>(sa_base, sa_rec, p_krem, lds + wA * Q8_HALF, voffA, wave, lane); else q8_stage_half<A_KC, (PCS)>(sa_base, sa_rec, p_krem, lds + wA * Q8_HALF, voffA, wave, lane); } \
                 if ((PART) == 1) q8_stage_half<B_KC, (PCS)>(sb_base, sb_rec, p_krem, lds + (NSLOT + wB) * Q8_HALF, voffB, wave, lane);             \
-                if ((PART) == 2) q8_stage_half<A_KC, (PCS)>(sa_base + a_half, sa_rec - a_half, p_krem, lds + wA * Q8_HALF, voffA, wave, lane);     \
+                if ((PART) == 2) { if (A96) q8_stage_half<A_KC, (PCS) & 1>(sa_base + a_half, sa_rec - a_half, p_krem, lds + wA * Q8_HALF, voffA, wave, lane); else q8_stage_half<A_KC, (PCS)>(sa_base + a_half, sa_rec - a_half, p_krem, lds + wA * Q8_HALF, voffA, wave, lane); } \
                 if ((PART) == 3) q8_stage_half<B_KC, (PCS)>(sb_base + b_half, sb_rec - b_half, p_krem, lds + (NSLOT + wB) * Q8_HALF, voffB, wave, lane); \
             }                                                                                                            \
             if ((PCS) & 2) {                                                                                             \
@@ -242,6 +252,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
 #define Q8_STAGE_PART(PART) Q8_STAGE_PCS(PART, 3)
     // every DMA of mine has landed, except that the `N_` youngest vector-memory operations (issued after it) may be pending
 #define Q8_WAIT_DMA(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
+    // the same with `A_` of the instructions allowed to stay in flight being second pieces of A half-tiles
+#define Q8_WAIT_DMA_A(N_, A_) do { if (A96) Q8_WAIT_DMA((N_) - (A_)); else Q8_WAIT_DMA(N_); } while (0)
 
     Q8Frag<A_KC> xm[4], ym[4];                        // two fragment groups (one k-step of 16 each): 4 M-side + 2 N-side
     Q8Frag<B_KC> xn[2], yn[2];
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     // this lane's 8 contraction values of M-side fragment F summed into S (strided operand: lo/hi halves)
 #define Q8_RS_ACC(FM)                                                                                                    \
     do {                                                                                                                 \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                               \
+        _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_) {                                                              \
             const hw_bf16x8 f_ = FM[t_].get();                                                                           \
             const bf16x8 b_ = __builtin_bit_cast(bf16x8, f_);                                                            \
             _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) rs[t_] += bf2f((bf16_t)b_[e_]);                             \
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
 #define Q8_RD1(FM, FN, SM, SN, KS, I)                                                                                    \
     do {                                                                                                                 \
         constexpr int isn_ = ((I) == 0 || (I) == 3), idx_ = (I) == 0 ? 0 : (I) == 3 ? 1 : (I) < 3 ? (I) - 1 : (I) - 2;   \
-        if (!(DBG & 32)) {                                                                                               \
+        if (!(DBG & 32) && (isn_ || idx_ < MT)) {                                                                        \
             if (isn_) { if (B_KC) FN[idx_].template read<idx_ * 4096>((SN) + offN[KS]); else FN[idx_].template read<(KS) * 4096>((SN) + offN[idx_]); } \
             else      { if (A_KC) FM[idx_].template read<idx_ * 4096>((SM) + offM[KS]); else FM[idx_].template read<(KS) * 4096>((SM) + offM[idx_]); } \
         }                                                                                                                \
@@ -274,7 +286,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
 #define Q8_MFMA1(FM, FN, J, ZERO)                                                                                        \
     do {                                                                                                                 \
         constexpr int q_ = (J) >> 1, mh_ = q_ >> 1, nh_ = (q_ == 1 || q_ == 2) ? 1 : 0, tm_ = 2 * mh_ + ((J) & 1);       \
-        if (DBG & 1) {                                                                                                   \
+        if (tm_ >= MT) {                                                                                                 \
+        } else if (DBG & 1) {                                                                                            \
             asm volatile("" ::"v"(FN[nh_].get()), "v"(FM[tm_].get()));                                                   \
             if (ZERO) acc[tm_][nh_] = zero16;                                                                            \
         } else {                                                                                                         \
@@ -301,12 +314,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     // The accumulators are only READ: the first K tile of the next output tile starts from C = 0 in the MFMA itself.
     auto store_quadrant = [&](int tm0, int tn0, int tz, auto mh_c, auto nh_c) {
         constexpr int MH = decltype(mh_c)::value, NH = decltype(nh_c)::value;
+        constexpr int NTM = (MH == 1 && MT == 3) ? 1 : 2;   // 32-row blocks of this quadrant
         if (DBG & 4) {   // keep the accumulators (and so the MFMAs) alive without storing them
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) asm volatile("" ::"v"(acc[2 * MH + tm][NH]));
+            for (int tm = 0; tm < NTM; ++tm) asm volatile("" ::"v"(acc[2 * MH + tm][NH]));
             return;
         }
-        const int mb = tm0 + wr * 128 + MH * 64;             // wave-uniform first row / column of the quadrant
+        const int mb = tm0 + wr * (32 * MT) + MH * 64;             // wave-uniform first row / column of the quadrant
         const int nb = tn0 + wc * 64 + NH * 32;
         const bool edge = nb + 32 > g.N;                     // uniform: some groups of 8 lie past N
         // wave-uniform addresses in the constant address space, pinned to SGPRs: scalar loads (lgkmcnt) that do not touch the DMA
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         // byte offsets: uniform tile part + lane part; a group past N gets offset 2^31, past every descriptor (< 2 GB, host-checked): dropped / reads 0
         unsigned uo[2][2], up[2][2], ug[2][2], ur[2][2];
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 const long row = mb + tm * 32, col = nb + 16 * gq;
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         // all loads of the quadrant ahead of its first store
         q8_u32x4 qg[2][2], qr[2][2], qo[2][2][2];
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 if (EPI == 3) qg[tm][gq] = __builtin_amdgcn_raw_buffer_load_b128(rG, ug[tm][gq], 0, 0);
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
                 }
             }
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 float v[8];
@@ -488,8 +502,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         /* group 3: every fragment of this K tile has arrived (slot free); my DMA of the next K tile has landed (published) */ \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
         if (pdone) Q8_WAIT_DMA(0);   /* end of the stream: groups 1-2 issued nothing */                                   \
-        else if ((FIRST) && have_pend) { if (ROWSUM && rsp_was) Q8_WAIT_DMA(4 * NST + 8); else Q8_WAIT_DMA(4 * NST + 4); } \
-        else Q8_WAIT_DMA(4);                                                                                             \
+        else if ((FIRST) && have_pend) { if (ROWSUM && rsp_was) Q8_WAIT_DMA(MT * NST + 8); else Q8_WAIT_DMA_A(MT * NST + 4, 1); } \
+        else Q8_WAIT_DMA_A(4, 1);   /* in flight: A_0 and B_0 of K tile t+2 (groups 1-2) */                              \
         if (!(DBG & 16)) __builtin_amdgcn_s_barrier();                                                                   \
         Q8_SB();                                                                                                         \
         Q8_GROUP(ym, yn, xm, xn, tM, tN, 0, 2, (LAST) ? 3 : -1, false, false);                                           \
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     // prologue: K tiles 0 and 1 issued, K tile 0 landed and published, its first group requested
     Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
     Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
-    Q8_WAIT_DMA(8);
+    Q8_WAIT_DMA_A(8, 2);   // in flight: the second K tile (two A half-tiles among its four parts)
     __builtin_amdgcn_s_barrier();
     Q8_READ_GROUP(xm, xn, lds + wr * Q8_HALF, lds + (NSLOT + (wc >> 1)) * Q8_HALF, 0);
     if constexpr ((DBG & 32) != 0 && A_KC && B_KC) {   // timing decomposition: real (random) fragments, read once and never again
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     bool have_pend = false;
     int pm0 = 0, pn0 = 0, pz = 0;
     for (int cv = (int)blockIdx.x; cv < total; cv += G) {
-        const Q8Item cit = q8_decode(g, cv, total);
+        const Q8Item cit = q8_decode<MT>(g, cv, total);
         const int cm0 = cit.m0, cn0 = cit.n0, cz = cit.z, cnt = cit.nt;
         if (ROWSUM) rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0;
         Q8_KTILE(true, false);
@@ -556,4 +570,5 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
 #undef Q8_KTILE
 #undef Q8_NEXT_ITEM
 #undef Q8_WAIT_DMA
+#undef Q8_WAIT_DMA_A
 }
