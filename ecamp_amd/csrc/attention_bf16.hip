@@ -853,7 +853,7 @@ __global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
 }
 
 template <int HD, int FLAGS>
-__global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && HD == 64) ? 4 : 1) void attn_head_bwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && HD == 64) ? 4 : 2) void attn_head_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RB = HeadCfg<HD>::RB;
     const int nthr = blockDim.x, nw = nthr >> 6;
