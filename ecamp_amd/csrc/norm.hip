@@ -86,6 +86,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // one global f32 atomic per column per workgroup.  One 16-wave workgroup per CU: a 12800-row call issues 0.4 M global atomics on
 // the 48 cache lines of dgamma/dbeta instead of the 1.5 M of a 4-wave / 1024-block layout, whose per-line serialisation at L2
 // held the small shapes at 2 TB/s.
+// the 4-element vector of a row as it lies in memory (8 B of bf16 / 16 B of f32), converted when it is consumed
+template <typename T> struct LnRaw;
+template <> struct LnRaw<float> {
+    typedef float4 type;
+    static __device__ __forceinline__ void cvt(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+template <> struct LnRaw<bf16_t> {
+    typedef uint2 type;
+    static __device__ __forceinline__ void cvt(const uint2& v, float (&o)[4]) {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+};
+
 #define LN_BWD_WAVES 16
 template <typename T, int IT>
 __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
@@ -111,17 +125,41 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
             gm[i][0] = gm[i][1] = gm[i][2] = gm[i][3] = 0.f;
         }
     }
-    for (long row = (long)blockIdx.x * LN_BWD_WAVES + wave; row < rows; row += (long)gridDim.x * LN_BWD_WAVES) {
-        const float mu = mean[row], rs = rstd[row];
+    // rows are software-pipelined: the loads of a wave's NEXT row are in flight while the current row is reduced, normalised and
+    // stored (a row is a dependent chain load -> two wave reductions -> store; without the prefetch a CU has no load outstanding
+    // for about half of it)
+    typedef typename LnRaw<T>::type raw_t;
+    raw_t rdy[IT], rz[IT], rq[IT];
+    float nmu = 0.f, nrs = 0.f;
+    const long stride = (long)gridDim.x * LN_BWD_WAVES;
+    auto fetch = [&](long row) {
+        nmu = mean[row];
+        nrs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                rdy[i] = *reinterpret_cast<const raw_t*>(dy + row * cols + c * 4);
+                rz[i] = *reinterpret_cast<const raw_t*>(z + row * cols + c * 4);
+                if (dres) rq[i] = *reinterpret_cast<const raw_t*>(dres + row * cols + c * 4);
+            }
+        }
+    };
+    long row = (long)blockIdx.x * LN_BWD_WAVES + wave;
+    if (row < rows) fetch(row);
+    for (; row < rows; row += stride) {
+        const float mu = nmu, rs = nrs;
         float xh[IT][4], g[IT][4];
+        raw_t cq[IT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             int c = lane + 64 * i;
+            cq[i] = rq[i];
             if (c < nv) {
                 float d[4], zz[4];
-                ld4<T>(dy + row * cols + c * 4, d);
-                ld4<T>(z + row * cols + c * 4, zz);
+                LnRaw<T>::cvt(rdy[i], d);
+                LnRaw<T>::cvt(rz[i], zz);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     xh[i][r] = (zz[r] - mu) * rs;
@@ -136,6 +174,7 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
                 for (int r = 0; r < 4; ++r) xh[i][r] = g[i][r] = 0.f;
             }
         }
+        if (row + stride < rows) fetch(row + stride);
         s1 = wave_sum(s1) / (float)cols;
         s2 = wave_sum(s2) / (float)cols;
 #pragma unroll
@@ -147,7 +186,7 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
                 for (int r = 0; r < 4; ++r) o[r] = rs * (g[i][r] - s1 - xh[i][r] * s2);
                 if (dres) {
                     float q[4];
-                    ld4<T>(dres + row * cols + c * 4, q);
+                    LnRaw<T>::cvt(cq[i], q);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] += q[r];
                 }
