@@ -8,9 +8,12 @@ from ecamp_amd import optim
 from ecamp_amd.data import synthetic_batch
 from ecamp_amd.module import model_ecamp
 from ecamp_amd.util.misc import NativeScalerWithGradNormCount
-ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=8); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--only", default="", help="substring of the config name, e.g. 'configs[3]' or 'fp8'"); args = ap.parse_args()
 dev = torch.device("cuda:0")
 def run(name, ctor, B, big, **kw):
+    if args.only and args.only not in name:
+        return
     torch.manual_seed(0)
     model = ctor(compute_dtype=torch.bfloat16, **kw).to(dev); model.prepare(); model.train()
     opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
