@@ -1083,6 +1083,35 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     ECAMP_CHECK_ARG(split_k == 1 || splitk_ws, "ecamp_gemm: split_k > 1 requires a workspace of split_k*M*N floats");
     ECAMP_CHECK_ARG(split_k == 1 || (!bias && !residual && !pre_out && !gmul && !act), "ecamp_gemm: split-K has no epilogue");
 
+    // Row-contiguous forms whose [M, ld] operands pass 2 GB (the vocabulary projection at B = 512: 65536 x 30000 bf16) are run as
+    // two calls over row halves, so that each half meets the 32-bit buffer offsets of the persistent kernels (q8_legal).
+    if (a_kc && dtype == ECAMP_BF16 && split_k == 1 && !rowsum && M >= 512) {
+        const long lim = 0x7fffffffl, esz = out_f32 ? 4 : 2;
+        const bool big = M * ldc * esz > lim || M * lda * 2 > lim || (residual && M * ldr * 2 > lim) || (pre_out && M * ldp * 2 > lim) || (gmul && M * ldg * 2 > lim);
+        if (big) {
+            const int64_t m1 = (M / 2 + 255) / 256 * 256;
+            auto rows = [](const void* p, int64_t r, int64_t ld, int64_t es) { return p ? (const void*)((const char*)p + r * ld * es) : nullptr; };
+            int rc = ecamp_gemm(A, B, C, m1, N, K, a_kc, lda, b_kc, ldb, ldc, bias, residual, ldr, pre_out, ldp, gmul, ldg, act, alpha, alpha_dev, dtype,
+                                out_f32, accumulate, 1, nullptr, nullptr, stream);
+            if (rc) return rc;
+            return ecamp_gemm(rows(A, m1, lda, 2), B, (void*)rows(C, m1, ldc, esz), M - m1, N, K, a_kc, lda, b_kc, ldb, ldc, bias, rows(residual, m1, ldr, 2), ldr,
+                              (void*)rows(pre_out, m1, ldp, 2), ldp, rows(gmul, m1, ldg, 2), ldg, act, alpha, alpha_dev, dtype, out_f32, accumulate, 1, nullptr,
+                              nullptr, stream);
+        }
+    }
+    // ... and the weight-gradient form whose [K, ld] operands pass 2 GB as two calls over halves of the contraction, the second accumulating
+    if (!a_kc && !b_kc && dtype == ECAMP_BF16 && out_f32 && K >= 1024) {
+        const long lim = 0x7fffffffl;
+        if (K * lda * 2 > lim || K * ldb * 2 > lim) {
+            const int64_t k1 = (K / 2 + 255) / 256 * 256;
+            int rc = ecamp_gemm(A, B, C, M, N, k1, a_kc, lda, b_kc, ldb, ldc, bias, residual, ldr, pre_out, ldp, gmul, ldg, act, alpha, alpha_dev, dtype, out_f32,
+                                accumulate, split_k, splitk_ws, rowsum, stream);
+            if (rc) return rc;
+            return ecamp_gemm((const char*)A + k1 * lda * 2, (const char*)B + k1 * ldb * 2, C, M, N, K - k1, a_kc, lda, b_kc, ldb, ldc, bias, residual, ldr, pre_out, ldp,
+                              gmul, ldg, act, alpha, alpha_dev, dtype, out_f32, 1, split_k, splitk_ws, rowsum, stream);
+        }
+    }
+
     GemmArgs g;
     g.dbg = 0; g.wide = 0; g.nsplit = 1;
     g.A = A; g.B = B; g.C = C;

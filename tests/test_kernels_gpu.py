@@ -791,3 +791,39 @@ def test_gemm_fp8_forward_epilogues(dev, M, N, K):
     e = ((o.linear_fwd_fp8(xd, w8, ws, bd).float().cpu() - exact).norm() / exact.norm()).item()
     print("  fp8 vs unquantised product: relative Frobenius error %.3e" % e)
     assert e < 6e-2
+
+
+def test_gemm_rows_past_2gb_are_split(dev):
+    """An output of more than 2 GB (the vocabulary projection at B = 512) runs as two row halves on the persistent kernel; the rows on
+    both sides of the seam match the same rows computed as a small GEMM."""
+    o = ops()
+    M, N, K = 65536, 16400, 128           # 65536 x 16400 bf16 = 2.15 GB
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(dev, torch.bfloat16)
+    w = (torch.randn(N, K, generator=torch.Generator().manual_seed(2)) * K ** -0.5).to(dev, torch.bfloat16)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
+    n0 = _q8_count()
+    y = o.linear_fwd(x, w, b)
+    assert _q8_count() >= n0 + 2, "the two halves did not run on the Q8 kernel"
+    for r0 in (0, 32768 - 8, 32768, 65536 - 16):
+        ref = (x[r0:r0 + 16].float() @ w.float().t() + b).to(torch.bfloat16).float()
+        assert (y[r0:r0 + 16].float() - ref).abs().max() < 3e-2 * ref.abs().max()
+    del y
+
+
+def test_gemm_wgrad_contraction_past_2gb_is_split(dev):
+    """A weight gradient whose dy operand passes 2 GB (the vocabulary head at B = 512) runs as two calls over halves of the rows, the second
+    accumulating: weight and bias gradient against torch on a column sample."""
+    o = ops()
+    M, N, K = 65536, 16400, 128           # dy [M, N] bf16 = 2.15 GB
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(dev, torch.bfloat16)
+    dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+    gw = torch.zeros(N, K, device=dev)
+    gb = torch.zeros(N, device=dev)
+    n0 = _q8_count()
+    o.linear_wgrad(dy, x, gw, gb=gb, accumulate=False)
+    assert _q8_count() >= n0 + 2, "the two halves did not run on the Q8 kernel"
+    cols = torch.tensor([0, 255, 256, 8191, 16399], device=dev)
+    ref = dy[:, cols].float().t() @ x.float()
+    assert (gw[cols] - ref).abs().max() < 2e-3 * ref.abs().max()
+    refb = dy[:, cols].float().sum(0)
+    assert (gb[cols] - refb).abs().max() < 2e-3 * refb.abs().max() + 1e-2
