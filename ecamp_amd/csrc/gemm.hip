@@ -1243,3 +1243,170 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
+
+// =============================================================================================
+// Grouped weight gradients: the (up to four) dW_p (+)= alpha * dY_p^T X_p of one transformer block -- same contraction length
+// `rows`, different shapes and operands -- as ONE launch of the Q8 kernel's item-table form (gemm_q8.h, ITEMS) plus one grouped
+// reduce.  Per-layer launches give every CU exactly one (tile, K slice) item: 2.5 us of ring fill and 6.5 us of f32 slab
+// stores with nothing to overlap per ~90 us launch, and 7-28 slabs per output tile (256 MB written and re-read per encoder
+// block).  Here the K tiles of ALL tiles of the block are dealt out evenly, in order, to the workgroups (ranges run across
+// tile boundaries), so a tile has 2-4 slabs and a workgroup one ring fill per block.
+#include <map>
+#include <string>
+#include <vector>
+struct WgTile { int prob, m0, n0, first, count; };
+struct WgRedProb { float* C; long ldc; int M, N; float alpha; int accumulate; const float* alpha_dev; };
+struct WgRedArgs { const WgTile* tiles; const float* slabs; int ntiles, pad; WgRedProb p[4]; };
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgRedArgs a) {
+    const int t = blockIdx.x >> 4, chunk = blockIdx.x & 15;
+    const WgTile T = a.tiles[t];
+    const WgRedProb P = T.prob == 0 ? a.p[0] : T.prob == 1 ? a.p[1] : T.prob == 2 ? a.p[2] : a.p[3];
+    const float al = P.alpha_dev ? P.alpha * P.alpha_dev[0] : P.alpha;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = chunk * 1024 + j * 256 + threadIdx.x;            // float4 index inside the 256 x 256 tile
+        const int r = idx >> 6, c = (idx & 63) * 4;
+        const int gm = T.m0 + r, gn = T.n0 + c;
+        if (gm >= P.M || gn >= P.N) continue;
+        const float4* src = reinterpret_cast<const float4*>(a.slabs + (long)T.first * 65536) + idx;
+        float4 acc = src[0];
+        for (int z = 1; z < T.count; ++z) {
+            const float4 p = src[(long)z * 16384];
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        float* c_ = P.C + (long)gm * P.ldc + gn;
+        float4 o = P.accumulate ? *reinterpret_cast<float4*>(c_) : make_float4(0.f, 0.f, 0.f, 0.f);
+        o.x += al * acc.x; o.y += al * acc.y; o.z += al * acc.z; o.w += al * acc.w;
+        *reinterpret_cast<float4*>(c_) = o;
+    }
+}
+
+struct WgPlan {
+    Q8ItemRec* d_items = nullptr;
+    int* d_first = nullptr;
+    WgTile* d_tiles = nullptr;
+    int nitems = 0, nwg = 0, ntiles = 0;
+};
+static std::map<std::string, WgPlan> g_wg_plans;
+
+static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, const unsigned* has_bias, int64_t rows, int ncu) {
+    std::string key((const char*)n_out, n * sizeof(int64_t));
+    key.append((const char*)k_in, n * sizeof(int64_t)).append((const char*)has_bias, n * sizeof(unsigned)).append((const char*)&rows, 8).append((const char*)&ncu, 4);
+    auto it = g_wg_plans.find(key);
+    if (it != g_wg_plans.end()) return &it->second;
+    const long KT = (rows + 63) / 64;
+    std::vector<WgTile> tiles;
+    for (int p = 0; p < n; ++p)
+        for (int mb = 0; mb < ceil_div(n_out[p], 256); ++mb)
+            for (int nb = 0; nb < ceil_div(k_in[p], 256); ++nb) tiles.push_back({p, mb * 256, nb * 256, 0, 0});
+    const long units = (long)tiles.size() * KT;
+    long q = (units + ncu - 1) / ncu;
+    q += q & 1;                                   // even quota, even KT (rows % 128 == 0): every piece has >= 2 K tiles
+    if (q < 2) q = 2;
+    std::vector<Q8ItemRec> items;
+    std::vector<int> first;
+    long u = 0;
+    while (u < units) {
+        first.push_back((int)items.size());
+        long take = q < units - u ? q : units - u;
+        while (take > 0) {
+            const long t = u / KT, k0 = u % KT, len = take < KT - k0 ? take : KT - k0;
+            WgTile& T = tiles[t];
+            if (T.count == 0) T.first = (int)items.size();
+            ++T.count;
+            const long kend = (k0 + len) * 64 < rows ? (k0 + len) * 64 : rows;
+            items.push_back({T.prob, T.m0, T.n0, (int)(k0 * 64), (int)kend, (int)items.size(), (T.n0 == 0 && has_bias[T.prob]) ? 1 : 0, 0});
+            u += len; take -= len;
+        }
+    }
+    first.push_back((int)items.size());
+    WgPlan pl;
+    pl.nitems = (int)items.size(); pl.nwg = (int)first.size() - 1; pl.ntiles = (int)tiles.size();
+    if (hipMalloc(&pl.d_items, items.size() * sizeof(Q8ItemRec)) != hipSuccess || hipMalloc(&pl.d_first, first.size() * sizeof(int)) != hipSuccess ||
+        hipMalloc(&pl.d_tiles, tiles.size() * sizeof(WgTile)) != hipSuccess) return nullptr;
+    if (hipMemcpy(pl.d_items, items.data(), items.size() * sizeof(Q8ItemRec), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(pl.d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(pl.d_tiles, tiles.data(), tiles.size() * sizeof(WgTile), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return &(g_wg_plans[key] = pl);
+}
+// Workgroups of the grouped launch: three quarters of the CUs.  It runs beside the data-gradient chain of the next block; with one
+// workgroup on every CU that chain's kernels wait for whole 250-us items (39.7-39.9 ms per step against 39.4 with per-layer
+// launches), with 192 they do not (39.4-39.9 against 39.7-40.1 on the same boxes; 160: +0.6 ms, 64: +4 ms).  ECAMP_WGRAD_GROUP_CUS overrides.
+static int wg_ncu() {
+    static const int env = getenv("ECAMP_WGRAD_GROUP_CUS") ? atoi(getenv("ECAMP_WGRAD_GROUP_CUS")) : 0;
+    if (env > 0) return env;
+    int ncu = p8_num_cu();
+    if (g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;
+    const int q = p8_num_cu() * 3 / 4;
+    return ncu < q ? ncu : q;
+}
+// 1 if the group can run as one launch (otherwise the caller issues per-layer ecamp_gemm calls)
+extern "C" int ecamp_wgrad_group_supported(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows) {
+    if (n < 1 || n > 4 || !n_out || !k_in || rows < 256 || rows % 128) return 0;
+    long tiles = 0;
+    for (int p = 0; p < n; ++p) {
+        if (n_out[p] % 8 || k_in[p] % 8 || n_out[p] <= 0 || k_in[p] <= 0) return 0;
+        if (rows * n_out[p] * 2 > 0x7fffffffl || rows * k_in[p] * 2 > 0x7fffffffl) return 0;
+        tiles += (long)ceil_div(n_out[p], 256) * ceil_div(k_in[p], 256);
+    }
+    return tiles >= 16 ? 1 : 0;
+}
+// bytes of `ws`: one 256 x 256 f32 slab per work item (0: not supported)
+extern "C" int64_t ecamp_wgrad_group_workspace_bytes(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows) {
+    if (!ecamp_wgrad_group_supported(n, n_out, k_in, rows)) return 0;
+    long tiles = 0;
+    for (int p = 0; p < n; ++p) tiles += (long)ceil_div(n_out[p], 256) * ceil_div(k_in[p], 256);
+    return (tiles + p8_num_cu() + 1) * 262144;    // every workgroup boundary adds at most one piece
+}
+// gw[p] [n_out[p], k_in[p]] (f32, contiguous) (+)= alpha * dy[p]^T x[p];  gb[p] [n_out[p]] (f32 or null) += alpha * column sums of dy[p].
+// dy[p] [rows, n_out[p]], x[p] [rows, k_in[p]] bf16, row-contiguous.  accumulate[p] = 0 overwrites gw[p].
+extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* const* x, float* const* gw, float* const* gb, const int64_t* n_out,
+                                 const int64_t* k_in, int64_t rows, float alpha, const float* alpha_dev, const int32_t* accumulate, float* ws,
+                                 hipStream_t stream) {
+    ECAMP_CHECK_ARG(dy && x && gw && gb && n_out && k_in && accumulate && ws, "wgrad_group: null pointer");
+    ECAMP_CHECK_ARG(ecamp_wgrad_group_supported(n, n_out, k_in, rows), "wgrad_group: unsupported group (1-4 layers, rows %% 128 == 0, dims %% 8 == 0, < 2 GB operands)");
+    unsigned hb[4] = {0, 0, 0, 0};
+    bool any_bias = false;
+    for (int p = 0; p < n; ++p) {
+        ECAMP_CHECK_ARG(dy[p] && x[p] && gw[p], "wgrad_group: null operand");
+        ECAMP_CHECK_ARG(((uintptr_t)dy[p] & 15) == 0 && ((uintptr_t)x[p] & 15) == 0 && ((uintptr_t)gw[p] & 15) == 0, "wgrad_group: operands must be 16-byte aligned");
+        hb[p] = gb[p] ? 1u : 0u;
+        any_bias = any_bias || gb[p];
+    }
+    const WgPlan* pl = wg_plan(n, n_out, k_in, hb, rows, wg_ncu());
+    ECAMP_CHECK_ARG(pl != nullptr, "wgrad_group: could not build the item table");
+    Q8Group G;
+    memset(&G, 0, sizeof(G));
+    G.items = pl->d_items; G.wg_first = pl->d_first; G.slabs = ws; G.nprob = n;
+    WgRedArgs R;
+    memset(&R, 0, sizeof(R));
+    R.tiles = pl->d_tiles; R.slabs = ws; R.ntiles = pl->ntiles;
+    for (int p = 0; p < n; ++p) {
+        G.p[p].A = dy[p]; G.p[p].B = x[p]; G.p[p].lda = n_out[p]; G.p[p].ldb = k_in[p]; G.p[p].M = (int)n_out[p]; G.p[p].N = (int)k_in[p];
+        G.p[p].rowsum = gb[p]; G.p[p].alpha_out = alpha; G.p[p].alpha_dev_out = alpha_dev;
+        R.p[p].C = gw[p]; R.p[p].ldc = k_in[p]; R.p[p].M = (int)n_out[p]; R.p[p].N = (int)k_in[p]; R.p[p].alpha = alpha; R.p[p].alpha_dev = alpha_dev;
+        R.p[p].accumulate = accumulate[p];
+    }
+    GemmArgs g;   // the item-table form takes operands and shapes from the group; these only keep the kernel's unused set-up code in range
+    memset(&g, 0, sizeof(g));
+    g.A = dy[0]; g.B = x[0]; g.C = ws; g.M = (int)n_out[0]; g.N = (int)k_in[0]; g.K = (int)rows; g.lda = n_out[0]; g.ldb = k_in[0]; g.ldc = k_in[0];
+    g.out_f32 = 1; g.alpha = 1.0f; g.alpha_out = alpha; g.nbm = 1; g.nbn = 1; g.nsplit = 1; g.k_per_split = (int)rows; g.wide = 1; g.partial = ws;
+    const size_t shm = 10 * Q8_HALF;
+    static bool attr[2] = {false, false};
+    if (!attr[any_bias]) {
+        if (any_bias) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_q8_items_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_q8_items_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr[any_bias] = true;
+    }
+    double work = 0.0;
+    for (int p = 0; p < n; ++p) work += 2.0 * (double)n_out[p] * (double)k_in[p] * (double)rows;
+    const bool prof = ecamp_prof_active();
+    if (prof) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, work, stream);
+    if (any_bias) hipLaunchKernelGGL(gemm_bf16_q8_items_kernel<true>, dim3(pl->nwg), dim3(512), shm, stream, g, G);
+    else hipLaunchKernelGGL(gemm_bf16_q8_items_kernel<false>, dim3(pl->nwg), dim3(512), shm, stream, g, G);
+    g_q8_launches += n;
+    hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(pl->ntiles * 16), dim3(256), 0, stream, R);
+    if (prof) ecamp_prof_end(stream);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}

@@ -31,6 +31,31 @@ struct GemmArgs {
     int nsplit;             // P8: number of split-K slices (the persistent kernel walks tiles x slices itself)
 };
 
+// ---- grouped weight gradients (gemm_q8.h, ITEMS form): several dW_p (+)= dY_p^T X_p sharing the contraction length (the four linear
+// layers of one transformer block) as ONE launch whose work items are (tile, K range) pieces cut so that every workgroup gets the
+// same number of K tiles (ranges run across tile boundaries).  Each piece writes a dense 256 x 256 f32 slab; a grouped reduce sums
+// the consecutive slabs of a tile into C.
+struct Q8Prob {
+    const void* A;            // dY [K, lda]  (rows = contraction)
+    const void* B;            // X  [K, ldb]
+    long lda, ldb;
+    int M, N;                 // output [M, N] = [out features, in features]
+    float* rowsum;            // bias gradient [M] or null
+    const float* alpha_dev_out;
+    float alpha_out;
+    int pad;
+};
+struct Q8ItemRec {            // 32 bytes, read with scalar loads
+    int prob, m0, n0, kbeg, kend, slab, flags, pad;   // flags bit 0: this piece also sums the bias gradient of rows m0.. (first N-tile column)
+};
+struct Q8Group {
+    const Q8ItemRec* items;
+    const int* wg_first;      // [workgroups + 1]: item range of each workgroup
+    float* slabs;             // [items][256][256] f32
+    int nprob, pad;
+    Q8Prob p[4];
+};
+
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     // Blocks are dealt round-robin to the 8 XCDs; give every XCD a contiguous range of tiles so that
     // neighbouring tiles (same A rows, different weight columns) share one L2.  Bijective for any nblk.

@@ -151,9 +151,12 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
 // fraction of a round (12800 x 768: 150 tiles on 256 CUs; 201 tiles of 3/4 the work take 3/4 of the time).  The LDS image, the DMA
 // and the rings do not change: an A half-tile still brings 128 rows, of which a wave row uses the first 96 (half-tile 1 starts
 // 96 rows in; the 32 surplus rows are rows of the other half / the next tile / zeros past M).
-template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false, int MT = 4>
-__global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
+// ITEMS (weight-gradient form only): the work items come from a table (Q8Group, gemm_args.h) instead of the tile x split arithmetic;
+// operands and leading dimensions change with the item's problem, every piece stores a dense f32 slab.
+template <bool A_KC, bool B_KC, int EPI, int DBG, bool ROWSUM, int MT, bool ITEMS>
+__device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     static_assert(MT == 3 || MT == 4, "tile heights: 192 or 256 rows");
+    static_assert(!ITEMS || (!A_KC && !B_KC && EPI == 4 && MT == 4 && DBG == 0), "the item-table form is the weight-gradient form");
     static_assert(MT == 4 || (A_KC && !ROWSUM), "the 192-row tile is built for contraction-contiguous M-side operands (forward / data-gradient forms)");
     static_assert(!ROWSUM || (!A_KC && !B_KC && EPI == 4), "rowsum is built for the weight-gradient form");
     constexpr int NST = (DBG & 4) ? 0 : Q8Epi<EPI>::NST;   // stores per quadrant (none in the no-epilogue timing variant)
@@ -162,9 +165,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // A ring (5 x 16 KB) | B ring (5 x 16 KB); the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int total = g.nbm * g.nbn * g.nsplit, G = (int)gridDim.x;
+    // ITEMS: this workgroup's consecutive pieces [it_beg, total) of the table; otherwise items blockIdx.x, + G, ... of the arithmetic order
+    typedef const int __attribute__((address_space(4))) cint4;
+    const int it_beg = ITEMS ? *(cint4*)(GR.wg_first + blockIdx.x) : (int)blockIdx.x;
+    const int total = ITEMS ? *(cint4*)(GR.wg_first + blockIdx.x + 1) : g.nbm * g.nbn * g.nsplit, G = ITEMS ? 1 : (int)gridDim.x;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+    // field F of problem P_ of the group (scalar selects: a run-time index into the by-value argument would put it in scratch)
+    // (selects of VALUES read once here: a select between the fields' addresses keeps the whole argument block in scratch)
+#define Q8_PROB_FIELD(F) const auto gp0_##F = GR.p[0].F, gp1_##F = GR.p[1].F, gp2_##F = GR.p[2].F, gp3_##F = GR.p[3].F
+    Q8_PROB_FIELD(A); Q8_PROB_FIELD(B); Q8_PROB_FIELD(lda); Q8_PROB_FIELD(ldb); Q8_PROB_FIELD(M); Q8_PROB_FIELD(rowsum);
+    Q8_PROB_FIELD(alpha_out); Q8_PROB_FIELD(alpha_dev_out);
+#undef Q8_PROB_FIELD
+    float* const gr_slabs = GR.slabs;
+#define Q8_PROB(P_, F) ((P_) == 0 ? gp0_##F : (P_) == 1 ? gp1_##F : (P_) == 2 ? gp2_##F : gp3_##F)
+    auto item_at = [&](int i) {   // record i of the table, through scalar loads (constant address space, wave-uniform index)
+        typedef int q8_i32x8 __attribute__((ext_vector_type(8)));
+        typedef const q8_i32x8 __attribute__((address_space(4))) crec4;
+        const q8_i32x8 w = *(crec4*)(reinterpret_cast<const int*>(GR.items) + (long)i * 8);
+        Q8ItemRec r;
+#define Q8_U(X) __builtin_amdgcn_readfirstlane(X)
+        r.prob = Q8_U(w[0]); r.m0 = Q8_U(w[1]); r.n0 = Q8_U(w[2]); r.kbeg = Q8_U(w[3]); r.kend = Q8_U(w[4]); r.slab = Q8_U(w[5]); r.flags = Q8_U(w[6]); r.pad = 0;
+#undef Q8_U
+        return r;
+    };
+    auto uniform_ptr = [](const void* q) {   // tells the compiler that a selected pointer is wave-uniform (it feeds scalar loads and descriptors)
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        return (const void*)(((unsigned long long)hi << 32) | lo);
+    };
     const int l31 = lane & 31, lh = lane >> 5;
     // N-side fragment row -> tile column (see header)
     const int ncol = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | ((l31 >> 4) << 4);
@@ -202,29 +231,46 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     // ---- DMA cursor over the flat K-tile stream; all of it wave-uniform (SGPRs): byte cursors of the A and B half-tile 0 of the
     // K tile being staged, bytes left in their valid ranges, contraction elements left in the staged output tile.  The four parts
     // of a K tile are staged in the order A_0, B_0 ("early": their ring slots were vacated two K tiles ago), A_1, B_1 ("late").
-    int pv = (int)blockIdx.x;
+    int pv = it_beg;
     bool pdone = pv >= total;
     const unsigned char *sa_base, *sb_base;
     int sa_rec, sb_rec, p_krem;
-    const int a_half = A_KC ? (int)g.lda * (64 * MT) : 64 * MT, a_step = A_KC ? 128 : (int)g.lda * 128;
+    const int a_half = A_KC ? (int)g.lda * (64 * MT) : 64 * MT;
+    int a_step = A_KC ? 128 : (int)g.lda * 128;   // (ITEMS: follows the staged item's problem)
     // 192-row tile: an A half-tile's second piece of a wave holds rows 64 + 8*wave ..: only those of waves 0-3 (rows < 96) are used, so
     // wave row 1 does not request it -- one DMA instruction fewer per A half-tile, which every counted wait of these waves allows for
     const bool A96 = MT == 3 && wr == 1;
-    const int b_half = B_KC ? (int)g.ldb * 256 : 256, b_step = B_KC ? 128 : (int)g.ldb * 128;
+    const int b_half = B_KC ? (int)g.ldb * 256 : 256;
+    int b_step = B_KC ? 128 : (int)g.ldb * 128;
+    long s_lda = ITEMS ? -1 : g.lda, s_ldb = ITEMS ? -1 : g.ldb;   // leading dimensions the per-lane DMA offsets were built for
+    unsigned voffA[2], voffB[2];
+    if (!ITEMS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { voffA[i] = q8_voff<A_KC>(i, wave, lane, g.lda); voffB[i] = q8_voff<B_KC>(i, wave, lane, g.ldb); }
+    }
 #define Q8_NEXT_ITEM()                                                                                                   \
     do {                                                                                                                 \
-        const Q8Item n_ = q8_decode<MT>(g, pv, total);                                                                       \
+        if (ITEMS) {                                                                                                     \
+            const Q8ItemRec r_ = item_at(pv);                                                                            \
+            const long la_ = Q8_PROB(r_.prob, lda), lb_ = Q8_PROB(r_.prob, ldb);                                         \
+            const bf16_t* A_ = reinterpret_cast<const bf16_t*>(uniform_ptr(Q8_PROB(r_.prob, A)));                        \
+            const bf16_t* B_ = reinterpret_cast<const bf16_t*>(uniform_ptr(Q8_PROB(r_.prob, B)));                        \
+            p_krem = r_.kend - r_.kbeg;                                                                                  \
+            sa_base = (const unsigned char*)(A_ + ((long)r_.kbeg * la_ + r_.m0)); sa_rec = (int)(((long)p_krem * la_ - r_.m0) * 2); \
+            sb_base = (const unsigned char*)(B_ + ((long)r_.kbeg * lb_ + r_.n0)); sb_rec = (int)(((long)p_krem * lb_ - r_.n0) * 2); \
+            if (la_ != s_lda) { s_lda = la_; a_step = (int)la_ * 128; voffA[0] = q8_voff<A_KC>(0, wave, lane, la_); voffA[1] = q8_voff<A_KC>(1, wave, lane, la_); } \
+            if (lb_ != s_ldb) { s_ldb = lb_; b_step = (int)lb_ * 128; voffB[0] = q8_voff<B_KC>(0, wave, lane, lb_); voffB[1] = q8_voff<B_KC>(1, wave, lane, lb_); } \
+        } else {                                                                                                         \
+        const Q8Item n_ = q8_decode<MT>(g, pv, total);                                                                   \
         p_krem = n_.kend - n_.kbeg;                                                                                      \
         if (A_KC) { sa_base = (const unsigned char*)(A + ((long)n_.m0 * g.lda + n_.kbeg)); sa_rec = (int)((((long)(g.M - n_.m0)) * g.lda - n_.kbeg) * 2); } \
         else      { sa_base = (const unsigned char*)(A + ((long)n_.kbeg * g.lda + n_.m0)); sa_rec = (int)(((long)p_krem * g.lda - n_.m0) * 2); }             \
         if (B_KC) { sb_base = (const unsigned char*)(B + ((long)n_.n0 * g.ldb + n_.kbeg)); sb_rec = (int)((((long)(g.N - n_.n0)) * g.ldb - n_.kbeg) * 2); } \
         else      { sb_base = (const unsigned char*)(B + ((long)n_.kbeg * g.ldb + n_.n0)); sb_rec = (int)(((long)p_krem * g.ldb - n_.n0) * 2); }             \
+        }                                                                                                                \
     } while (0)
     if (!pdone) Q8_NEXT_ITEM();
     int wA = 0, wB = 0;                                // ring slots the next A / B half-tile goes to
-    unsigned voffA[2], voffB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { voffA[i] = q8_voff<A_KC>(i, wave, lane, g.lda); voffB[i] = q8_voff<B_KC>(i, wave, lane, g.ldb); }
     // stage pieces PCS (bit 0: piece `wave`, bit 1: piece `8 + wave`) of part PART (0: A_0, 1: B_0, 2: A_1, 3: B_1) of the K tile
     // being staged; the cursor moves on with the second piece of part 3
 #define Q8_STAGE_PCS(PART, PCS)                                                                                          \
@@ -260,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     int rA = 0, rB = 0;                               // ring slots of A_0 / B_0 of the K tile being multiplied
     float rs[4] = {0.f, 0.f, 0.f, 0.f}, rsp[4] = {0.f, 0.f, 0.f, 0.f};   // ROWSUM: running / finished-tile partial sums of row l31 of tile tm
     bool rs_on = false, rsp_on = false;
-    int rsp_m0 = 0;
+    int rsp_m0 = 0, rsp_prob = 0;
     // this lane's 8 contraction values of M-side fragment F summed into S (strided operand: lo/hi halves)
 #define Q8_RS_ACC(FM)                                                                                                    \
     do {                                                                                                                 \
@@ -318,6 +364,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
         if (DBG & 4) {   // keep the accumulators (and so the MFMAs) alive without storing them
 #pragma unroll
             for (int tm = 0; tm < NTM; ++tm) asm volatile("" ::"v"(acc[2 * MH + tm][NH]));
+            return;
+        }
+        if constexpr (ITEMS) {   // dense 256 x 256 f32 slab `tz`: no bounds, no scaling (the grouped reduce applies alpha), 8 stores
+            const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(gr_slabs + (long)tz * 65536), 0, 262144, 0x00020000);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                    const unsigned o = (unsigned)((((wr * 128 + MH * 64 + tm * 32 + l31) * 256) + wc * 64 + NH * 32 + 16 * gq + 8 * lh) * 4);
+                    const f32x16& a_ = acc[2 * MH + tm][NH];
+                    __builtin_amdgcn_raw_buffer_store_b128((q8_u32x4){__float_as_uint(a_[8 * gq]), __float_as_uint(a_[8 * gq + 1]), __float_as_uint(a_[8 * gq + 2]), __float_as_uint(a_[8 * gq + 3])}, rI, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((q8_u32x4){__float_as_uint(a_[8 * gq + 4]), __float_as_uint(a_[8 * gq + 5]), __float_as_uint(a_[8 * gq + 6]), __float_as_uint(a_[8 * gq + 7])}, rI, o + 16, 0, 0);
+                }
             return;
         }
         const int mb = tm0 + wr * (32 * MT) + MH * 64;             // wave-uniform first row / column of the quadrant
@@ -425,13 +484,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)(ROWSUM && g.rowsum ? (void*)g.rowsum : g.C), 0, (int)(unsigned)((long)g.M * 4), 0x00020000);
     auto rowsum_flush = [&]() {
         typedef const float __attribute__((address_space(4))) cfloat4;
-        float al = g.alpha_out;
-        if (g.alpha_dev_out) { float ad = *(cfloat4*)g.alpha_dev_out; asm volatile("" : "+s"(ad)); al *= ad; }
+        float al = ITEMS ? Q8_PROB(rsp_prob, alpha_out) : g.alpha_out;
+        const float* adp = ITEMS ? (const float*)uniform_ptr(Q8_PROB(rsp_prob, alpha_dev_out)) : g.alpha_dev_out;
+        if (adp) { float ad = *(cfloat4*)adp; asm volatile("" : "+s"(ad)); al *= ad; }
+        __amdgpu_buffer_rsrc_t rSi = rS;
+        if (ITEMS) rSi = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(Q8_PROB(rsp_prob, rowsum)), 0, (int)(unsigned)((long)Q8_PROB(rsp_prob, M) * 4), 0x00020000);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float tot = (rsp[t] + __shfl_xor(rsp[t], 32, 64)) * al;
             const unsigned off = lh ? 0x80000000u : (unsigned)((rsp_m0 + wr * 128 + t * 32 + l31) * 4);
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, rS, off, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, rSi, off, 0, 0);
         }
         rsp_on = false;
     };
@@ -538,17 +600,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     // ---- main loop over this workgroup's output tiles (every tile has at least two K tiles: the host guarantees K/split >= 128)
     bool have_pend = false;
     int pm0 = 0, pn0 = 0, pz = 0;
-    for (int cv = (int)blockIdx.x; cv < total; cv += G) {
-        const Q8Item cit = q8_decode<MT>(g, cv, total);
-        const int cm0 = cit.m0, cn0 = cit.n0, cz = cit.z, cnt = cit.nt;
-        if (ROWSUM) rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0;
+    for (int cv = it_beg; cv < total; cv += G) {
+        int cm0, cn0, cz, cnt;   // ITEMS: cn0 carries the problem index and cz the slab index into the epilogue
+        if (ITEMS) {
+            const Q8ItemRec cr = item_at(cv);
+            cm0 = cr.m0; cn0 = cr.prob; cz = cr.slab; cnt = (cr.kend - cr.kbeg + 63) >> 6;
+            if (ROWSUM) rs_on = (cr.flags & 1) != 0 && wc == 0 && Q8_PROB(cr.prob, rowsum) != nullptr;
+        } else {
+            const Q8Item cit = q8_decode<MT>(g, cv, total);
+            cm0 = cit.m0; cn0 = cit.n0; cz = cit.z; cnt = cit.nt;
+            if (ROWSUM) rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0;
+        }
         Q8_KTILE(true, false);
 #pragma unroll 1
         for (int t = 2; t < cnt; ++t) Q8_KTILE(false, false);
         Q8_KTILE(false, true);
         have_pend = true; pm0 = cm0; pn0 = cn0; pz = cz;
         if (ROWSUM) {
-            rsp_on = rs_on; rsp_m0 = cm0;
+            rsp_on = rs_on; rsp_m0 = cm0; rsp_prob = cn0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) { rsp[t] = rs[t]; rs[t] = 0.f; }
         }
@@ -572,3 +641,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
 #undef Q8_WAIT_DMA
 #undef Q8_WAIT_DMA_A
 }
+#undef Q8_PROB
+
+template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false, int MT = 4>
+__global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
+    Q8Group none;   // never read in this form
+    q8_body<A_KC, B_KC, EPI, DBG, ROWSUM, MT, false>(g, none);
+}
+// grouped weight gradients: `g` only supplies the fields the item-table form does not take from the group (none of the operands)
+template <bool ROWSUM>
+__global__ __launch_bounds__(512) void gemm_bf16_q8_items_kernel(GemmArgs g, Q8Group GR) {
+    q8_body<false, false, 4, 0, ROWSUM, 4, true>(g, GR);
+}
+

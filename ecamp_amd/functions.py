@@ -26,11 +26,62 @@ def _none(n):
     return (None,) * n
 
 
+_BLOCK = None   # [arena, [(dy, x, gw, gb, accumulate)], [parameters reported ready]] while a block's backward collects its weight gradients
+
+
+class _wgrad_block:
+    """`with _wgrad_block(arena):` around the backward of one transformer block: its weight gradients (2-4 linear layers over the
+    same rows) are collected and issued as ONE grouped launch on the side stream when the block's backward has been queued
+    (ops.wgrad_group_async; per-layer launches when the group does not qualify).  `arena.ready(...)` calls made inside are held
+    back until then: the data-parallel reducer may only see a parameter once its gradient GEMM is in a stream."""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        global _BLOCK
+        self.prev, _BLOCK = _BLOCK, [self.arena, [], []]
+        self._ready = self.arena.ready
+        self.arena.ready = lambda *ps, _b=_BLOCK: _b[2].extend(ps)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _BLOCK
+        blk, _BLOCK = _BLOCK, self.prev
+        del self.arena.ready          # back to the class method
+        if et is None:
+            _issue(blk[1])
+            if blk[2]:
+                self.arena.ready(*blk[2])
+        return False
+
+
+def _issue(items):
+    if len(items) >= 2 and ops.wgrad_group_supported(items):
+        ops.wgrad_group_async(items)
+    else:
+        for dy, x, gw, gb, acc in items:
+            ops.linear_wgrad_async(dy, x, gw, gb=gb, accumulate=acc)
+
+
+_GROUP_SIZE = int(__import__("os").environ.get("ECAMP_WGRAD_GROUP_SIZE", "2"))   # layers per grouped launch (2: MLP pair, then attention pair; 4: whole block)
+
+
+def _wgrad_flush():
+    """Issue what the current block has collected so far (a block may be cut into two grouped launches)."""
+    if _BLOCK is not None and _BLOCK[1] and len(_BLOCK[1]) >= _GROUP_SIZE:
+        _issue(_BLOCK[1])
+        del _BLOCK[1][:]
+
+
 def _wgrad(A, dy, x, w, gb=None, alpha_dev=None, shape=None):
     """Weight gradient of one nn.Linear (or of adjacent ones run as a single GEMM) on the side stream: dW (+)= dy^T x straight into
     the gradient arena -- overwriting on the first backward after zero_grad(), accumulating afterwards (ParamArena.gradw) -- and
-    db += column sums of dy inside the same GEMM."""
+    db += column sums of dy inside the same GEMM.  Inside a `_wgrad_block` it joins the block's grouped launch."""
     gw, acc = A.gradw(w, shape)
+    if _BLOCK is not None and _BLOCK[0] is A and alpha_dev is None and len(_BLOCK[1]) < 4:
+        _BLOCK[1].append((dy, x, gw, gb, acc))
+        return
     ops.linear_wgrad_async(dy, x, gw, alpha_dev=alpha_dev, gb=gb, accumulate=acc)
 
 
@@ -110,9 +161,19 @@ class VitBlockFn(torch.autograd.Function):
         hd = D // heads
         dx2 = dx2.contiguous()
         fc1, fc2, proj, qk = blk.mlp.fc1, blk.mlp.fc2, blk.attn.proj, blk.attn.qkv
+        with _wgrad_block(A):
+            dx = VitBlockFn._backward_body(ctx, dx2, A, G, D, hd, fc1, fc2, proj, qk)
+        ctx.s = None
+        return (dx,) + _none(5)
+
+    @staticmethod
+    def _backward_body(ctx, dx2, A, G, D, hd, fc1, fc2, proj, qk):
+        x, mean1, rstd1, h, qkv, a, lse, x1, mean2, rstd2, h2, pre, u = ctx.s
+        blk, m, B, T, heads = ctx.cfg
         _wgrad(A, dx2, u, fc2.weight, gb=G(fc2.bias))
         dpre = ops.linear_dgrad(dx2, A.w(fc2.weight), gmul=pre)
         _wgrad(A, dpre, h2, fc1.weight, gb=G(fc1.bias))
+        _wgrad_flush()
         dh2 = ops.linear_dgrad(dpre, A.w(fc1.weight))
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), dres=dx2)
         A.ready(fc2.weight, fc2.bias, fc1.weight, fc1.bias, blk.norm2.weight, blk.norm2.bias)
@@ -127,8 +188,7 @@ class VitBlockFn(torch.autograd.Function):
         dh = ops.linear_dgrad(dqkv, A.w(qk.weight))
         dx = ops.layernorm_bwd(dh, x, mean1, rstd1, blk.norm1.weight.data, G(blk.norm1.weight), G(blk.norm1.bias), dres=dx1)
         A.ready(proj.weight, proj.bias, qk.weight, qk.bias, blk.norm1.weight, blk.norm1.bias)
-        ctx.s = None
-        return (dx,) + _none(5)
+        return dx
 
 
 # =============================================================================================
@@ -417,6 +477,7 @@ def _ffn_bwd(m, rec, dout, ph):
     _wgrad(A, dy, u, out.dense.weight, gb=G(out.dense.bias))
     dpre = ops.linear_dgrad(dy, A.w(out.dense.weight), gmul=pre)
     _wgrad(A, dpre, x, inter.dense.weight, gb=G(inter.dense.bias))
+    _wgrad_flush()
     dx = ops.linear_dgrad(dpre, A.w(inter.dense.weight), residual=dz)
     A.ready(ln.weight, ln.bias, out.dense.weight, out.dense.bias, inter.dense.weight, inter.dense.bias)
     return dx
@@ -434,8 +495,9 @@ class BertLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do):
         tape, m, B, S, key_mask, pa, ph = ctx.s
-        da = _ffn_bwd(m, tape[1], do.contiguous(), ph)
-        dh = _self_attn_bwd(m, tape[0], da, B, S, key_mask, pa, ph)
+        with _wgrad_block(m.arena):
+            da = _ffn_bwd(m, tape[1], do.contiguous(), ph)
+            dh = _self_attn_bwd(m, tape[0], da, B, S, key_mask, pa, ph)
         ctx.s = None
         return (dh,) + _none(7)
 

@@ -125,6 +125,41 @@ def linear_wgrad(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None, accumulate=True)
          accumulate=bool(accumulate), split_k=_split_k(N, K, M, dy.dtype), rowsum=gb)
 
 
+WGRAD_GROUP = __import__("os").environ.get("ECAMP_WGRAD_GROUP", "1") != "0"   # one launch per transformer block for its weight gradients
+
+
+def wgrad_group_supported(items):
+    """items: [(dy, x, gw, gb or None, accumulate)] -- can they run as one grouped launch (same row count, bf16, aligned shapes)?"""
+    if not WGRAD_GROUP or not 1 <= len(items) <= 4:
+        return False
+    rows = items[0][0].shape[0]
+    for dy, x, gw, gb, _ in items:
+        if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.shape[0] != rows or x.shape[0] != rows:
+            return False
+        if not (dy.is_contiguous() and x.is_contiguous() and gw.is_contiguous() and gw.dtype == torch.float32):
+            return False
+    n = len(items)
+    no = (ctypes.c_int64 * n)(*[it[0].shape[1] for it in items])
+    ki = (ctypes.c_int64 * n)(*[it[1].shape[1] for it in items])
+    return bool(_lib.load().ecamp_wgrad_group_supported(n, ctypes.cast(no, ctypes.c_void_p), ctypes.cast(ki, ctypes.c_void_p), rows))
+
+
+def wgrad_group(items, alpha=1.0, alpha_dev=None):
+    """gw_p [N_p, K_p] (f32) (+)= alpha * dy_p^T x_p and gb_p += alpha * column sums of dy_p for every (dy, x, gw, gb, accumulate) of
+    `items` in ONE persistent launch + one reduce (ecamp_wgrad_group): the weight gradients of one transformer block."""
+    n = len(items)
+    rows = items[0][0].shape[0]
+    no = (ctypes.c_int64 * n)(*[it[0].shape[1] for it in items])
+    ki = (ctypes.c_int64 * n)(*[it[1].shape[1] for it in items])
+    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts])
+    dyp, xp, gwp, gbp = vp([it[0] for it in items]), vp([it[1] for it in items]), vp([it[2] for it in items]), vp([it[3] for it in items])
+    acc = (ctypes.c_int32 * n)(*[1 if it[4] else 0 for it in items])
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    nws = int(_lib.load().ecamp_wgrad_group_workspace_bytes(n, cv(no), cv(ki), rows)) // 4
+    ws = torch.empty((nws,), device=items[0][0].device, dtype=torch.float32)
+    call("ecamp_wgrad_group", n, cv(dyp), cv(xp), cv(gwp), cv(gbp), cv(no), cv(ki), rows, float(alpha), ptr(alpha_dev), cv(acc), ptr(ws), stream())
+
+
 def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):
     """out[N] (f32) += alpha * sum_m x[m, :]  (optionally only rows with lo <= m % period < hi)."""
     _chk(x, out)
@@ -436,6 +471,26 @@ def branch_stream(device):
     if st is None:
         st = _side[key] = torch.cuda.Stream(device=device)
     return st
+
+
+def wgrad_group_async(items):
+    """wgrad_group on the weight-gradient side stream (see linear_wgrad_async)."""
+    if not OVERLAP_WGRAD:
+        return wgrad_group(items)
+    dev = items[0][0].device
+    st = side_stream(dev)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        wgrad_group(items)
+    for dy, x, _, _, _ in items:
+        dy.record_stream(st)
+        x.record_stream(st)
+    if not _side.get("cb"):
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+            _side["cb"] = True
+        except RuntimeError:  # not inside a backward pass: join immediately
+            _join_side()
 
 
 def linear_wgrad_async(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None, accumulate=True):

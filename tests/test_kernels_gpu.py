@@ -827,3 +827,39 @@ def test_gemm_wgrad_contraction_past_2gb_is_split(dev):
     assert (gw[cols] - ref).abs().max() < 2e-3 * ref.abs().max()
     refb = dy[:, cols].float().sum(0)
     assert (gb[cols] - refb).abs().max() < 2e-3 * refb.abs().max() + 1e-2
+
+
+@pytest.mark.parametrize("rows,shapes", [(1280, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+                                         (2560, [(1000, 520), (264, 264), (520, 1000)]),
+                                         (12800, [(2304, 768), (768, 768), (3072, 768), (768, 3072)])])
+def test_wgrad_group_matches_per_layer_weight_gradients(dev, rows, shapes):
+    """ecamp_wgrad_group (the weight and bias gradients of a block's linear layers as ONE item-table launch of the Q8 kernel + one
+    grouped reduce) against the per-layer GEMMs: K ranges cut across tile boundaries, ragged output shapes, overwrite and accumulate,
+    layers with and without a bias, and the production shapes of one encoder block."""
+    o = ops()
+    gen_ = torch.Generator().manual_seed(rows)
+    items, refs = [], []
+    for i, (n_out, k_in) in enumerate(shapes):
+        dy = (torch.randn(rows, n_out, generator=gen_) * 0.5).to(dev, torch.bfloat16)
+        x = torch.randn(rows, k_in, generator=gen_).to(dev, torch.bfloat16)
+        acc = i % 2 == 1
+        base = torch.randn(n_out, k_in, generator=gen_).to(dev) if acc else torch.zeros(n_out, k_in, device=dev)
+        gw, gw_ref = base.clone(), base.clone()
+        bias = i != 1
+        gb, gb_ref = (torch.ones(n_out, device=dev), torch.ones(n_out, device=dev)) if bias else (None, None)
+        o.linear_wgrad(dy, x, gw_ref, gb=gb_ref, accumulate=acc)
+        items.append((dy, x, gw, gb, acc))
+        refs.append((gw_ref, gb_ref))
+    assert o.wgrad_group_supported(items)
+    o.wgrad_group(items)
+    torch.cuda.synchronize()
+    for (dy, x, gw, gb, acc), (gw_ref, gb_ref) in zip(items, refs):
+        scale = gw_ref.abs().max()
+        assert (gw - gw_ref).abs().max() < 1e-4 * scale + 1e-3, (gw - gw_ref).abs().max()
+        if gb is not None:
+            assert (gb - gb_ref).abs().max() < 1e-3 * gb_ref.abs().max() + 1e-2
+    # a second call accumulates on top of the first where asked to and overwrites elsewhere
+    o.wgrad_group(items)
+    for (dy, x, gw, gb, acc), (gw_ref, gb_ref) in zip(items, refs):
+        o.linear_wgrad(dy, x, gw_ref, gb=gb_ref, accumulate=acc)
+        assert (gw - gw_ref).abs().max() < 1e-4 * gw_ref.abs().max() + 1e-3
