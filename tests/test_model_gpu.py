@@ -505,3 +505,34 @@ def test_fp8_forward_mode_tracks_bf16(dev):
     assert d0.max() < 2e-2 and d1.max() < 3e-2 and cos > 0.98
     with pytest.raises(ValueError):
         me.ecamp(compute_dtype=torch.float32, fp8_forward=True)
+
+
+def test_grouped_and_per_layer_weight_gradients_agree_at_model_level_bf16(dev):
+    """Full-size step (B=256): the gradient arena with the weight gradients issued as grouped launches (ecamp_wgrad_group, the default)
+    against the same backward with one GEMM per linear layer -- same inputs, dropout off; only the f32 summation order differs."""
+    from ecamp_amd import hip_ops
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    torch.manual_seed(0)
+    model = me.ecamp(compute_dtype=torch.bfloat16).to(dev)
+    model.eval()
+    B, S = 256, 128
+    batch = synthetic_batch(B, S, 448, seed=13, device=dev)
+    noise = torch.rand(B, 196, generator=torch.Generator().manual_seed(7)).to(dev)
+    arena = model.prepare()
+    grads = []
+    old = hip_ops.WGRAD_GROUP
+    try:
+        for flag in (True, False):
+            hip_ops.WGRAD_GROUP = flag
+            arena.flat_g.zero_()
+            sum(model(batch, noise=noise)).backward()
+            torch.cuda.synchronize()
+            grads.append(arena.flat_g.clone())
+    finally:
+        hip_ops.WGRAD_GROUP = old
+    num = float((grads[0] - grads[1]).double().norm())
+    den = float(grads[1].double().norm())
+    worst = float((grads[0] - grads[1]).abs().max() / grads[1].abs().max())
+    print("grouped vs per-layer gradients: rel l2 %.3e, worst element / max %.3e" % (num / den, worst))
+    assert num / den < 1e-5 and worst < 1e-4
