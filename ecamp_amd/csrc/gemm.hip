@@ -1334,7 +1334,7 @@ static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, c
 // launches), with 192 they do not (39.4-39.9 against 39.7-40.1 on the same boxes; 160: +0.6 ms, 64: +4 ms).  ECAMP_WGRAD_GROUP_CUS overrides.
 static int wg_ncu() {
     static const int env = getenv("ECAMP_WGRAD_GROUP_CUS") ? atoi(getenv("ECAMP_WGRAD_GROUP_CUS")) : 0;
-    if (env > 0) return env;
+    if (env > 0) return env < p8_num_cu() ? env : p8_num_cu();   // (the workspace is sized for at most one workgroup per CU)
     int ncu = p8_num_cu();
     if (g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;
     const int q = p8_num_cu() * 3 / 4;
