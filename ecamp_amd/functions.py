@@ -26,7 +26,7 @@ def _none(n):
     return (None,) * n
 
 
-_BLOCK = None   # [arena, [(dy, x, gw, gb, accumulate)], [parameters reported ready]] while a block's backward collects its weight gradients
+_BLOCK = None   # [arena, [(dy, x, gw, gb, accumulate)], [parameters reported ready], first group issued] while a block's backward collects its weight gradients
 
 
 class _wgrad_block:
@@ -40,7 +40,7 @@ class _wgrad_block:
 
     def __enter__(self):
         global _BLOCK
-        self.prev, _BLOCK = _BLOCK, [self.arena, [], []]
+        self.prev, _BLOCK = _BLOCK, [self.arena, [], [], False]
         self._ready = self.arena.ready
         self.arena.ready = lambda *ps, _b=_BLOCK: _b[2].extend(ps)
         return self
@@ -64,14 +64,8 @@ def _issue(items):
             ops.linear_wgrad_async(dy, x, gw, gb=gb, accumulate=acc)
 
 
-_GROUP_SIZE = int(__import__("os").environ.get("ECAMP_WGRAD_GROUP_SIZE", "2"))   # layers per grouped launch (2: MLP pair, then attention pair; 4: whole block)
-
-
-def _wgrad_flush():
-    """Issue what the current block has collected so far (a block may be cut into two grouped launches)."""
-    if _BLOCK is not None and _BLOCK[1] and len(_BLOCK[1]) >= _GROUP_SIZE:
-        _issue(_BLOCK[1])
-        del _BLOCK[1][:]
+_FIRST_GROUP = int(__import__("os").environ.get("ECAMP_WGRAD_GROUP_SIZE", "2"))   # layers in a block's first launch, issued as soon as they
+# are collected (1: the first layer alone, 2: the MLP pair, 4: nothing early); the rest of the block goes out when its backward has been queued
 
 
 def _wgrad(A, dy, x, w, gb=None, alpha_dev=None, shape=None):
@@ -81,6 +75,10 @@ def _wgrad(A, dy, x, w, gb=None, alpha_dev=None, shape=None):
     gw, acc = A.gradw(w, shape)
     if _BLOCK is not None and _BLOCK[0] is A and alpha_dev is None and len(_BLOCK[1]) < 4:
         _BLOCK[1].append((dy, x, gw, gb, acc))
+        if not _BLOCK[3] and len(_BLOCK[1]) == _FIRST_GROUP:
+            _BLOCK[3] = True
+            _issue(_BLOCK[1])
+            del _BLOCK[1][:]
         return
     ops.linear_wgrad_async(dy, x, gw, alpha_dev=alpha_dev, gb=gb, accumulate=acc)
 
@@ -173,7 +171,6 @@ class VitBlockFn(torch.autograd.Function):
         _wgrad(A, dx2, u, fc2.weight, gb=G(fc2.bias))
         dpre = ops.linear_dgrad(dx2, A.w(fc2.weight), gmul=pre)
         _wgrad(A, dpre, h2, fc1.weight, gb=G(fc1.bias))
-        _wgrad_flush()
         dh2 = ops.linear_dgrad(dpre, A.w(fc1.weight))
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), dres=dx2)
         A.ready(fc2.weight, fc2.bias, fc1.weight, fc1.bias, blk.norm2.weight, blk.norm2.bias)
@@ -477,7 +474,6 @@ def _ffn_bwd(m, rec, dout, ph):
     _wgrad(A, dy, u, out.dense.weight, gb=G(out.dense.bias))
     dpre = ops.linear_dgrad(dy, A.w(out.dense.weight), gmul=pre)
     _wgrad(A, dpre, x, inter.dense.weight, gb=G(inter.dense.bias))
-    _wgrad_flush()
     dx = ops.linear_dgrad(dpre, A.w(inter.dense.weight), residual=dz)
     A.ready(ln.weight, ln.bias, out.dense.weight, out.dense.bias, inter.dense.weight, inter.dense.bias)
     return dx
