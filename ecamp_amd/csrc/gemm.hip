@@ -1362,7 +1362,7 @@ extern "C" int64_t ecamp_wgrad_group_workspace_bytes(int32_t n, const int64_t* n
 // dy[p] [rows, n_out[p]], x[p] [rows, k_in[p]] bf16, row-contiguous.  accumulate[p] = 0 overwrites gw[p].
 extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* const* x, float* const* gw, float* const* gb, const int64_t* n_out,
                                  const int64_t* k_in, int64_t rows, float alpha, const float* alpha_dev, const int32_t* accumulate, float* ws,
-                                 hipStream_t stream) {
+                                 int32_t workgroups, hipStream_t stream) {
     ECAMP_CHECK_ARG(dy && x && gw && gb && n_out && k_in && accumulate && ws, "wgrad_group: null pointer");
     ECAMP_CHECK_ARG(ecamp_wgrad_group_supported(n, n_out, k_in, rows), "wgrad_group: unsupported group (1-4 layers, rows %% 128 == 0, dims %% 8 == 0, < 2 GB operands)");
     unsigned hb[4] = {0, 0, 0, 0};
@@ -1373,7 +1373,9 @@ extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* c
         hb[p] = gb[p] ? 1u : 0u;
         any_bias = any_bias || gb[p];
     }
-    const WgPlan* pl = wg_plan(n, n_out, k_in, hb, rows, wg_ncu());
+    int nwg = wg_ncu();
+    if (workgroups > 0) nwg = workgroups < p8_num_cu() ? workgroups : p8_num_cu();   // caller's choice (how much of the chip to leave to what runs beside it)
+    const WgPlan* pl = wg_plan(n, n_out, k_in, hb, rows, nwg);
     ECAMP_CHECK_ARG(pl != nullptr, "wgrad_group: could not build the item table");
     Q8Group G;
     memset(&G, 0, sizeof(G));

@@ -63,38 +63,57 @@ class DevicePrefetcher:
     def __len__(self):
         return len(self.loader)
 
+    NBUF = 3   # staging slots: batch i+1 is copied while step i computes; a slot is overwritten two steps after its batch was consumed
+
     def __iter__(self):
         dev = self.device
         side = torch.cuda.Stream(device=dev)
+        # Fixed staging slots instead of a fresh device tensor per batch: with per-batch allocations the caching allocator decides,
+        # from how far the host happens to run ahead of the GPU, whether a 616 MB block is free or has to be hipMalloc'ed inside a
+        # training step (seen as sporadic 200 ms stalls in bench.py's timed region).  A slot is reused only after the step that
+        # consumed its previous batch has finished on the compute stream (event wait on the copy stream: no host synchronisation).
+        slots = [dict() for _ in range(self.NBUF)]
+        done = [None] * self.NBUF
 
-        def stage(batch):
+        def stage(batch, s):
+            out, todo = {}, []
+            for k, v in batch.items():
+                if torch.is_tensor(v) and v.device.type == "cpu":
+                    if not v.is_pinned():
+                        v = v.pin_memory()
+                    dst = slots[s].get(k)
+                    if dst is None or dst.shape != v.shape or dst.dtype != v.dtype:   # (owned by the compute stream's pool: that is where it is read)
+                        dst = slots[s][k] = torch.empty(v.shape, dtype=v.dtype, device=dev)
+                        side.wait_stream(torch.cuda.current_stream(dev))
+                    todo.append((dst, v))
+                    out[k] = dst
+                else:
+                    out[k] = v
             with torch.cuda.stream(side):
-                out = {}
-                for k, v in batch.items():
-                    if torch.is_tensor(v) and v.device.type == "cpu":
-                        if not v.is_pinned():
-                            v = v.pin_memory()
-                        out[k] = v.to(dev, non_blocking=True)
-                    else:
-                        out[k] = v
+                if done[s] is not None:
+                    side.wait_event(done[s])
+                for dst, v in todo:
+                    dst.copy_(v, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(side)
             return out, ev
 
         it = iter(self.loader)
         try:
-            nxt = stage(next(it))
+            nxt = stage(next(it), 0)
         except StopIteration:
             return
+        i = 0
         while nxt is not None:
             cur, ev = nxt
             try:
-                nxt = stage(next(it))
+                nxt = stage(next(it), (i + 1) % self.NBUF)
             except StopIteration:
                 nxt = None
             main = torch.cuda.current_stream(dev)
             main.wait_event(ev)
-            for v in cur.values():
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(main)   # allocated on the side stream, consumed on the compute stream
             yield cur
+            # the consumer has queued the whole step on the compute stream by the time it asks for the next batch
+            done[i % self.NBUF] = torch.cuda.Event()
+            done[i % self.NBUF].record(torch.cuda.current_stream(dev))
+            i += 1

@@ -56,9 +56,9 @@ class _wgrad_block:
         return False
 
 
-def _issue(items):
+def _issue(items, workgroups=0):
     if len(items) >= 2 and ops.wgrad_group_supported(items):
-        ops.wgrad_group_async(items)
+        ops.wgrad_group_async(items, workgroups=workgroups)
     else:
         for dy, x, gw, gb, acc in items:
             ops.linear_wgrad_async(dy, x, gw, gb=gb, accumulate=acc)

@@ -144,7 +144,7 @@ def wgrad_group_supported(items):
     return bool(_lib.load().ecamp_wgrad_group_supported(n, ctypes.cast(no, ctypes.c_void_p), ctypes.cast(ki, ctypes.c_void_p), rows))
 
 
-def wgrad_group(items, alpha=1.0, alpha_dev=None):
+def wgrad_group(items, alpha=1.0, alpha_dev=None, workgroups=0):
     """gw_p [N_p, K_p] (f32) (+)= alpha * dy_p^T x_p and gb_p += alpha * column sums of dy_p for every (dy, x, gw, gb, accumulate) of
     `items` in ONE persistent launch + one reduce (ecamp_wgrad_group): the weight gradients of one transformer block."""
     n = len(items)
@@ -157,7 +157,7 @@ def wgrad_group(items, alpha=1.0, alpha_dev=None):
     cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
     nws = int(_lib.load().ecamp_wgrad_group_workspace_bytes(n, cv(no), cv(ki), rows)) // 4
     ws = torch.empty((nws,), device=items[0][0].device, dtype=torch.float32)
-    call("ecamp_wgrad_group", n, cv(dyp), cv(xp), cv(gwp), cv(gbp), cv(no), cv(ki), rows, float(alpha), ptr(alpha_dev), cv(acc), ptr(ws), stream())
+    call("ecamp_wgrad_group", n, cv(dyp), cv(xp), cv(gwp), cv(gbp), cv(no), cv(ki), rows, float(alpha), ptr(alpha_dev), cv(acc), ptr(ws), int(workgroups), stream())
 
 
 def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):
@@ -473,15 +473,15 @@ def branch_stream(device):
     return st
 
 
-def wgrad_group_async(items):
+def wgrad_group_async(items, workgroups=0):
     """wgrad_group on the weight-gradient side stream (see linear_wgrad_async)."""
     if not OVERLAP_WGRAD:
-        return wgrad_group(items)
+        return wgrad_group(items, workgroups=workgroups)
     dev = items[0][0].device
     st = side_stream(dev)
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
-        wgrad_group(items)
+        wgrad_group(items, workgroups=workgroups)
     for dy, x, _, _, _ in items:
         dy.record_stream(st)
         x.record_stream(st)

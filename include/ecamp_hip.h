@@ -51,12 +51,13 @@ int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc
  * model_ecamp.py:66-68,233-234, BertLayer at bert_layers.py): gw[p] [n_out[p], k_in[p]] (f32, contiguous) (+)= alpha * dy[p]^T x[p] and
  * gb[p] [n_out[p]] (f32, may be null) += alpha * column sums of dy[p], for the 1-4 linear layers of one block that share the row count
  * `rows` of dy[p] [rows, n_out[p]] / x[p] [rows, k_in[p]] (bf16, row-contiguous), as ONE persistent launch + one reduce.
- * accumulate[p] = 0 overwrites gw[p].  ws: ecamp_wgrad_group_workspace_bytes(...) bytes.  ecamp_wgrad_group_supported == 0: issue per-layer ecamp_gemm calls. */
+ * accumulate[p] = 0 overwrites gw[p].  ws: ecamp_wgrad_group_workspace_bytes(...) bytes.  workgroups: 0 = three quarters of the CUs
+ * (what is left runs whatever is queued beside it), otherwise at most one per CU.  ecamp_wgrad_group_supported == 0: issue per-layer ecamp_gemm calls. */
 int ecamp_wgrad_group_supported(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows);
 int64_t ecamp_wgrad_group_workspace_bytes(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows);
 int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* const* x, float* const* gw, float* const* gb, const int64_t* n_out,
                       const int64_t* k_in, int64_t rows, float alpha, const float* alpha_dev, const int32_t* accumulate, float* ws,
-                      ecampStream_t stream);
+                      int32_t workgroups, ecampStream_t stream);
 /* Workspace sizes (bytes) the caller allocates and passes in -- the library never allocates:
  *   ecamp_gemm_workspace_bytes      `splitk_ws` of ecamp_gemm for this split count (0 when split_k <= 1)
  *   ecamp_attn_bwd_workspace_bytes  `delta_ws` of ecamp_attn_bwd (one f32 per query row)
