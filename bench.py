@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ECAMP pre-training throughput on MI355X (the metric of BASELINE.json).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 10      (the defaults: SURVEY.md 8(d))
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one full optimizer-inclusive pre-training micro-step of configs[1]: ViT-B/16 MAE encoder/decoder + SR
@@ -9,8 +9,8 @@ head + reference BERT (6L/6H/1536, vocab 30000) with context fusion, B=256 pairs
 images resized on device), reports of S=128 tokens, bf16 activations / f32 master weights, train mode (dropout
 active), host->HBM copy of the batch + forward + backward + grad all-reduce (N>1) + grad-norm + fused AdamW + zero_grad
 (accum_iter=1).  The batch starts in pinned HOST memory (what a DataLoader with pin_memory hands over) and crosses PCIe inside
-the timed region, one step ahead on a copy stream (ecamp_amd.data.DevicePrefetcher; the pipeline runs through warm-up and timed steps
-alike, so each timed step issues one batch copy and consumes the one issued a step earlier): `value` is the PCIe-inclusive rate;
+the timed region on a copy stream, beside the previous step's kernels (ecamp_amd.data.DevicePrefetcher; the pipeline runs through
+warm-up and timed steps alike, each timed step issues and consumes its own batch copy): `value` is the PCIe-inclusive rate;
 `resident_pairs_per_s` (inputs already in HBM), forward-only and forward+backward-only rates are reported beside it.
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment launches its own N ranks (one child process per GPU,
@@ -94,15 +94,17 @@ def cpu_baseline(seq, budget_s=25.0):
         n += 1
     dt = time.time() - t0
     model, phys, logical = cpu_info()
-    # the other legs of BASELINE.md section 3 (B=32, S=256): one step each, no warm-up (bounded: the default run stays within minutes)
+    # the other legs of BASELINE.md section 3 (S=256 at B=8; B=32): 1 warm-up + 3 timed optimizer-inclusive steps each
     legs = []
     for b2, s2 in ((8, 256), (32, seq)):
         try:
             batch = recipe.recipe_batch(cfg, b2, s2, seed=1)
             B = b2
+            step(100)   # warm-up of this shape
             tl = time.time()
-            step(100)
-            legs.append({"B": b2, "S": s2, "pairs_per_s": round(b2 / (time.time() - tl), 4), "steps": 1})
+            for j in range(3):
+                step(101 + j)
+            legs.append({"B": b2, "S": s2, "pairs_per_s": round(3 * b2 / (time.time() - tl), 4), "steps": 3, "warmup": 1})
         except Exception as e:
             legs.append({"B": b2, "S": s2, "error": repr(e)})
     return {"value": round(8 * n / dt, 4), "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": model, "physical_cores": phys,
@@ -112,11 +114,72 @@ def cpu_baseline(seq, budget_s=25.0):
                       "thread count)" % (n, seq, torch.__version__, cores)}
 
 
+def launch_ranks(cmd, n, poll_s=0.2, grace_s=5.0, check_devices=True):
+    """Self-launch: `n` fresh child processes of `cmd`, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment), started BEFORE this process touches the GPU and never re-exec'ed.  The children are polled: when one exits
+    non-zero the others are terminated (they would otherwise sit in an RCCL collective until the driver's timeout), the parent says
+    which rank failed, shows the tail of its stderr and returns its code.  Returns 0 when every rank exited 0."""
+    import tempfile
+    if check_devices:
+        have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+        if have < n:
+            print("bench.py: --gpus %d but this box has %d visible GPU(s): nothing launched" % (n, have), file=sys.stderr)
+            return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    threads = max(1, (os.cpu_count() or n) // n)   # host threads per rank (pinning / copies / CPU-side torch ops): cores / N, not 256 each
+    procs, logs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("OMP_NUM_THREADS", str(min(threads, 32)))
+        log = tempfile.TemporaryFile(mode="w+")
+        logs.append(log)
+        procs.append(subprocess.Popen(cmd, env=env, stderr=log))
+    failed = None
+    while failed is None:
+        codes = [pr.poll() for pr in procs]
+        for r, c in enumerate(codes):
+            if c is not None and c != 0:
+                failed = (r, c)
+                break
+        if failed is None and all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        t_end = time.time() + grace_s
+        for pr in procs:
+            try:
+                pr.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+    for r, log in enumerate(logs):   # pass the children's stderr on (rank 0's warnings included), the failed rank's last
+        if failed is not None and r == failed[0]:
+            continue
+        log.seek(0)
+        sys.stderr.write(log.read())
+    if failed is not None:
+        r, c = failed
+        logs[r].seek(0)
+        tail = logs[r].read().splitlines()[-25:]
+        print("bench.py: rank %d of %d exited with code %d; the other ranks were terminated.  Its stderr (tail):" % (r, n, c), file=sys.stderr)
+        for line in tail:
+            print("  [rank %d] %s" % (r, line), file=sys.stderr)
+        return abs(c) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)   # SURVEY 8(d): >= 50 timed steps after 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU (configs[1] = 256)")
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -126,20 +189,7 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
-        # self-launch: one fresh child process per GPU, BEFORE anything here initialises the GPU (never re-exec a process that has)
-        sock = socket.socket()
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-        sock.close()
-        procs = []
-        for r in range(args.gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-        rc = 0
-        for pr in procs:
-            rc = max(rc, abs(pr.wait()))
-        raise SystemExit(rc)
+        raise SystemExit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -192,10 +242,10 @@ def main():
             dist.barrier()
         return time.perf_counter() - t0
 
-    # ONE prefetch pipeline across warm-up and timed steps, as in a training run: taking batch i out of it issues the copy of batch
-    # i+1, so each of the K timed steps carries exactly one host->HBM batch copy (the copy of the first timed batch was issued by the
-    # last warm-up step, the last timed step issues one for a batch that is never consumed: K copies inside the region either way).
-    pipeline = iter(DevicePrefetcher([host_batch] * (args.warmup + args.steps + 1), dev))
+    # ONE prefetch pipeline across warm-up and timed steps, as in a training run: asking it for batch i (after step i-1 has been
+    # queued) issues the copy of batch i on the copy stream, where it runs beside the GPU's step i-1.  Each of the K timed steps
+    # carries exactly its own host->HBM batch copy; the first one has no earlier step to hide behind (the clock starts on an idle GPU).
+    pipeline = iter(DevicePrefetcher([host_batch] * (args.warmup + args.steps), dev))
 
     def run_inclusive(n):
         nonlocal out
@@ -203,14 +253,28 @@ def main():
             out = step(next(pipeline))
 
     out = None
+    if world > 1:
+        net.reducer.timing = True   # event pairs around every bucket's all-reduce on the communication stream (the `rccl` record)
     if args.warmup > 0:
         run_inclusive(args.warmup)   # untimed warm-up on the SAME path: the caching allocator settles on its staging blocks
     lib = _lib.load()
+    if world > 1:
+        net.reducer.comm_ms()   # drop the warm-up's records
     dt = timed(run_inclusive, args.steps)          # THE metric: K steps, host batch -> HBM inside
+    rccl = None
+    if world > 1:
+        red = net.reducer
+        rccl = {"world": world, "backend": dist.get_backend(), "buckets": len(red.buckets), "bucket_mb": round(max(hi - lo for lo, hi, _ in red.buckets) * 4 / 2 ** 20, 1),
+                "payload_mb_per_step": round(red.flat_g.numel() * 4 / 2 ** 20, 1), "op": "AVG" if red.use_avg else "SUM+div",
+                "p8_wgrad_reserve_cus": int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")),
+                "allreduce_ms_per_step": round(red.comm_ms() / args.steps, 3),
+                "note": "all-reduce of the f32 gradient arena in buckets on a side HIP stream, overlapped with backward; ms = sum of the "
+                        "buckets' event-bracketed durations on that stream on rank 0 (they overlap compute, so this is not added step time)"}
+        red.timing = False
     if args.only_value:
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": round(args.batch * world * args.steps / dt, 2), "unit": "pairs/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "rccl": rccl,
                               "note": "--only-value: side measurements, roofline pass and CPU baseline skipped"}))
         if world > 1:
             dist.destroy_process_group()
@@ -280,6 +344,8 @@ def main():
                "resident_pairs_per_s": round(args.batch * world / dt_res, 2), "resident_ms_per_step": round(1e3 * dt_res, 3),
                "fwd_only_ms": round(1e3 * dt_fwd, 3), "fwd_only_pairs_per_s": round(args.batch * world / dt_fwd, 2),
                "fwd_bwd_ms": round(1e3 * dt_fb, 3), "fwd_bwd_pairs_per_s": round(args.batch * world / dt_fb, 2)}
+        if rccl is not None:
+            res["rccl"] = rccl
         if not args.no_prof:
             ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
             cat = 0 if args.dtype == "bf16" else 1

@@ -1281,11 +1281,16 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgRedArgs a) {
     }
 }
 
+// The item table of a group is pure host arithmetic on the shapes; it lives in a host-side cache here and in a device buffer the
+// CALLER owns (ecamp_wgrad_group_table fills a host image the caller uploads once per shape set): the library never allocates
+// device memory and never synchronises -- ecamp_wgrad_group only enqueues two kernels, so it can be captured into a HIP graph.
+// Image layout: items [nitems] (32 B each) | wg_first [nwg + 1] int32, padded to 32 B | tiles [ntiles] (20 B each).
 struct WgPlan {
-    Q8ItemRec* d_items = nullptr;
-    int* d_first = nullptr;
-    WgTile* d_tiles = nullptr;
+    std::vector<Q8ItemRec> items;
+    std::vector<int> first;
+    std::vector<WgTile> tiles;
     int nitems = 0, nwg = 0, ntiles = 0;
+    size_t off_first = 0, off_tiles = 0, bytes = 0;
 };
 static std::map<std::string, WgPlan> g_wg_plans;
 
@@ -1295,7 +1300,8 @@ static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, c
     auto it = g_wg_plans.find(key);
     if (it != g_wg_plans.end()) return &it->second;
     const long KT = (rows + 63) / 64;
-    std::vector<WgTile> tiles;
+    WgPlan pl;
+    std::vector<WgTile>& tiles = pl.tiles;
     for (int p = 0; p < n; ++p)
         for (int mb = 0; mb < ceil_div(n_out[p], 256); ++mb)
             for (int nb = 0; nb < ceil_div(k_in[p], 256); ++nb) tiles.push_back({p, mb * 256, nb * 256, 0, 0});
@@ -1303,8 +1309,8 @@ static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, c
     long q = (units + ncu - 1) / ncu;
     q += q & 1;                                   // even quota, even KT (rows % 128 == 0): every piece has >= 2 K tiles
     if (q < 2) q = 2;
-    std::vector<Q8ItemRec> items;
-    std::vector<int> first;
+    std::vector<Q8ItemRec>& items = pl.items;
+    std::vector<int>& first = pl.first;
     long u = 0;
     while (u < units) {
         first.push_back((int)items.size());
@@ -1320,14 +1326,11 @@ static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, c
         }
     }
     first.push_back((int)items.size());
-    WgPlan pl;
     pl.nitems = (int)items.size(); pl.nwg = (int)first.size() - 1; pl.ntiles = (int)tiles.size();
-    if (hipMalloc(&pl.d_items, items.size() * sizeof(Q8ItemRec)) != hipSuccess || hipMalloc(&pl.d_first, first.size() * sizeof(int)) != hipSuccess ||
-        hipMalloc(&pl.d_tiles, tiles.size() * sizeof(WgTile)) != hipSuccess) return nullptr;
-    if (hipMemcpy(pl.d_items, items.data(), items.size() * sizeof(Q8ItemRec), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(pl.d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(pl.d_tiles, tiles.data(), tiles.size() * sizeof(WgTile), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    return &(g_wg_plans[key] = pl);
+    pl.off_first = items.size() * sizeof(Q8ItemRec);
+    pl.off_tiles = pl.off_first + (first.size() * sizeof(int) + 31) / 32 * 32;
+    pl.bytes = pl.off_tiles + tiles.size() * sizeof(WgTile);
+    return &(g_wg_plans[key] = std::move(pl));
 }
 // Workgroups of the grouped launch: three quarters of the CUs.  It runs beside the data-gradient chain of the next block; with one
 // workgroup on every CU that chain's kernels wait for whole 250-us items (39.7-39.9 ms per step against 39.4 with per-layer
@@ -1358,12 +1361,43 @@ extern "C" int64_t ecamp_wgrad_group_workspace_bytes(int32_t n, const int64_t* n
     for (int p = 0; p < n; ++p) tiles += (long)ceil_div(n_out[p], 256) * ceil_div(k_in[p], 256);
     return (tiles + p8_num_cu() + 1) * 262144;    // every workgroup boundary adds at most one piece
 }
+static long g_wg_launches = 0;
+extern "C" int64_t ecamp_wgrad_group_launches(void) { return g_wg_launches; }
+// workgroups a grouped launch will use for the caller's `workgroups` argument (0 = the library's choice): part of the table's identity
+extern "C" int ecamp_wgrad_group_workgroups(int32_t workgroups) {
+    if (workgroups > 0) return workgroups < p8_num_cu() ? workgroups : p8_num_cu();
+    return wg_ncu();
+}
+// upper bound of the item-table image for any workgroup count (0: group not supported)
+extern "C" int64_t ecamp_wgrad_group_table_bytes(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows) {
+    if (!ecamp_wgrad_group_supported(n, n_out, k_in, rows)) return 0;
+    long tiles = 0;
+    for (int p = 0; p < n; ++p) tiles += (long)ceil_div(n_out[p], 256) * ceil_div(k_in[p], 256);
+    const long ncu = p8_num_cu();
+    return (tiles + ncu + 1) * (long)sizeof(Q8ItemRec) + ((ncu + 2) * 4 + 31) / 32 * 32 + tiles * (long)sizeof(WgTile) + 64;
+}
+// fills `host_table` (HOST memory, ecamp_wgrad_group_table_bytes bytes) with the item table of this group for
+// ecamp_wgrad_group_workgroups(workgroups) workgroups; returns the bytes used (< 0: error).  has_bias[p] != 0: gb[p] will be given.
+extern "C" int64_t ecamp_wgrad_group_table(int32_t n, const int64_t* n_out, const int64_t* k_in, const int32_t* has_bias, int64_t rows,
+                                           int32_t workgroups, void* host_table) {
+    if (!n_out || !k_in || !has_bias || !host_table || !ecamp_wgrad_group_supported(n, n_out, k_in, rows))
+        return ecamp_set_error(-1, "wgrad_group_table: unsupported group or null pointer");
+    unsigned hb[4] = {0, 0, 0, 0};
+    for (int p = 0; p < n; ++p) hb[p] = has_bias[p] ? 1u : 0u;
+    const WgPlan* pl = wg_plan(n, n_out, k_in, hb, rows, ecamp_wgrad_group_workgroups(workgroups));
+    char* out = (char*)host_table;
+    memcpy(out, pl->items.data(), pl->items.size() * sizeof(Q8ItemRec));
+    memcpy(out + pl->off_first, pl->first.data(), pl->first.size() * sizeof(int));
+    memcpy(out + pl->off_tiles, pl->tiles.data(), pl->tiles.size() * sizeof(WgTile));
+    return (int64_t)pl->bytes;
+}
 // gw[p] [n_out[p], k_in[p]] (f32, contiguous) (+)= alpha * dy[p]^T x[p];  gb[p] [n_out[p]] (f32 or null) += alpha * column sums of dy[p].
 // dy[p] [rows, n_out[p]], x[p] [rows, k_in[p]] bf16, row-contiguous.  accumulate[p] = 0 overwrites gw[p].
 extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* const* x, float* const* gw, float* const* gb, const int64_t* n_out,
                                  const int64_t* k_in, int64_t rows, float alpha, const float* alpha_dev, const int32_t* accumulate, float* ws,
-                                 int32_t workgroups, hipStream_t stream) {
-    ECAMP_CHECK_ARG(dy && x && gw && gb && n_out && k_in && accumulate && ws, "wgrad_group: null pointer");
+                                 const void* table, int32_t workgroups, hipStream_t stream) {
+    ECAMP_CHECK_ARG(dy && x && gw && gb && n_out && k_in && accumulate && ws && table, "wgrad_group: null pointer");
+    ECAMP_CHECK_ARG(((uintptr_t)table & 31) == 0, "wgrad_group: the item table must be 32-byte aligned");
     ECAMP_CHECK_ARG(ecamp_wgrad_group_supported(n, n_out, k_in, rows), "wgrad_group: unsupported group (1-4 layers, rows %% 128 == 0, dims %% 8 == 0, < 2 GB operands)");
     unsigned hb[4] = {0, 0, 0, 0};
     bool any_bias = false;
@@ -1373,16 +1407,15 @@ extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* c
         hb[p] = gb[p] ? 1u : 0u;
         any_bias = any_bias || gb[p];
     }
-    int nwg = wg_ncu();
-    if (workgroups > 0) nwg = workgroups < p8_num_cu() ? workgroups : p8_num_cu();   // caller's choice (how much of the chip to leave to what runs beside it)
-    const WgPlan* pl = wg_plan(n, n_out, k_in, hb, rows, nwg);
-    ECAMP_CHECK_ARG(pl != nullptr, "wgrad_group: could not build the item table");
+    const int nwg = ecamp_wgrad_group_workgroups(workgroups);   // caller's choice (how much of the chip to leave to what runs beside it) or the default
+    const WgPlan* pl = wg_plan(n, n_out, k_in, hb, rows, nwg);   // host arithmetic (cached): counts and offsets of the caller's device image
+    const char* tb = (const char*)table;
     Q8Group G;
     memset(&G, 0, sizeof(G));
-    G.items = pl->d_items; G.wg_first = pl->d_first; G.slabs = ws; G.nprob = n;
+    G.items = (const Q8ItemRec*)tb; G.wg_first = (const int*)(tb + pl->off_first); G.slabs = ws; G.nprob = n;
     WgRedArgs R;
     memset(&R, 0, sizeof(R));
-    R.tiles = pl->d_tiles; R.slabs = ws; R.ntiles = pl->ntiles;
+    R.tiles = (const WgTile*)(tb + pl->off_tiles); R.slabs = ws; R.ntiles = pl->ntiles;
     for (int p = 0; p < n; ++p) {
         G.p[p].A = dy[p]; G.p[p].B = x[p]; G.p[p].lda = n_out[p]; G.p[p].ldb = k_in[p]; G.p[p].M = (int)n_out[p]; G.p[p].N = (int)k_in[p];
         G.p[p].rowsum = gb[p]; G.p[p].alpha_out = alpha; G.p[p].alpha_dev_out = alpha_dev;
@@ -1407,6 +1440,7 @@ extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* c
     if (any_bias) hipLaunchKernelGGL(gemm_bf16_q8_items_kernel<true>, dim3(pl->nwg), dim3(512), shm, stream, g, G);
     else hipLaunchKernelGGL(gemm_bf16_q8_items_kernel<false>, dim3(pl->nwg), dim3(512), shm, stream, g, G);
     g_q8_launches += n;
+    ++g_wg_launches;
     hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(pl->ntiles * 16), dim3(256), 0, stream, R);
     if (prof) ecamp_prof_end(stream);
     ECAMP_LAUNCH_CHECK();

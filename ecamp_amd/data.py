@@ -100,20 +100,26 @@ class DevicePrefetcher:
 
         it = iter(self.loader)
         try:
-            nxt = stage(next(it), 0)
+            cur = stage(next(it), 0)
         except StopIteration:
             return
         i = 0
-        while nxt is not None:
-            cur, ev = nxt
-            try:
-                nxt = stage(next(it), (i + 1) % self.NBUF)
-            except StopIteration:
-                nxt = None
-            main = torch.cuda.current_stream(dev)
-            main.wait_event(ev)
-            yield cur
-            # the consumer has queued the whole step on the compute stream by the time it asks for the next batch
-            done[i % self.NBUF] = torch.cuda.Event()
-            done[i % self.NBUF].record(torch.cuda.current_stream(dev))
-            i += 1
+        try:
+            while cur is not None:
+                batch, ev = cur
+                torch.cuda.current_stream(dev).wait_event(ev)
+                yield batch
+                # Resumed: the consumer has queued the whole of step i on the compute stream and asks for batch i+1.  Only now is
+                # the loader asked for it (the launch of step i never waits for the loader or for pin_memory()); its copy still runs
+                # beside the GPU's step i, which the host is ahead of.
+                done[i % self.NBUF] = torch.cuda.Event()
+                done[i % self.NBUF].record(torch.cuda.current_stream(dev))
+                try:
+                    cur = stage(next(it), (i + 1) % self.NBUF)
+                except StopIteration:
+                    cur = None
+                i += 1
+        finally:
+            # an abandoned iterator (exception, early break) may leave a copy in flight into a slot: the slots go back to the compute
+            # stream's allocator pool when this frame dies, so that stream must not touch them before the copy stream is done
+            torch.cuda.current_stream(dev).wait_stream(side)

@@ -36,6 +36,21 @@ def _range(on, name):
             torch.cuda.nvtx.range_pop()
 
 
+def _flush_tb(log_writer, pending):
+    """Write the buffered (epoch_1000x, [mim, res, mlm] on the device, lr) records: ONE device read-back for all of them."""
+    if not pending:
+        return
+    vals = torch.stack([r for _, r, _ in pending]).tolist()
+    for (x, _, lr), r in zip(pending, vals):
+        if not all(math.isfinite(v) for v in r):
+            print("warning: non-finite loss {}".format(r))
+        log_writer.add_scalar("mim_loss", r[0], x)
+        log_writer.add_scalar("res_loss", r[1], x)
+        log_writer.add_scalar("mlm_loss", r[2], x)
+        log_writer.add_scalar("lr", lr, x)
+    del pending[:]
+
+
 def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer, device: torch.device,
                     epoch: int, loss_scaler, log_writer=None, args=None):
     model.train(True)
@@ -48,6 +63,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     if log_writer is not None:
         print("log_dir: {}".format(log_writer.log_dir))
     n_iter = len(data_loader)
+    tb_pending = []
     prof = bool(getattr(args, "profile", False))
     if prof:
         from . import _lib
@@ -78,15 +94,13 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
         metric_logger.update(lr=lr)
         reduced = misc.all_reduce_mean(losses)
         if log_writer is not None and update_grad:
-            # epoch_1000x as the x-axis calibrates curves across batch sizes (main_pretrain.py:168-175)
-            epoch_1000x = int((data_iter_step / n_iter + epoch) * 1000)
-            r = reduced.tolist()
-            if not all(math.isfinite(v) for v in r):
-                print("warning: non-finite loss {}".format(r))
-            log_writer.add_scalar("mim_loss", r[0], epoch_1000x)
-            log_writer.add_scalar("res_loss", r[1], epoch_1000x)
-            log_writer.add_scalar("mlm_loss", r[2], epoch_1000x)
-            log_writer.add_scalar("lr", lr, epoch_1000x)
+            # epoch_1000x as the x-axis calibrates curves across batch sizes (main_pretrain.py:168-175).  The values stay on the device
+            # until the meters are printed anyway (every `print_freq` steps) or the epoch ends: no host synchronisation per optimizer step
+            tb_pending.append((int((data_iter_step / n_iter + epoch) * 1000), reduced, lr))
+            if (data_iter_step + 1) % print_freq == 0 or data_iter_step == n_iter - 1:
+                _flush_tb(log_writer, tb_pending)
+    if log_writer is not None:
+        _flush_tb(log_writer, tb_pending)
     if prof:
         torch.cuda.synchronize()
         lib.ecamp_prof_enable(0)

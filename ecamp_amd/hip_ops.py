@@ -144,6 +144,26 @@ def wgrad_group_supported(items):
     return bool(_lib.load().ecamp_wgrad_group_supported(n, ctypes.cast(no, ctypes.c_void_p), ctypes.cast(ki, ctypes.c_void_p), rows))
 
 
+_WG_TABLES = {}   # (device, shapes, has_bias, rows, workgroups) -> device image of the group's item table (uploaded once, kept)
+
+
+def _wgrad_group_table(dev, n, no, ki, hb, rows, workgroups):
+    lib = _lib.load()
+    nwg = int(lib.ecamp_wgrad_group_workgroups(int(workgroups)))
+    key = (str(dev), tuple(no), tuple(ki), tuple(hb), int(rows), nwg)
+    t = _WG_TABLES.get(key)
+    if t is None:
+        cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        cap = int(lib.ecamp_wgrad_group_table_bytes(n, cv(no), cv(ki), rows))
+        host = torch.empty((cap,), dtype=torch.uint8)
+        used = int(lib.ecamp_wgrad_group_table(n, cv(no), cv(ki), cv((ctypes.c_int32 * n)(*hb)), rows, int(workgroups), ctypes.c_void_p(host.data_ptr())))
+        if used <= 0:
+            raise _lib.EcampHipError("ecamp_wgrad_group_table failed: %s" % lib.ecamp_last_error().decode())
+        # one-time upload on the current stream (a blocking copy from pageable memory: the first call for a shape set, never in a captured region)
+        t = _WG_TABLES[key] = host[:used].to(dev)
+    return t
+
+
 def wgrad_group(items, alpha=1.0, alpha_dev=None, workgroups=0):
     """gw_p [N_p, K_p] (f32) (+)= alpha * dy_p^T x_p and gb_p += alpha * column sums of dy_p for every (dy, x, gw, gb, accumulate) of
     `items` in ONE persistent launch + one reduce (ecamp_wgrad_group): the weight gradients of one transformer block."""
@@ -155,9 +175,12 @@ def wgrad_group(items, alpha=1.0, alpha_dev=None, workgroups=0):
     dyp, xp, gwp, gbp = vp([it[0] for it in items]), vp([it[1] for it in items]), vp([it[2] for it in items]), vp([it[3] for it in items])
     acc = (ctypes.c_int32 * n)(*[1 if it[4] else 0 for it in items])
     cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    dev = items[0][0].device
+    table = _wgrad_group_table(dev, n, no, ki, [1 if it[3] is not None else 0 for it in items], rows, workgroups)
     nws = int(_lib.load().ecamp_wgrad_group_workspace_bytes(n, cv(no), cv(ki), rows)) // 4
-    ws = torch.empty((nws,), device=items[0][0].device, dtype=torch.float32)
-    call("ecamp_wgrad_group", n, cv(dyp), cv(xp), cv(gwp), cv(gbp), cv(no), cv(ki), rows, float(alpha), ptr(alpha_dev), cv(acc), ptr(ws), int(workgroups), stream())
+    ws = torch.empty((nws,), device=dev, dtype=torch.float32)
+    call("ecamp_wgrad_group", n, cv(dyp), cv(xp), cv(gwp), cv(gbp), cv(no), cv(ki), rows, float(alpha), ptr(alpha_dev), cv(acc), ptr(ws), ptr(table),
+         int(workgroups), stream())
 
 
 def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):

@@ -44,6 +44,9 @@ class GradReducer:
         # buckets are staged through host memory, synchronously -- a test / debugging path, never the production one
         self.host_staged = backend == "gloo" and flat_g.is_cuda
         self._cb_queued = False
+        self.main_stream = None   # the step's compute stream (set by the wrapper's forward); the collectives also wait for it
+        self.timing = False       # record event pairs around every collective (bench.py's `rccl` record)
+        self._timed = []
         self.dirty = False      # a backward pass has reported gradients that finalize() has not yet reduced
         self.reset()
 
@@ -63,25 +66,52 @@ class GradReducer:
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         if self.host_staged:
             from . import hip_ops
+            cur = torch.cuda.current_stream()
+            if self.main_stream is not None and self.main_stream != cur:
+                cur.wait_stream(self.main_stream)
             for wst in hip_ops.side_streams(self.flat_g.device):
-                torch.cuda.current_stream().wait_stream(wst)
+                cur.wait_stream(wst)
             host = buf.cpu()
             dist.all_reduce(host, op=op, group=self.group)
             buf.copy_(host)
             self.works.append((None, b))
             return
         if self.side is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.side.wait_event(ev)
-            from . import hip_ops  # gradients of this bucket may still be running on the wgrad side stream or the branch stream
+            # the collective may start once every stream that can hold gradient work of this bucket has reached this point: the stream
+            # that reported the parameter (a backward node may run on the branch stream), the MAIN compute stream of the step (the
+            # report side's gradients of the same bucket are written there even when the reporting node ran elsewhere), the weight-
+            # gradient side stream and the branch stream
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)
+            if self.main_stream is not None and self.main_stream != cur:
+                self.side.wait_stream(self.main_stream)
+            from . import hip_ops
             for wst in hip_ops.side_streams(self.flat_g.device):
                 self.side.wait_stream(wst)
             with torch.cuda.stream(self.side):
+                t0 = None
+                if self.timing:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(self.side)
                 w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+                w.wait()       # stream-level: the SIDE stream waits for RCCL's stream (the host does not block)
+                done = torch.cuda.Event(enable_timing=self.timing)
+                done.record(self.side)
+                if t0 is not None:
+                    self._timed.append((t0, done))
+            self.works.append((done, b))
         else:
             w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
-        self.works.append((w, b))
+            self.works.append((w, b))
+
+    def comm_ms(self):
+        """Sum of the all-reduce durations (ms, events on the communication stream) recorded since the last call; needs `timing`."""
+        tot = 0.0
+        for a, b in self._timed:
+            b.synchronize()
+            tot += a.elapsed_time(b)
+        self._timed = []
+        return tot
 
     def mark_ready(self, slots):
         """Called from inside the backward stages as soon as a parameter's gradient is final."""
@@ -113,7 +143,9 @@ class GradReducer:
             if not self.launched[b]:
                 self._launch(b)
         for w, b in self.works:
-            if w is not None:
+            if isinstance(w, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(w)   # the compute stream sees the reduced bucket
+            elif w is not None:
                 w.wait()
             if not self.use_avg and self.world > 1:
                 lo, hi, _ = self.buckets[b]
@@ -155,6 +187,8 @@ class DistributedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         if self.module.arena is not None and self.module.arena.on_ready is None:
             self.module.arena.on_ready = self.reducer.mark_ready
+        if self.reducer.flat_g.is_cuda:
+            self.reducer.main_stream = torch.cuda.current_stream()
         return self.module(*args, **kwargs)
 
     def set_grad_sync(self, flag):

@@ -52,12 +52,22 @@ int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc
  * gb[p] [n_out[p]] (f32, may be null) += alpha * column sums of dy[p], for the 1-4 linear layers of one block that share the row count
  * `rows` of dy[p] [rows, n_out[p]] / x[p] [rows, k_in[p]] (bf16, row-contiguous), as ONE persistent launch + one reduce.
  * accumulate[p] = 0 overwrites gw[p].  ws: ecamp_wgrad_group_workspace_bytes(...) bytes.  workgroups: 0 = three quarters of the CUs
- * (what is left runs whatever is queued beside it), otherwise at most one per CU.  ecamp_wgrad_group_supported == 0: issue per-layer ecamp_gemm calls. */
+ * (what is left runs whatever is queued beside it), otherwise at most one per CU.  ecamp_wgrad_group_supported == 0: issue per-layer ecamp_gemm calls.
+ * table: DEVICE copy (32-byte aligned) of the group's item table -- pure host arithmetic on (shapes, has_bias, rows, workgroup count)
+ * that ecamp_wgrad_group_table writes into HOST memory of ecamp_wgrad_group_table_bytes(...) bytes; the caller uploads it once per
+ * shape set and keeps it (the library never allocates and never synchronises: the call is two kernel launches, capturable into a
+ * HIP graph).  ecamp_wgrad_group_workgroups(w) = the workgroup count the launch uses for argument w (part of the table's identity). */
 int ecamp_wgrad_group_supported(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows);
 int64_t ecamp_wgrad_group_workspace_bytes(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows);
+int64_t ecamp_wgrad_group_table_bytes(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows);
+int64_t ecamp_wgrad_group_table(int32_t n, const int64_t* n_out, const int64_t* k_in, const int32_t* has_bias, int64_t rows,
+                                int32_t workgroups, void* host_table);
+int ecamp_wgrad_group_workgroups(int32_t workgroups);
 int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* const* x, float* const* gw, float* const* gb, const int64_t* n_out,
                       const int64_t* k_in, int64_t rows, float alpha, const float* alpha_dev, const int32_t* accumulate, float* ws,
-                      int32_t workgroups, ecampStream_t stream);
+                      const void* table, int32_t workgroups, ecampStream_t stream);
+/* development aid: grouped launches issued so far (tests assert that the grouped path really ran) */
+int64_t ecamp_wgrad_group_launches(void);
 /* Workspace sizes (bytes) the caller allocates and passes in -- the library never allocates:
  *   ecamp_gemm_workspace_bytes      `splitk_ws` of ecamp_gemm for this split count (0 when split_k <= 1)
  *   ecamp_attn_bwd_workspace_bytes  `delta_ws` of ecamp_attn_bwd (one f32 per query row)
@@ -199,7 +209,10 @@ int ecamp_adamw_grouped(float* p, const float* g, float* m, float* v, void* p_bf
 
 /* ---- optional in-process timing (bench.py roofline): HIP-event pairs around every GEMM / attention launch ---- */
 int ecamp_prof_enable(int on);
-int ecamp_prof_collect(int category, double* total_ms, double* total_work, int64_t* count); /* 0 gemm bf16, 1 gemm f32, 2 attention; <0 clears */
+int ecamp_prof_collect(int category, double* total_ms, double* total_work, int64_t* count); /* 0 gemm bf16, 1 gemm f32, 2 attention, 3 gemm fp8; <0 clears */
+/* event pairs the timing facility currently holds: bounded (a pool of 4096 pairs whose finished records are folded into running
+ * totals), however many steps run under `main_pretrain.py --profile` */
+int64_t ecamp_prof_live_events(void);
 
 #ifdef __cplusplus
 }

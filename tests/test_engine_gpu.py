@@ -212,13 +212,15 @@ def test_lazy_zero_grad_matches_memset_and_flushes_unwritten_weights(dev):
                 assert (g - b[k]).abs().max().item() <= 5e-3 * b[k].abs().max().item() + 1e-9, k
 
 
-@pytest.mark.parametrize("accum", [1, 2])
-def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum):
+@pytest.mark.parametrize("accum,branches", [(1, 0), (2, 0), (1, 1)])
+def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum, branches):
     """SURVEY.md section 4, "distributed without a cluster" (main_pretrain.py:247-250): two data-parallel ranks of B=4 (accum 1) or
     2 x B=2 with no_sync on the first micro-step (accum 2) must leave, after the bucketed all-reduce, the SAME gradient arena and
     the same parameters after one AdamW step as ONE process on the concatenated B=8 batch.  Both ranks share cuda:0 (this pool
     has one GPU per box), so the process group is gloo on device tensors; rank 1 starts from a different initialisation, which the
-    wrapper's parameter broadcast must overwrite.  fp32 parity mode, tiny config, recipe inputs."""
+    wrapper's parameter broadcast must overwrite.  fp32 parity mode, tiny config, recipe inputs.  branches=1: the ranks run with
+    ECAMP_OVERLAP_BRANCHES=1 (image decoder and report side on two streams, forward and backward): a bucket reported from a
+    branch-stream node must still wait for the main stream's share of its gradients."""
     import socket
     import subprocess
     import sys
@@ -253,7 +255,8 @@ def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum):
     sock.close()
     out = os.path.join(tmp_path, "ddp_rank0.pt")
     worker = os.path.join(root, "tests", "_ddp_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(accum), out], cwd=root) for r in range(2)]
+    env = dict(os.environ, ECAMP_OVERLAP_BRANCHES=str(branches))
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(accum), out], cwd=root, env=env) for r in range(2)]
     rcs = [p.wait(timeout=600) for p in procs]
     assert rcs == [0, 0], rcs
     got = torch.load(out, map_location="cpu")
@@ -282,3 +285,38 @@ def test_optimizer_refuses_unreduced_gradients(dev):
         opt.step()
     A.reducer.finalize()
     opt.step()
+
+
+def test_device_prefetcher_delivers_every_batch_intact(dev):
+    """ecamp_amd.data.DevicePrefetcher (defines bench.py's `value`): eight DISTINCT host batches through its three staging slots with a
+    slow consumer arrive intact and in order; an early break with a copy in flight, followed by allocations that recycle the slots'
+    memory, corrupts nothing; an exception inside the consumer leaves the iterator closed cleanly."""
+    from ecamp_amd.data import DevicePrefetcher
+    g = torch.Generator().manual_seed(0)
+    host = [{"image": torch.randn(4, 3, 448, 448, generator=g), "ids": torch.randint(0, 30000, (4, 128), generator=g), "tag": i} for i in range(8)]
+    seen = []
+    for i, b in enumerate(DevicePrefetcher(host, dev)):
+        assert b["tag"] == i and b["image"].is_cuda and b["ids"].is_cuda
+        # slow consumer: a long kernel chain reads the batch well after the host has moved on to staging the next ones
+        acc = b["image"].clone()
+        for _ in range(20):
+            acc = acc * 1.0001 + 0.0
+        seen.append((b["image"].clone(), b["ids"].clone(), acc))
+    torch.cuda.synchronize()
+    assert len(seen) == 8
+    for i, (im, ids, _) in enumerate(seen):
+        assert torch.equal(im.cpu(), host[i]["image"]) and torch.equal(ids.cpu(), host[i]["ids"]), i
+    # early break while batch 2's copy may be in flight, then recycle memory on the compute stream
+    it = iter(DevicePrefetcher(host, dev))
+    first = next(it)["image"].clone()
+    second = next(it)["image"]
+    keep = second.clone()
+    it.close()
+    junk = [torch.full((4, 3, 448, 448), float(k), device=dev) for k in range(6)]
+    torch.cuda.synchronize()
+    assert torch.equal(first.cpu(), host[0]["image"]) and torch.equal(keep.cpu(), host[1]["image"])
+    assert all(float(j.flatten()[0]) == float(k) and float(j.flatten()[-1]) == float(k) for k, j in enumerate(junk))
+    with pytest.raises(RuntimeError, match="consumer failed"):
+        for b in DevicePrefetcher(host, dev):
+            raise RuntimeError("consumer failed")
+    torch.cuda.synchronize()

@@ -863,3 +863,28 @@ def test_wgrad_group_matches_per_layer_weight_gradients(dev, rows, shapes):
     for (dy, x, gw, gb, acc), (gw_ref, gb_ref) in zip(items, refs):
         o.linear_wgrad(dy, x, gw_ref, gb=gb_ref, accumulate=acc)
         assert (gw - gw_ref).abs().max() < 1e-4 * gw_ref.abs().max() + 1e-3
+
+
+def test_profiling_events_are_bounded(dev):
+    """csrc/profile.hip: `main_pretrain.py --profile` brackets every GEMM / attention launch of a whole epoch with HIP events; the pool
+    holds at most 4096 pairs however many launches are recorded (finished records are folded into running totals), and the totals
+    still count every launch."""
+    import ctypes
+    from ecamp_amd import _lib
+    lib = _lib.load()
+    o = ops()
+    x = torch.randn(256, 128, device=dev).bfloat16()
+    w = torch.randn(64, 128, device=dev).bfloat16()
+    lib.ecamp_prof_collect(-1, None, None, None)
+    lib.ecamp_prof_enable(1)
+    try:
+        for _ in range(9000):
+            o.linear_fwd(x, w)
+    finally:
+        lib.ecamp_prof_enable(0)
+    assert 0 < int(lib.ecamp_prof_live_events()) <= 4096
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    lib.ecamp_prof_collect(0, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+    assert n.value == 9000 and ms.value > 0 and fl.value == pytest.approx(9000 * 2.0 * 256 * 64 * 128)
+    lib.ecamp_prof_collect(-1, None, None, None)
+    assert int(lib.ecamp_prof_live_events()) == 0

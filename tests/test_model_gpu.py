@@ -19,14 +19,14 @@ def _load(name):
     return np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"), allow_pickle=False)
 
 
-def _build(name, dtype, dev):
+def _build(name, dtype, dev, fp8=False):
     from ecamp_amd.module import model_ecamp as me
     from oracle import ecamp_oracle as orc
     from oracle import recipe
     tiny = name.startswith("tiny")
     cfg = orc.cfg_tiny() if tiny else orc.cfg_base()
     torch.manual_seed(0)
-    model = (me.ecamp_tiny if tiny else me.ecamp)(compute_dtype=dtype)
+    model = (me.ecamp_tiny if tiny else me.ecamp)(compute_dtype=dtype, **({"fp8_forward": True} if fp8 else {}))
     model.load_state_dict(recipe.recipe_state(cfg, seed=0), strict=True)
     model.to(dev)
     return model, cfg
@@ -89,19 +89,35 @@ def test_forward_backward_matches_reference_fp32(dev, name):
     assert rel(gn, float(g["grad/global_norm"])) < 1e-3
 
 
-@pytest.mark.parametrize("name", ["tiny_b4_s128", "base_b2_s128"])
-def test_forward_backward_bf16_within_tolerance(dev, name):
+@pytest.mark.parametrize("q8_mode", [-1, 2])
+@pytest.mark.parametrize("name", GOLD)
+def test_forward_backward_bf16_within_tolerance(dev, name, q8_mode):
+    """bf16 production mode against the reference's golden vectors.  q8_mode=-1: the library's own kernel selection (at B=2/4 every
+    GEMM is below the persistent kernel's threshold and runs on the 128^2 kernel); q8_mode=2: the persistent 256x256x64 kernel
+    (the one the benchmark runs) wherever its alignment conditions hold -- edge tiles, short contractions and all."""
+    from ecamp_amd import _lib, hip_ops
+    hip_ops.set_option("q8_mode", q8_mode)
+    n0 = int(_lib.load().ecamp_gemm_q8_launches())
+    try:
+        _bf16_golden_case(dev, name)
+    finally:
+        hip_ops.set_option("q8_mode", -1)
+    if q8_mode == 2:
+        assert int(_lib.load().ecamp_gemm_q8_launches()) - n0 > 50, "the persistent kernel did not run"
+
+
+def _bf16_golden_case(dev, name, fp8=False, loss_tol=3e-2, med_tol=1e-2, max_tol=6e-2, act_tol=3e-2):
     from oracle import recipe
     g = _load(name)
     B, S = int(g["meta/B"]), int(g["meta/S"])
     from oracle.make_golden import digest
-    model, cfg = _build(name, torch.bfloat16, dev)
+    model, cfg = _build(name, torch.bfloat16, dev, fp8=fp8)
     model.eval()
     model.keep_aux = True
     mim, res, mlm = model(recipe.recipe_batch(cfg, B, S, seed=0), mask_ratio=0.75, noise=recipe.recipe_noise(B, cfg.num_patches, seed=0))
     losses = np.array([mim.item(), res.item(), mlm.item()])
-    print(name, "bf16 losses", losses, "golden", g["losses"], "rel", np.abs(losses - g["losses"]) / g["losses"])
-    assert (np.abs(losses - g["losses"]) / g["losses"]).max() < 3e-2
+    print(name, "fp8-forward" if fp8 else "bf16", "losses", losses, "golden", g["losses"], "rel", np.abs(losses - g["losses"]) / g["losses"])
+    assert (np.abs(losses - g["losses"]) / g["losses"]).max() < loss_tol
     # activations of the PRODUCTION kernels (bf16 GEMM / attention / LayerNorm) against the reference's own, at bf16 resolution: the
     # norm of each tensor to 3e-2, its strided sample to 3e-2 of the tensor's largest sampled magnitude
     aux, L = model._aux, cfg.num_patches
@@ -111,7 +127,7 @@ def test_forward_backward_bf16_within_tolerance(dev, name):
         nm, s = digest(t.float().cpu())
         e = max(rel(nm[0], g["act/%s/nm" % k][0]), rel(s, g["act/%s/s" % k]))
         print("  bf16 act %-10s rel err %.2e" % (k, e))
-        assert e < 3e-2, (k, e)
+        assert e < act_tol, (k, e)
     (mim + res + mlm).backward()
     names = list(g["grad/names"])
     params = dict(model.named_parameters())
@@ -119,7 +135,14 @@ def test_forward_backward_bf16_within_tolerance(dev, name):
     big = g["grad/norms"] > 1e-3 * g["grad/norms"].max()
     e = np.abs(norms - g["grad/norms"])[big] / g["grad/norms"][big]
     print("  bf16 grad-norm rel err: median %.2e max %.2e" % (np.median(e), e.max()))
-    assert np.median(e) < 1e-2 and e.max() < 6e-2   # measured: median 2e-3, worst tensor 2e-2
+    assert np.median(e) < med_tol and e.max() < max_tol   # measured in bf16: median 2e-3, worst tensor 2e-2
+
+
+def test_fp8_forward_mode_matches_reference_golden(dev):
+    """BASELINE.json configs[4] against the REFERENCE (not against this repo's own bf16 path): `fp8_forward=True` (e4m3 copies of the
+    activations and weights of the ViT-block linear layers, per-tensor scales, bf16 gradients) on the golden vectors of the base
+    model: losses within 5e-2, activation digests within 6e-2, per-tensor gradient norms median 3e-2 / worst 1.5e-1."""
+    _bf16_golden_case(dev, "base_b2_s128", fp8=True, loss_tol=5e-2, med_tol=3e-2, max_tol=1.5e-1, act_tol=6e-2)
 
 
 def test_engine_step_matches_reference(dev):
@@ -536,3 +559,116 @@ def test_grouped_and_per_layer_weight_gradients_agree_at_model_level_bf16(dev):
     worst = float((grads[0] - grads[1]).abs().max() / grads[1].abs().max())
     print("grouped vs per-layer gradients: rel l2 %.3e, worst element / max %.3e" % (num / den, worst))
     assert num / den < 1e-5 and worst < 1e-4
+
+
+def _host_mem_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.mark.parametrize("B", [128, 256])
+def test_production_kernel_selection_matches_oracle_bf16(dev, B):
+    """The kernels the BENCHMARK runs, against the oracle at model level: `ecamp(bfloat16)` with the library's own (automatic) kernel
+    selection at a size where it picks the persistent 256x256x64 GEMM for the forward / data-gradient / weight-gradient forms and the
+    grouped weight-gradient launches (B=128: qkv, fc1, decoder, BERT and vocabulary GEMMs; B=256 = BASELINE configs[1] adds the
+    12800 x 768 outputs and their 192-row tile), on recipe weights and inputs, S=128, dropout off.  The oracle (fp32, host cores) runs
+    forward + backward on the same batch (~5-7 pairs/s).  Losses to 3e-2, per-tensor gradient norms median 1e-2 / worst 6e-2, a
+    strided sample of four gradients to 6e-2 of their largest element; launch counters prove which kernels ran."""
+    import os
+    from ecamp_amd import _lib
+    from ecamp_amd.module import model_ecamp as me
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    need = 45 if B == 128 else 100
+    if _host_mem_gb() < need:
+        pytest.skip("the oracle's fp32 activations at B=%d need ~%d GB of host memory" % (B, need))
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    cfg = orc.cfg_base()
+    S = 128
+    state = recipe.recipe_state(cfg, seed=0)
+    batch = recipe.recipe_batch(cfg, B, S, seed=21)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=21)
+    lib = _lib.load()
+    model = me.ecamp(compute_dtype=torch.bfloat16)
+    model.load_state_dict(state, strict=True)
+    model.to(dev).eval()
+    q0, w0 = int(lib.ecamp_gemm_q8_launches()), int(lib.ecamp_wgrad_group_launches())
+    out = model(batch, mask_ratio=0.75, noise=noise)
+    sum(out).backward()
+    torch.cuda.synchronize()
+    nq, nw = int(lib.ecamp_gemm_q8_launches()) - q0, int(lib.ecamp_wgrad_group_launches()) - w0
+    got = np.array([t.item() for t in out])
+    params = dict(model.named_parameters())
+    names = [n for n in orc.trainable_names(cfg) if params[n].grad is not None]
+    gn = {n: params[n].grad.double().norm().item() for n in names}
+    keys = ("blocks.3.mlp.fc1.weight", "decoder_blocks.1.attn.qkv.weight", "bert_encoder.model.bert.encoder.layer.2.output.dense.weight",
+            "bert_encoder.model.cls.predictions.decoder.weight")
+    samp = {k: params[k].grad.float().flatten()[::997].cpu().clone() for k in keys}
+    del model, out, params
+    torch.cuda.empty_cache()
+    import time
+    t0 = time.time()
+    P = orc.set_requires_grad(orc.load_state(orc.new_params(cfg), state), cfg)
+    ref = orc.forward(P, cfg, batch, 0.75, noise)
+    sum(ref).backward()
+    want = np.array([t.item() for t in ref])
+    print("B=%d: Q8 launches %d, grouped weight-gradient launches %d; oracle fwd+bwd %.1f s" % (B, nq, nw, time.time() - t0))
+    print("  losses hip", got, "oracle", want, "rel", np.abs(got - want) / want)
+    assert nq > 150 and nw >= 30, (nq, nw)     # the persistent kernel and the grouped launches are what ran
+    assert (np.abs(got - want) / want).max() < 3e-2
+    ref_n = np.array([P[n].grad.double().norm().item() for n in names])
+    hip_n = np.array([gn[n] for n in names])
+    big = ref_n > 1e-3 * ref_n.max()
+    e = np.abs(hip_n - ref_n)[big] / ref_n[big]
+    worst = np.array(names)[big][int(e.argmax())]
+    print("  grad-norm rel err: median %.2e max %.2e (%s)" % (np.median(e), e.max(), worst))
+    assert np.median(e) < 1e-2 and e.max() < 6e-2, (worst, e.max())
+    for k in keys:
+        r = P[k].grad.flatten()[::997]
+        d = float((samp[k] - r).abs().max() / r.abs().max())
+        print("  grad sample %-70s rel-to-max err %.2e" % (k, d))
+        assert d < 6e-2, (k, d)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_b512_step_is_the_mean_of_its_sub_batches(dev, fp8):
+    """BASELINE.json configs[4] at its full size (B=512 per GPU, S=128; bf16 and fp8 forward): the losses and the gradient arena of the
+    whole batch equal the mean over its 8 sub-batches of 64.  At B=512 the vocabulary head's operands pass 2 GB, so the model-level
+    step runs the row / contraction splits of ecamp_gemm that the B=256 tests never reach.  (fp8: the per-tensor activation scales
+    are taken per call, so the full batch and a sub-batch quantise with different scales -- looser bounds.)"""
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    torch.manual_seed(0)
+    model = me.ecamp(compute_dtype=torch.bfloat16, **({"fp8_forward": True} if fp8 else {})).to(dev)
+    model.eval()
+    B, S, NB = 512, 128, 64
+    batch = synthetic_batch(B, S, 448, seed=14, device=dev)
+    noise = torch.rand(B, 196, generator=torch.Generator().manual_seed(8)).to(dev)
+    arena = model.prepare()
+    arena.flat_g.zero_()
+    out = model(batch, noise=noise)
+    sum(out).backward()
+    torch.cuda.synchronize()
+    full = torch.stack([t.detach() for t in out]).double().cpu()
+    g_full = arena.flat_g.clone()
+    del out
+    arena.flat_g.zero_()
+    parts = []
+    for i in range(0, B, NB):
+        sub = {k: v[i:i + NB] for k, v in batch.items()}
+        o = model(sub, noise=noise[i:i + NB])
+        sum(o).backward()
+        parts.append(torch.stack([t.detach() for t in o]).double().cpu())
+    torch.cuda.synchronize()
+    parts = torch.stack(parts).mean(0)
+    g_parts = arena.flat_g / float(B // NB)
+    le = float(((full - parts).abs() / parts.abs()).max())
+    ge = float((g_full - g_parts).double().norm() / g_parts.double().norm())
+    print("B=512 %s: losses full %s, mean of parts %s (rel %.2e); gradient rel l2 %.3e" % ("fp8" if fp8 else "bf16", full.tolist(), parts.tolist(), le, ge))
+    assert torch.isfinite(full).all() and torch.isfinite(g_full).all() and float(g_full.abs().max()) > 0
+    assert le < (1e-2 if fp8 else 2e-3) and ge < (8e-2 if fp8 else 2e-2)
