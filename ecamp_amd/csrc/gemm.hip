@@ -956,26 +956,6 @@ static q8_fn q8_pick(int a_kc, int b_kc, int epi, bool rowsum) {
     if (!a_kc && !b_kc && epi == 4) return rowsum ? gemm_bf16_q8_kernel<false, false, 4, 0, true> : gemm_bf16_q8_kernel<false, false, 4, 0, false>;
     return nullptr;
 }
-// the 192 x 256 tile (gemm_q8.h, MT = 3) exists for the forward / data-gradient forms without the GELU epilogue
-static q8_fn q8_pick192(int a_kc, int b_kc, int epi) {
-    if (a_kc && b_kc) return epi == 0 ? gemm_bf16_q8_kernel<true, true, 0, 0, false, 3> : epi == 2 ? gemm_bf16_q8_kernel<true, true, 2, 0, false, 3> : (q8_fn) nullptr;
-    if (a_kc && !b_kc)
-        return epi == 0 ? gemm_bf16_q8_kernel<true, false, 0, 0, false, 3> : epi == 2 ? gemm_bf16_q8_kernel<true, false, 2, 0, false, 3>
-             : epi == 3 ? gemm_bf16_q8_kernel<true, false, 3, 0, false, 3> : (q8_fn) nullptr;
-    return nullptr;
-}
-// ... and is taken when its rounds cost at least a tenth less than the 256-row tiling's (rounds x rows per tile; a 192-row tile's DMA
-// still brings 128-row halves, so ties go to 256).  ECAMP_Q8_MT=3 / 4 forces one (tests, A/B runs); option "q8_mt" likewise.
-static int g_q8_mt = 0;
-static bool q8_use192(int64_t M, int64_t N, int ncu, q8_fn fn192) {
-    static const int env = getenv("ECAMP_Q8_MT") ? atoi(getenv("ECAMP_Q8_MT")) : 0;
-    const int force = g_q8_mt ? g_q8_mt : env;
-    if (!fn192 || force == 4) return false;
-    if (force == 3) return true;
-    const long nbn = ceil_div(N, 256), t256 = ceil_div(M, 256) * nbn, t192 = ceil_div(M, 192) * nbn;
-    const long c256 = (t256 + ncu - 1) / ncu * 256, c192 = (t192 + ncu - 1) / ncu * 192;
-    return 10 * c192 <= 9 * c256;
-}
 static bool q8_legal(const void* A, const void* B, const void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda, int b_kc, int64_t ldb, int64_t ldc,
                      const float* bias, const void* residual, int64_t ldr, const void* pre_out, int64_t ldp, const void* gmul, int64_t ldg, int act,
                      int dtype, int out_f32, int split_k, const float* splitk_ws, const float* rowsum) {
@@ -1006,7 +986,6 @@ extern "C" int ecamp_set_option(const char* name, int32_t value) {
     ECAMP_CHECK_ARG(name != nullptr, "set_option: null name");
     if (strcmp(name, "p8_mode") == 0) { g_p8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 always
     if (strcmp(name, "q8_mode") == 0) { g_q8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 whenever legal
-    if (strcmp(name, "q8_mt") == 0) { g_q8_mt = (value == 3 || value == 4) ? value : 0; return 0; }         // 0 automatic, 3 / 4: force the 192- / 256-row tile
     if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
     if (strcmp(name, "attn_head") == 0) { attn_set_head_mode(value); return 0; }   // attention_bf16.hip: 1 head kernels (default), 0 streaming kernels
@@ -1144,10 +1123,6 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
             g.nsplit = split_k; g.wide = 1;
             int ncu = p8_num_cu();
             if (!(a_kc && b_kc) && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;
-            if (split_k == 1 && !rowsum && q8_use192(M, N, ncu, q8_pick192(a_kc, b_kc, epi))) {
-                fn = q8_pick192(a_kc, b_kc, epi);
-                g.nbm = ceil_div(M, 192);
-            }
             const long total8 = (long)g.nbm * g.nbn * split_k;
             const size_t shm = 10 * Q8_HALF;   // the whole 160 KB LDS of a CU
             static q8_fn attr_done[32];

@@ -1,26 +1,29 @@
 // "Q8": persistent 256x256x64 bf16 GEMM on v_mfma_f32_32x32x16_bf16, eight waves (2 x 4) of 128x64, one workgroup per CU.
 //
-// What the measurements on MI355X say (tools/gemm_lab, profiles/r02_gemm_lab_*.txt) and how the kernel answers them:
-//  * With random operands the matrix pipes are power-limited: a pure MFMA stream (no LDS, no DMA) runs at ~1.6 PFLOP/s, and the
-//    L2->LDS DMA path tops out at ~14 TB/s chip-wide (~26 B/clk/CU).  A 256^2 tile needs 64 KB per K=64 tile: 1.18 us of DMA
-//    against 1.33 us of MFMA.  Both are near saturation, so the loop is built to keep BOTH queues non-empty all the time.
+// What the measurements on MI355X say (tools/gemm_lab, profiles/r02_gemm_lab_*.txt, profiles/r03_gemm_lab_*.txt) and how the kernel
+// answers them:
+//  * With random operands the matrix pipes are power-limited: a pure MFMA stream (no LDS, no DMA) runs at ~1.6 PFLOP/s.  A 256^2 tile
+//    needs 64 KB of operands per K = 64 tile through the CU's vector-memory path, and its 128 KB of bf16 output leave through the
+//    same path at ~16 B/clk: the loop below runs at ~90 % of what that path delivers under MFMA load, and the epilogue's stores ADD
+//    their time to it however they are arranged (round 3: a tile packed to bf16 and stored one instruction per phase over the next
+//    four K tiles takes exactly as long as the burst) -- so the epilogue is the plain burst.
 //  * Operand tiles are HALF-TILES of 128 rows x 64 k (16 KB: A_0/A_1 = rows of wave row 0/1, B_0/B_1 = columns of wave columns
 //    0-1 / 2-3) in two rings of 5 slots (all 160 KB of LDS = 2.5 K tiles).  They are filled by buffer_load_dwordx4 ... lds through
 //    per-half-tile descriptors built with scalar ALU only (per-lane offsets are kernel constants; rows / contraction steps past
-//    the end read as zero).  ONE half-tile (2 instructions per wave) is issued per MFMA group, 4 to 6 groups ahead of its use, so
-//    the DMA engine always has work queued; it is waited for with a counted s_waitcnt once per K tile.
-//  * A K tile is four GROUPS (k-steps of 16): 8 independent MFMAs (the wave's 4 x 2 tiles of 32x32) on 4 + 2 fragments that were
-//    read from LDS one group earlier into the other half of a register double buffer, the 6 reads of the NEXT group being issued
-//    one by one between this group's MFMAs.  No MFMA ever waits for LDS latency and the accumulators are never dependent
-//    within 8 instructions.  The loop with DMA and epilogue removed reaches 93 % of the pure-MFMA rate.
-//  * ONE s_barrier per K tile, at the start of group 3: by then a wave has received every fragment of this K tile (slot
-//    free) and has waited for its own DMA pieces of the next one (published).
-//  * LDS-DMA issue blocks the issuing wave (the CU's address path takes one wave instruction at a time): wave row 0 issues in the
-//    first half of a group, wave row 1 in the second, so the other wave of the SIMD keeps multiplying.
-//  * Epilogue: the previous output tile's quadrants are stored between the quadrants of the first group of the next tile, whose
-//    MFMAs start from C = 0 (no accumulator copy, no drain).  Buffer stores (bounds by descriptor, no exec-masked branches), so
-//    their COUNT is exact: vmcnt retires in order on gfx9 and loads and stores share it, and the one DMA wait that follows a
-//    tile's stores excludes exactly those stores.
+//    the end read as zero), one half-tile (2 instructions per wave) per phase, as one flat stream over the workgroup's tiles, and
+//    waited for with a counted s_waitcnt once per K tile.
+//  * PHASE SCHEDULE (round 3).  A K tile is four PHASES (k-steps of 16).  In a phase a wave first LOADS -- the six fragment reads of
+//    this very phase (4 M-side + 2 N-side, one register set), its two DMA instructions, the waits -- then, after a barrier, MULTIPLIES:
+//    its 8 independent MFMAs (4 x 2 tiles of 32x32) back to back at raised priority, then a second barrier.  Wave row 1 runs ONE
+//    BARRIER BEHIND wave row 0, and the two waves of a SIMD belong to different rows: while one multiplies the other loads.  The matrix
+//    pipe sees one uncontended MFMA stream at a time, and the LDS / DMA issue stalls of the loading wave cost no MFMA slot (a wave
+//    blocked issuing an LDS-DMA piece cannot issue MFMAs; interleaving everything in every wave -- the round-2 schedule: fragments a
+//    group ahead in a register double buffer, one barrier per K tile -- left both waves of a SIMD stalled at the same moments:
+//    forward / data-gradient / weight-gradient forms 7-15 % slower on every shape, tools/gemm_lab --ph=0 before its removal).
+//    The single fragment set also frees 24 registers (180 instead of 215 in the plain forward form).
+//  * Epilogue: the previous output tile is stored at the head of the next tile's first phase, whose MFMAs start from C = 0 (no
+//    accumulator copy).  Buffer stores (bounds by descriptor, no exec-masked branches); they are older than every DMA the tile's
+//    first wait covers, and vmcnt retires in order.
 //  * LDS images are DMA-linear (128-B rows, 8 rows per wave piece); the bank swizzle (16-B chunk ^ ((row >> 1) & 7)) is applied
 //    to the lane's SOURCE offset and again on the fragment reads (conflict-free for the 32-row b128 fragments, both row maps:
 //    SQ_LDS_BANK_CONFLICT = 0).  Strided operands stay as they lie in HBM (64 k-rows x 256 B) and are read with
@@ -45,7 +48,6 @@ static __device__ __attribute__((aligned(16))) unsigned int q8_zero16[4] = {0u, 
 struct Q8Item {
     int m0, n0, kbeg, kend, nt, z, ncol;
 };
-template <int MT = 4>
 __device__ __forceinline__ Q8Item q8_decode(const GemmArgs& g, int v, int total) {
     const unsigned f = (unsigned)xcd_remap(v, total), ntile = (unsigned)(g.nbm * g.nbn);
     // grouped order inside a split: 8 M-blocks are walked for one N-block before the next N-block, so the ~32 tiles an XCD works
@@ -55,7 +57,7 @@ __device__ __forceinline__ Q8Item q8_decode(const GemmArgs& g, int v, int total)
     const unsigned gsz = min(8u, (unsigned)g.nbm - first);
     const unsigned nb = in / gsz, mb = first + (in - nb * gsz);
     Q8Item it;
-    it.m0 = (int)mb * (64 * MT); it.n0 = (int)nb * 256; it.z = (int)z; it.ncol = (int)nb;
+    it.m0 = (int)mb * 256; it.n0 = (int)nb * 256; it.z = (int)z; it.ncol = (int)nb;
     it.kbeg = (int)z * g.k_per_split;
     it.kend = min(g.K, it.kbeg + g.k_per_split);
     it.nt = (it.kend - it.kbeg + 63) >> 6;
@@ -134,32 +136,23 @@ __device__ __forceinline__ void q8_wait2(Q8Frag<true> (&)[2]) {}
 // epilogue can do -- with every option tested at run time the epilogue's branches push the kernel over its 256 registers:
 //   0  bf16 C = alpha*acc (+bias)            1  ... + save pre-activation + exact GELU        2  ... + residual
 //   3  bf16 C = alpha*acc * gelu'(gmul) (+residual)                                            4  f32: split-K slab, or C (+= old)
-// Stores per quadrant (exact, whatever the bounds): 4 for EPI 0/2/3, 8 for EPI 1/4.
-template <int EPI> struct Q8Epi { static constexpr int NST = (EPI == 1 || EPI == 4) ? 8 : 4; };
 typedef unsigned int q8_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
     return (q8_u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
 }
 
-// DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 8 = no s_setprio, 16 = no barrier in the
+// DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 8 = no s_setprio, 16 = no barriers in the
 // loop, 32 = no fragment reads, 64 = every DMA re-reads the tile's first K tile (timing decomposition only: 16, 32, 64 give wrong results),
 // 128 / 256 = nt / sc1 output stores, 512 = workgroups start in four phases 9 us apart (lock-step epilogue bursts: the stagger costs what it saves)
 // ROWSUM (weight-gradient form only): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient -- summed on the VALU from the M-side
 // fragments by the first wave column of the tiles in the first N-tile column, added with 4 buffer atomics per wave and tile.
-// MT: 32-row blocks per wave on the M side.  4: the 256 x 256 tile.  3: a 192 x 256 tile for shapes whose 256-row tiling fills a
-// fraction of a round (12800 x 768: 150 tiles on 256 CUs; 201 tiles of 3/4 the work take 3/4 of the time).  The LDS image, the DMA
-// and the rings do not change: an A half-tile still brings 128 rows, of which a wave row uses the first 96 (half-tile 1 starts
-// 96 rows in; the 32 surplus rows are rows of the other half / the next tile / zeros past M).
 // ITEMS (weight-gradient form only): the work items come from a table (Q8Group, gemm_args.h) instead of the tile x split arithmetic;
 // operands and leading dimensions change with the item's problem, every piece stores a dense f32 slab.
-template <bool A_KC, bool B_KC, int EPI, int DBG, bool ROWSUM, int MT, bool ITEMS>
+template <bool A_KC, bool B_KC, int EPI, int DBG, bool ROWSUM, bool ITEMS>
 __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
-    static_assert(MT == 3 || MT == 4, "tile heights: 192 or 256 rows");
-    static_assert(!ITEMS || (!A_KC && !B_KC && EPI == 4 && MT == 4 && DBG == 0), "the item-table form is the weight-gradient form");
-    static_assert(MT == 4 || (A_KC && !ROWSUM), "the 192-row tile is built for contraction-contiguous M-side operands (forward / data-gradient forms)");
+    static_assert(!ITEMS || (!A_KC && !B_KC && EPI == 4 && DBG == 0), "the item-table form is the weight-gradient form");
     static_assert(!ROWSUM || (!A_KC && !B_KC && EPI == 4), "rowsum is built for the weight-gradient form");
-    constexpr int NST = (DBG & 4) ? 0 : Q8Epi<EPI>::NST;   // stores per quadrant (none in the no-epilogue timing variant)
     constexpr int NSLOT = 5;                          // half-tile slots per operand ring
     constexpr int ST_AUX = (DBG & 128) ? 2 : (DBG & 256) ? 16 : 0;   // cache policy of the bf16 output stores: 2 = nt, 16 = sc1 (write-through)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // A ring (5 x 16 KB) | B ring (5 x 16 KB); the ONLY LDS object
@@ -235,11 +228,8 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     bool pdone = pv >= total;
     const unsigned char *sa_base, *sb_base;
     int sa_rec, sb_rec, p_krem;
-    const int a_half = A_KC ? (int)g.lda * (64 * MT) : 64 * MT;
+    const int a_half = A_KC ? (int)g.lda * 256 : 256;     // bytes from half-tile 0 to half-tile 1 (128 rows)
     int a_step = A_KC ? 128 : (int)g.lda * 128;   // (ITEMS: follows the staged item's problem)
-    // 192-row tile: an A half-tile's second piece of a wave holds rows 64 + 8*wave ..: only those of waves 0-3 (rows < 96) are used, so
-    // wave row 1 does not request it -- one DMA instruction fewer per A half-tile, which every counted wait of these waves allows for
-    const bool A96 = MT == 3 && wr == 1;
     const int b_half = B_KC ? (int)g.ldb * 256 : 256;
     int b_step = B_KC ? 128 : (int)g.ldb * 128;
     long s_lda = ITEMS ? -1 : g.lda, s_ldb = ITEMS ? -1 : g.ldb;   // leading dimensions the per-lane DMA offsets were built for
@@ -261,7 +251,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
             if (la_ != s_lda) { s_lda = la_; a_step = (int)la_ * 128; voffA[0] = q8_voff<A_KC>(0, wave, lane, la_); voffA[1] = q8_voff<A_KC>(1, wave, lane, la_); } \
             if (lb_ != s_ldb) { s_ldb = lb_; b_step = (int)lb_ * 128; voffB[0] = q8_voff<B_KC>(0, wave, lane, lb_); voffB[1] = q8_voff<B_KC>(1, wave, lane, lb_); } \
         } else {                                                                                                         \
-        const Q8Item n_ = q8_decode<MT>(g, pv, total);                                                                   \
+        const Q8Item n_ = q8_decode(g, pv, total);                                                                   \
         p_krem = n_.kend - n_.kbeg;                                                                                      \
         if (A_KC) { sa_base = (const unsigned char*)(A + ((long)n_.m0 * g.lda + n_.kbeg)); sa_rec = (int)((((long)(g.M - n_.m0)) * g.lda - n_.kbeg) * 2); } \
         else      { sa_base = (const unsigned char*)(A + ((long)n_.kbeg * g.lda + n_.m0)); sa_rec = (int)(((long)p_krem * g.lda - n_.m0) * 2); }             \
@@ -277,9 +267,9 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     do {                                                                                                                 \
         if (!pdone) {                                                                                                    \
             if (!(DBG & 2)) {                                                                                            \
-                if ((PART) == 0) { if (A96) q8_stage_half<A_KC, (PCS) & 1>(sa_base, sa_rec, p_krem, lds + wA * Q8_HALF, voffA, wave, lane); else q8_stage_half<A_KC, (PCS)>(sa_base, sa_rec, p_krem, lds + wA * Q8_HALF, voffA, wave, lane); } \
+                if ((PART) == 0) q8_stage_half<A_KC, (PCS)>(sa_base, sa_rec, p_krem, lds + wA * Q8_HALF, voffA, wave, lane);                         \
                 if ((PART) == 1) q8_stage_half<B_KC, (PCS)>(sb_base, sb_rec, p_krem, lds + (NSLOT + wB) * Q8_HALF, voffB, wave, lane);             \
-                if ((PART) == 2) { if (A96) q8_stage_half<A_KC, (PCS) & 1>(sa_base + a_half, sa_rec - a_half, p_krem, lds + wA * Q8_HALF, voffA, wave, lane); else q8_stage_half<A_KC, (PCS)>(sa_base + a_half, sa_rec - a_half, p_krem, lds + wA * Q8_HALF, voffA, wave, lane); } \
+                if ((PART) == 2) q8_stage_half<A_KC, (PCS)>(sa_base + a_half, sa_rec - a_half, p_krem, lds + wA * Q8_HALF, voffA, wave, lane);       \
                 if ((PART) == 3) q8_stage_half<B_KC, (PCS)>(sb_base + b_half, sb_rec - b_half, p_krem, lds + (NSLOT + wB) * Q8_HALF, voffB, wave, lane); \
             }                                                                                                            \
             if ((PCS) & 2) {                                                                                             \
@@ -298,22 +288,25 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
 #define Q8_STAGE_PART(PART) Q8_STAGE_PCS(PART, 3)
     // every DMA of mine has landed, except that the `N_` youngest vector-memory operations (issued after it) may be pending
 #define Q8_WAIT_DMA(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
-    // the same with `A_` of the instructions allowed to stay in flight being second pieces of A half-tiles
-#define Q8_WAIT_DMA_A(N_, A_) do { if (A96) Q8_WAIT_DMA((N_) - (A_)); else Q8_WAIT_DMA(N_); } while (0)
 
-    Q8Frag<A_KC> xm[4], ym[4];                        // two fragment groups (one k-step of 16 each): 4 M-side + 2 N-side
-    Q8Frag<B_KC> xn[2], yn[2];
+    Q8Frag<A_KC> xm[4];                               // the fragments of one phase (a k-step of 16): 4 M-side + 2 N-side
+    Q8Frag<B_KC> xn[2];
     int rA = 0, rB = 0;                               // ring slots of A_0 / B_0 of the K tile being multiplied
     float rs[4] = {0.f, 0.f, 0.f, 0.f}, rsp[4] = {0.f, 0.f, 0.f, 0.f};   // ROWSUM: running / finished-tile partial sums of row l31 of tile tm
     bool rs_on = false, rsp_on = false;
     int rsp_m0 = 0, rsp_prob = 0;
-    // this lane's 8 contraction values of M-side fragment F summed into S (strided operand: lo/hi halves)
+    // this lane's 8 contraction values of every M-side fragment summed into rs[]: four v_dot2c_f32_bf16 per fragment against a pair of
+    // bf16 ones -- or zeros for the waves / tiles that do not sum (rs_ones), so the code is branch-free and can sit between the MFMAs
+    // of a phase, where the matrix pipe hides it (no builtin lowers to the instruction on gfx950: inline asm, non-volatile)
+    unsigned rs_ones = 0u;
 #define Q8_RS_ACC(FM)                                                                                                    \
     do {                                                                                                                 \
-        _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_) {                                                              \
-            const hw_bf16x8 f_ = FM[t_].get();                                                                           \
-            const bf16x8 b_ = __builtin_bit_cast(bf16x8, f_);                                                            \
-            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) rs[t_] += bf2f((bf16_t)b_[e_]);                             \
+        typedef unsigned int q8_u32x4_ __attribute__((ext_vector_type(4)));                                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                               \
+            _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                          \
+                const q8_u32x4_ w_ = __builtin_bit_cast(q8_u32x4_, FM[t_].get());                                        \
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(rs[t_]) : "v"(w_[j_]), "v"(rs_ones));                           \
+            }                                                                                                            \
         }                                                                                                                \
     } while (0)
 
@@ -321,7 +314,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
 #define Q8_RD1(FM, FN, SM, SN, KS, I)                                                                                    \
     do {                                                                                                                 \
         constexpr int isn_ = ((I) == 0 || (I) == 3), idx_ = (I) == 0 ? 0 : (I) == 3 ? 1 : (I) < 3 ? (I) - 1 : (I) - 2;   \
-        if (!(DBG & 32) && (isn_ || idx_ < MT)) {                                                                        \
+        if (!(DBG & 32)) {                                                                        \
             if (isn_) { if (B_KC) FN[idx_].template read<idx_ * 4096>((SN) + offN[KS]); else FN[idx_].template read<(KS) * 4096>((SN) + offN[idx_]); } \
             else      { if (A_KC) FM[idx_].template read<idx_ * 4096>((SM) + offM[KS]); else FM[idx_].template read<(KS) * 4096>((SM) + offM[idx_]); } \
         }                                                                                                                \
@@ -332,8 +325,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
 #define Q8_MFMA1(FM, FN, J, ZERO)                                                                                        \
     do {                                                                                                                 \
         constexpr int q_ = (J) >> 1, mh_ = q_ >> 1, nh_ = (q_ == 1 || q_ == 2) ? 1 : 0, tm_ = 2 * mh_ + ((J) & 1);       \
-        if (tm_ >= MT) {                                                                                                 \
-        } else if (DBG & 1) {                                                                                            \
+        if (DBG & 1) {                                                                                            \
             asm volatile("" ::"v"(FN[nh_].get()), "v"(FM[tm_].get()));                                                   \
             if (ZERO) acc[tm_][nh_] = zero16;                                                                            \
         } else {                                                                                                         \
@@ -360,7 +352,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     // The accumulators are only READ: the first K tile of the next output tile starts from C = 0 in the MFMA itself.
     auto store_quadrant = [&](int tm0, int tn0, int tz, auto mh_c, auto nh_c) {
         constexpr int MH = decltype(mh_c)::value, NH = decltype(nh_c)::value;
-        constexpr int NTM = (MH == 1 && MT == 3) ? 1 : 2;   // 32-row blocks of this quadrant
+        constexpr int NTM = 2;   // 32-row blocks of this quadrant
         if (DBG & 4) {   // keep the accumulators (and so the MFMAs) alive without storing them
 #pragma unroll
             for (int tm = 0; tm < NTM; ++tm) asm volatile("" ::"v"(acc[2 * MH + tm][NH]));
@@ -379,7 +371,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                 }
             return;
         }
-        const int mb = tm0 + wr * (32 * MT) + MH * 64;             // wave-uniform first row / column of the quadrant
+        const int mb = tm0 + wr * 128 + MH * 64;             // wave-uniform first row / column of the quadrant
         const int nb = tn0 + wc * 64 + NH * 32;
         const bool edge = nb + 32 > g.N;                     // uniform: some groups of 8 lie past N
         // wave-uniform addresses in the constant address space, pinned to SGPRs: scalar loads (lgkmcnt) that do not touch the DMA
@@ -508,67 +500,48 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         if ((Q) == 3) store_quadrant(TM0, TN0, TZ, I1(), I0());                               \
     } while (0)
 #define Q8_SB() __builtin_amdgcn_sched_barrier(0)
-    // one group of a K tile: 8 MFMAs on group (CM, CN) with the six fragment reads of the NEXT group (NM, NN) <- k-step NKS of the
-    // half-tiles at NSM / NSN issued one by one between them, and the two DMA instructions of half-tile part D (-1: none; D2: a
-    // second part) -- wave row 0 in the slots after MFMA 0-3, wave row 1 after MFMA 4-7 (see header).  EPI_HOOK: the previous
-    // output tile's quadrants are stored ahead of the MFMAs that overwrite them.  Fragments read by hipcc-tracked loads need no
-    // explicit wait (lgkmcnt(n) per MFMA); asm transpose reads are waited for at the top.
-#define Q8_DMA_SLOT(J, DA, DB)                                                                                           \
+    // ---- one PHASE = one k-step of 16 of a K tile: [load interval: the six fragment reads of this phase, one half-tile part of DMA,
+    // the waits] barrier [matrix interval: 8 MFMAs back to back at raised priority] barrier.  Wave row 1 runs one barrier behind wave
+    // row 0, so the two intervals of the two waves of a SIMD alternate (see header).  DMA of K tile t, one part per phase, in stream
+    // order: A_1(t+1), B_1(t+1), A_0(t+2), B_0(t+2).  Ring reuse (5 half-tile slots per operand): A_1 / B_1 of K tile u overwrite
+    // A_0 / B_0 of K tile u-2, A_0 / B_0 of K tile u the slot of A_1 / B_1 of K tile u-3; the last reads of a slot are retired
+    // (lgkmcnt(0)) before the barrier that precedes the overwriting DMA's issue, for either wave row.  Phase 3 waits for the four
+    // parts of K tile t+1 (the four DMA instructions of phases 2-3 are younger and stay in flight); each row's wait is followed by
+    // a barrier before anyone reads K tile t+1.
+    // PRE_HOOK (first phase of an output tile): the previous tile's epilogue -- its accumulators are overwritten by this phase's
+    // MFMAs, which start from C = 0 -- and the bias-gradient atomics; all older than the DMA the next wait covers.
+#define Q8_PHASE(KS, DPART, WAIT, ZERO, PRE_HOOK)                                                                     \
     do {                                                                                                                 \
-        if (((J) & 3) == 0 && (DA) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DA) < 0 ? 0 : (DA), 1); Q8_SB(); }          \
-        if (((J) & 3) == 1 && (DA) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DA) < 0 ? 0 : (DA), 2); Q8_SB(); }          \
-        if (((J) & 3) == 2 && (DB) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DB) < 0 ? 0 : (DB), 1); Q8_SB(); }          \
-        if (((J) & 3) == 3 && (DB) >= 0 && wr == ((J) >> 2)) { Q8_STAGE_PCS((DB) < 0 ? 0 : (DB), 2); Q8_SB(); }          \
-    } while (0)
-#define Q8_GROUP(CM, CN, NM, NN, NSM, NSN, NKS, DA, DB, EPI_HOOK, ZERO)                                                  \
-    do {                                                                                                                 \
-        if (!A_KC || !B_KC) { q8_wait4(CM); q8_wait2(CN); Q8_SB(); }                                                     \
-        if (ROWSUM) { if (rs_on) { Q8_RS_ACC(CM); } Q8_SB(); }                                                           \
-        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                                                   \
-        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); } Q8_SB(); }                                       \
-        Q8_MFMA1(CM, CN, 0, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 0); Q8_SB(); Q8_DMA_SLOT(0, DA, DB);           \
-        Q8_MFMA1(CM, CN, 1, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 1); Q8_SB(); Q8_DMA_SLOT(1, DA, DB);           \
-        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 1); } Q8_SB(); }                                       \
-        Q8_MFMA1(CM, CN, 2, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 2); Q8_SB(); Q8_DMA_SLOT(2, DA, DB);           \
-        Q8_MFMA1(CM, CN, 3, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 3); Q8_SB(); Q8_DMA_SLOT(3, DA, DB);           \
-        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 2); } Q8_SB(); }                                       \
-        Q8_MFMA1(CM, CN, 4, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 4); Q8_SB(); Q8_DMA_SLOT(4, DA, DB);           \
-        Q8_MFMA1(CM, CN, 5, ZERO); Q8_SB(); Q8_RD1(NM, NN, NSM, NSN, NKS, 5); Q8_SB(); Q8_DMA_SLOT(5, DA, DB);           \
-        if (EPI_HOOK) { if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 3); } if (ROWSUM) { if (rsp_on) rowsum_flush(); } Q8_SB(); } \
-        Q8_MFMA1(CM, CN, 6, ZERO); Q8_SB(); Q8_DMA_SLOT(6, DA, DB);                                                      \
-        Q8_MFMA1(CM, CN, 7, ZERO); Q8_SB(); Q8_DMA_SLOT(7, DA, DB);                                                      \
-        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);                                                                   \
-    } while (0)
-
-    // ---- one K tile t = four groups (k-steps of 16), fragments double-buffered X/Y one group ahead.  DMA issued during it:
-    //   group 0: B_1(t+1)   group 1: A_0(t+2)   group 2: B_0(t+2)   [barrier]   group 3: A_1(t+2)
-    // (A_1 / B_1 of K tile u overwrite A_0 / B_0 of K tile u-2, free after the barrier of K tile u-2; A_0 / B_0 of K tile u go to
-    // the ring's fifth slot, vacated a K tile earlier.)  At the barrier K tile t+1 must have landed: the 4 DMA instructions of
-    // groups 1-2 are younger and may stay in flight.
-    // FIRST: first K tile of an output tile: the previous tile's quadrants are stored between the quadrants of group 0, whose MFMAs
-    //        start from C = 0; its group 0 issues no DMA (see LAST).
-    // LAST:  last K tile: group 3 also issues the next tile's group-0 part, so that every DMA the next barrier waits for is OLDER
-    //        than the epilogue's stores and the wait can exclude exactly them.
-    // Literal flags: three straight-line copies of the body (no accumulator is live across a branch that writes it).
-#define Q8_KTILE(FIRST, LAST)                                                                                            \
-    do {                                                                                                                 \
-        const int ra_ = rA + wr, rb_ = rB + (wc >> 1), na_ = rA + 2 + wr, nb_ = rB + 2 + (wc >> 1);                      \
-        const bool rsp_was = ROWSUM && (FIRST) && rsp_on;   /* 4 atomics follow this tile's epilogue stores */            \
-        const unsigned char* sM = lds + (ra_ >= NSLOT ? ra_ - NSLOT : ra_) * Q8_HALF;                                    \
-        const unsigned char* sN = lds + (NSLOT + (rb_ >= NSLOT ? rb_ - NSLOT : rb_)) * Q8_HALF;                          \
-        const unsigned char* tM = lds + (na_ >= NSLOT ? na_ - NSLOT : na_) * Q8_HALF;                                    \
-        const unsigned char* tN = lds + (NSLOT + (nb_ >= NSLOT ? nb_ - NSLOT : nb_)) * Q8_HALF;                          \
-        Q8_GROUP(xm, xn, ym, yn, sM, sN, 1, (FIRST) ? -1 : 3, -1, FIRST, FIRST);                                         \
-        Q8_GROUP(ym, yn, xm, xn, sM, sN, 2, 0, -1, false, false);                                                        \
-        Q8_GROUP(xm, xn, ym, yn, sM, sN, 3, 1, -1, false, false);                                                        \
-        /* group 3: every fragment of this K tile has arrived (slot free); my DMA of the next K tile has landed (published) */ \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-        if (pdone) Q8_WAIT_DMA(0);   /* end of the stream: groups 1-2 issued nothing */                                   \
-        else if ((FIRST) && have_pend) { if (ROWSUM && rsp_was) Q8_WAIT_DMA(MT * NST + 8); else Q8_WAIT_DMA_A(MT * NST + 4, 1); } \
-        else Q8_WAIT_DMA_A(4, 1);   /* in flight: A_0 and B_0 of K tile t+2 (groups 1-2) */                              \
+        if (PRE_HOOK) {                                                                                                  \
+            if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); } \
+            if (ROWSUM) { if (rsp_on) rowsum_flush(); }                                                                  \
+            Q8_SB();                                                                                                     \
+        }                                                                                                                \
+        Q8_READ_GROUP(xm, xn, sM, sN, KS); Q8_SB();                                                                      \
+        Q8_STAGE_PART(DPART); Q8_SB();                                                                                   \
+        if (WAIT) { if (pdone) Q8_WAIT_DMA(0); else Q8_WAIT_DMA(4); }   /* in flight: A_0 and B_0 of K tile t+2 */   \
+        if (!A_KC || !B_KC) { q8_wait4(xm); q8_wait2(xn); }                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); Q8_SB();                                                      \
         if (!(DBG & 16)) __builtin_amdgcn_s_barrier();                                                                   \
         Q8_SB();                                                                                                         \
-        Q8_GROUP(ym, yn, xm, xn, tM, tN, 0, 2, (LAST) ? 3 : -1, false, false);                                           \
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                                                   \
+        if (ROWSUM) { Q8_RS_ACC(xm); }   /* no scheduling fence: the compiler spreads these between the MFMAs */          \
+        Q8_MFMA1(xm, xn, 0, ZERO); Q8_MFMA1(xm, xn, 1, ZERO); Q8_MFMA1(xm, xn, 2, ZERO); Q8_MFMA1(xm, xn, 3, ZERO);      \
+        Q8_MFMA1(xm, xn, 4, ZERO); Q8_MFMA1(xm, xn, 5, ZERO); Q8_MFMA1(xm, xn, 6, ZERO); Q8_MFMA1(xm, xn, 7, ZERO);      \
+        Q8_SB();                                                                                                         \
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);                                                                   \
+        if (!(DBG & 16)) __builtin_amdgcn_s_barrier();                                                                   \
+        Q8_SB();                                                                                                         \
+    } while (0)
+#define Q8_KTILE(FIRST)                                                                                               \
+    do {                                                                                                                 \
+        const int ra_ = rA + wr, rb_ = rB + (wc >> 1);                                                                   \
+        const unsigned char* sM = lds + (ra_ >= NSLOT ? ra_ - NSLOT : ra_) * Q8_HALF;                                    \
+        const unsigned char* sN = lds + (NSLOT + (rb_ >= NSLOT ? rb_ - NSLOT : rb_)) * Q8_HALF;                          \
+        Q8_PHASE(0, 2, false, FIRST, FIRST);                                                                          \
+        Q8_PHASE(1, 3, false, false, false);                                                                          \
+        Q8_PHASE(2, 0, false, false, false);                                                                          \
+        Q8_PHASE(3, 1, true, false, false);                                                                           \
         rA = rA + 2 >= NSLOT ? rA + 2 - NSLOT : rA + 2;                                                                  \
         rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
     } while (0)
@@ -578,23 +551,17 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         const long long d = (long long)(blockIdx.x & 3) * 900;
         while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
     }
-    // prologue: K tiles 0 and 1 issued, K tile 0 landed and published, its first group requested
+    // prologue: K tile 0 and A_0 / B_0 of K tile 1 issued, K tile 0 landed and published
     Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
-    Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
-    Q8_WAIT_DMA_A(8, 2);   // in flight: the second K tile (two A half-tiles among its four parts)
+    Q8_STAGE_PART(0); Q8_STAGE_PART(1);
+    Q8_WAIT_DMA(4);    // in flight: A_0 and B_0 of the second K tile
     __builtin_amdgcn_s_barrier();
-    Q8_READ_GROUP(xm, xn, lds + wr * Q8_HALF, lds + (NSLOT + (wc >> 1)) * Q8_HALF, 0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind (wave row 0 makes up for it at the end)
     if constexpr ((DBG & 32) != 0 && A_KC && B_KC) {   // timing decomposition: real (random) fragments, read once and never again
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xm[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + offM[0] + i * 4096);
-            ym[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + offM[1] + i * 4096);
-        }
+        for (int i = 0; i < 4; ++i) xm[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + offM[0] + i * 4096);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            xn[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + NSLOT * Q8_HALF + offN[0] + i * 4096);
-            yn[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + NSLOT * Q8_HALF + offN[1] + i * 4096);
-        }
+        for (int i = 0; i < 2; ++i) xn[i].v = *reinterpret_cast<const hw_bf16x8*>(lds + NSLOT * Q8_HALF + offN[0] + i * 4096);
     }
 
     // ---- main loop over this workgroup's output tiles (every tile has at least two K tiles: the host guarantees K/split >= 128)
@@ -605,16 +572,15 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         if (ITEMS) {
             const Q8ItemRec cr = item_at(cv);
             cm0 = cr.m0; cn0 = cr.prob; cz = cr.slab; cnt = (cr.kend - cr.kbeg + 63) >> 6;
-            if (ROWSUM) rs_on = (cr.flags & 1) != 0 && wc == 0 && Q8_PROB(cr.prob, rowsum) != nullptr;
+            if (ROWSUM) { rs_on = (cr.flags & 1) != 0 && wc == 0 && Q8_PROB(cr.prob, rowsum) != nullptr; rs_ones = rs_on ? 0x3f803f80u : 0u; }
         } else {
-            const Q8Item cit = q8_decode<MT>(g, cv, total);
+            const Q8Item cit = q8_decode(g, cv, total);
             cm0 = cit.m0; cn0 = cit.n0; cz = cit.z; cnt = cit.nt;
-            if (ROWSUM) rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0;
+            if (ROWSUM) { rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0; rs_ones = rs_on ? 0x3f803f80u : 0u; }
         }
-        Q8_KTILE(true, false);
+        Q8_KTILE(true);
 #pragma unroll 1
-        for (int t = 2; t < cnt; ++t) Q8_KTILE(false, false);
-        Q8_KTILE(false, true);
+        for (int t = 1; t < cnt; ++t) Q8_KTILE(false);
         have_pend = true; pm0 = cm0; pn0 = cn0; pz = cz;
         if (ROWSUM) {
             rsp_on = rs_on; rsp_m0 = cm0; rsp_prob = cn0;
@@ -622,11 +588,9 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
             for (int t = 0; t < 4; ++t) { rsp[t] = rs[t]; rs[t] = 0.f; }
         }
     }
-    if (!A_KC || !B_KC) { q8_wait4(xm); q8_wait2(xn); }   // the dangling request of the group after the last
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // wave row 0's share of the row lag
     if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); }
     if (ROWSUM) { if (rsp_on) rowsum_flush(); }
-#undef Q8_GROUP
 #undef Q8_STORE_Q
 #undef Q8_SB
 #undef Q8_READ_GROUP
@@ -634,23 +598,21 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
 #undef Q8_RD1
 #undef Q8_STAGE_PART
 #undef Q8_STAGE_PCS
-#undef Q8_DMA_SLOT
 #undef Q8_RS_ACC
 #undef Q8_KTILE
+#undef Q8_PHASE
 #undef Q8_NEXT_ITEM
 #undef Q8_WAIT_DMA
-#undef Q8_WAIT_DMA_A
 }
 #undef Q8_PROB
 
-template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false, int MT = 4>
+template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false>
 __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     Q8Group none;   // never read in this form
-    q8_body<A_KC, B_KC, EPI, DBG, ROWSUM, MT, false>(g, none);
+    q8_body<A_KC, B_KC, EPI, DBG, ROWSUM, false>(g, none);
 }
 // grouped weight gradients: `g` only supplies the fields the item-table form does not take from the group (none of the operands)
 template <bool ROWSUM>
 __global__ __launch_bounds__(512) void gemm_bf16_q8_items_kernel(GemmArgs g, Q8Group GR) {
-    q8_body<false, false, 4, 0, ROWSUM, 4, true>(g, GR);
+    q8_body<false, false, 4, 0, ROWSUM, true>(g, GR);
 }
-

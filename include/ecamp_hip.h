@@ -80,11 +80,9 @@ int64_t ecamp_sr_bwd_workspace_bytes(void);
  * one-workgroup-per-CU kernel.  "p8_wgrad_reserve_cus" (default 0): launch that kernel with this many fewer workgroups than CUs --
  * set by the data-parallel wrapper, whose all-reduce kernels share the CUs during backward. */
 int ecamp_set_option(const char* name, int32_t value);
-/* "q8_mode" (ecamp_set_option): -1 automatic (default), 0 never, 2 whenever its alignment / size conditions hold -- the round-2
+/* "q8_mode" (ecamp_set_option): -1 automatic (default), 0 never, 2 whenever its alignment / size conditions hold -- the
  * persistent 256x256x64 kernel (csrc/gemm_q8.h) that serves the forward, data-gradient and weight-gradient forms.
  * Development aid: number of GEMM calls the library has routed to that kernel so far (tests assert that it really ran). */
-/* "q8_mt" (ecamp_set_option; env ECAMP_Q8_MT): 0 automatic (default), 3 / 4 force the 192 x 256 / 256 x 256 tile of that kernel
- * in the forward and data-gradient forms (the 192-row tile is picked by itself where it saves >= 10 % of rounds x rows). */
 /* "attn_head" (ecamp_set_option): 1 (default; env ECAMP_ATTN_HEAD) one workgroup per (batch, head) with everything resident in LDS
  * for sequences that fit (<= 256 tokens here), 0 the 64-row streaming kernels for every length, -1 back to the environment's choice */
 int64_t ecamp_gemm_q8_launches(void);

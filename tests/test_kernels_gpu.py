@@ -687,28 +687,6 @@ def test_gemm_q8_dgrad_wgrad_ragged(dev, q8_always, M, N, K):
     assert _q8_count() >= n0 + 5, "the Q8 kernel did not run"
 
 
-@pytest.fixture
-def q8_tile192():
-    """The Q8 kernel with its 192 x 256 tile forced (gemm_q8.h, MT = 3; by itself it is only picked for shapes like 12800 x 768)."""
-    o = ops()
-    o.set_option("q8_mode", 2)
-    o.set_option("q8_mt", 3)
-    yield o
-    o.set_option("q8_mt", 0)
-    o.set_option("q8_mode", -1)
-
-
-@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 2304, 768), (12800, 768, 768), (1000, 1000, 200), (577, 520, 136)])
-def test_gemm_q8_tile192_ragged(dev, q8_tile192, M, N, K):
-    """Forward epilogues (bias, residual; the GELU form stays on the 256-row tile) and data gradients (plain, gelu', residual) on the
-    192-row tile: row counts that end inside the first / second / third 32-row block of a wave row, one and many tiles per workgroup,
-    and the production shape that selects it (201 tiles)."""
-    n0 = _q8_count()
-    test_gemm_fwd_epilogues(dev, torch.bfloat16, M, N, K)
-    test_gemm_dgrad_wgrad(dev, torch.bfloat16, M, N, K)
-    assert _q8_count() >= n0 + 6, "the Q8 kernel did not run"
-
-
 def test_gemm_full_size_kernels_agree(dev):
     """BASELINE configs[1] sizes (timm Mlp.fc1 of the encoder at B=256: 12800 x 3072 x 768): forward with bias + GELU + saved
     pre-activation, data gradient through GELU', weight + bias gradient -- the persistent kernel against the 128^2 kernel on the
