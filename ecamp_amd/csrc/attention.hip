@@ -588,10 +588,11 @@ static void bwd_dispatch(const AttnArgs& a, hipStream_t st) {
     LAUNCH_LDS((attn_bwd_dkv_kernel<T, HD>), grid2, block, shm2, st, a);
 }
 
+extern "C" int64_t ecamp_attn_mask_bytes(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t dtype);
 extern "C" int ecamp_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* key_mask,
                               int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, const int64_t* q_strides,
                               const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, float scale,
-                              float drop_p, uint64_t seed, uint64_t offset, int32_t dtype, hipStream_t stream) {
+                              float drop_p, uint64_t seed, uint64_t offset, int32_t dtype, void* drop_mask, hipStream_t stream) {
     ECAMP_CHECK_ARG(q && k && v && o && lse && q_strides && k_strides && v_strides && o_strides, "attn_fwd: null pointer");
     AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -601,6 +602,7 @@ extern "C" int ecamp_attn_fwd(const void* q, const void* k, const void* v, void*
     a.v_sb = v_strides[0]; a.v_st = v_strides[1]; a.v_sh = v_strides[2];
     a.o_sb = o_strides[0]; a.o_st = o_strides[1]; a.o_sh = o_strides[2];
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
+    a.drop_bits = (dtype == ECAMP_BF16 && drop_p > 0.f && ecamp_attn_mask_bytes(B, H, Tq, Tk, hd, dtype) > 0) ? reinterpret_cast<unsigned char*>(drop_mask) : nullptr;
     if (int rc = attn_check(a, hd, dtype, false)) return rc;
     const bool prof = ecamp_prof_active();
     if (prof) ecamp_prof_begin(ECAMP_PROF_ATTN, 4.0 * B * H * (double)Tq * Tk * hd, stream);
@@ -617,6 +619,13 @@ extern "C" int ecamp_attn_fwd(const void* q, const void* k, const void* v, void*
     return 0;
 }
 
+// Bytes of the optional `drop_mask` buffer (32 per query row and head): 0 when the shape is not served by the head-resident bf16
+// kernels under the current options -- the caller then passes NULL and every pass regenerates the mask from the Philox counters.
+extern "C" int64_t ecamp_attn_mask_bytes(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t dtype) {
+    if (dtype != ECAMP_BF16 || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || Tk > 256) return 0;
+    if (hd != 32 && hd != 64 && hd != 128) return 0;
+    return attn_bf16_head_path(Tq, Tk, hd, false) ? (int64_t)B * H * Tq * 32 : 0;
+}
 // Workspace of ecamp_attn_bwd(..., delta_ws, ...): delta[b, h, i] = dO_i . O_i, one f32 per query row.
 extern "C" int64_t ecamp_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq) { return (int64_t)B * H * Tq * 4; }
 
@@ -625,7 +634,7 @@ extern "C" int ecamp_attn_bwd(const void* q, const void* k, const void* v, const
                               int32_t Tq, int32_t Tk, int32_t hd, const int64_t* q_strides, const int64_t* k_strides,
                               const int64_t* v_strides, const int64_t* o_strides, const int64_t* do_strides,
                               const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides, float scale,
-                              float drop_p, uint64_t seed, uint64_t offset, int32_t dtype, hipStream_t stream) {
+                              float drop_p, uint64_t seed, uint64_t offset, int32_t dtype, const void* drop_mask, hipStream_t stream) {
     ECAMP_CHECK_ARG(q && k && v && o && dout && lse && delta_ws && dq && dk && dv, "attn_bwd: null pointer");
     AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -640,6 +649,7 @@ extern "C" int ecamp_attn_bwd(const void* q, const void* k, const void* v, const
     a.dk_sb = dk_strides[0]; a.dk_st = dk_strides[1]; a.dk_sh = dk_strides[2];
     a.dv_sb = dv_strides[0]; a.dv_st = dv_strides[1]; a.dv_sh = dv_strides[2];
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
+    a.drop_bits = (dtype == ECAMP_BF16 && drop_p > 0.f) ? reinterpret_cast<unsigned char*>(const_cast<void*>(drop_mask)) : nullptr;
     if (int rc = attn_check(a, hd, dtype, true)) return rc;
     const bool prof = ecamp_prof_active();
     if (prof) ecamp_prof_begin(ECAMP_PROF_ATTN, 8.0 * B * H * (double)Tq * Tk * hd, stream);

@@ -825,13 +825,18 @@ __global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
                 sum += p[r] + p[4 + r];
             }
             if (FLAGS && a.drop_p > 0.f) {
-                float dm[4];
+                float dm[4], dn[4];
                 attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 4 * g, inv_keep, dm);
+                attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 16 + 4 * g, inv_keep, dn);
+                unsigned bits = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] *= dm[r];
-                attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 16 + 4 * g, inv_keep, dm);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[4 + r] *= dm[r];
+                for (int r = 0; r < 4; ++r) {
+                    p[r] *= dm[r];
+                    p[4 + r] *= dn[r];
+                    bits |= (dm[r] != 0.f ? 1u << r : 0u) | (dn[r] != 0.f ? 16u << r : 0u);
+                }
+                // the mask leaves as bits for the backward pass (the only Philox evaluation of this score)
+                if (a.drop_bits && qi < a.Tq) a.drop_bits[(((long)bh * a.Tq + qi) * 4 + g) * 8 + pp] = (unsigned char)bits;
             }
             const bf16x8 pf = hpack8(p);
 #pragma unroll
@@ -864,9 +869,11 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
     float* KB = reinterpret_cast<float*>(smem + 2 * prow * RB);   // key bias, prow entries
     float* LS = KB + prow;                                        // lse in base-2 units (+1e30 past Tq: p = 0)
     float* DL = LS + prow;                                        // delta = rowsum(dO * O)
+    unsigned char* MB = reinterpret_cast<unsigned char*>(DL + prow);   // phase 2 (saved dropout bits only): [g][pp][row] bytes, 32 * prow
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const long bh = blockIdx.x;
+    const bool use_bits = FLAGS && a.drop_p > 0.f && a.drop_bits != nullptr;   // the forward pass left the keep-mask as bits
     const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_sb + h * a.q_sh;
     const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_sb + h * a.k_sh;
     const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_sb + h * a.v_sh;
@@ -883,11 +890,13 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
     // the fragments a wave owns come from global memory; the first block's are requested before the staging loads
     bf16x8 qf[HD / 32], gf[HD / 32], of[HD / 32];
     float lse_c = 0.f;
+    uint2 mw = make_uint2(0u, 0u);   // this lane's mask bytes of its query row: byte pp = key tiles 2pp (low nibble) and 2pp + 1
     auto load_q = [&](int q0, bf16x8 (&q_)[HD / 32], bf16x8 (&g_)[HD / 32], bf16x8 (&o_)[HD / 32], float& l_) {
         load_row_frags<HD>(q_, qb, a.q_st, q0, a.Tq, lane);
         load_row_frags<HD>(g_, gb, a.do_st, q0, a.Tq, lane);
         load_row_frags<HD>(o_, ob, a.o_st, q0, a.Tq, lane);
         l_ = q0 + li < a.Tq ? a.lse[bh * a.Tq + q0 + li] : 0.f;
+        if (use_bits && q0 + li < a.Tq) mw = *reinterpret_cast<const uint2*>(a.drop_bits + (((long)bh * a.Tq + q0 + li) * 4 + g) * 8);
     };
     if (wave * 16 < a.Tq) load_q(wave * 16, qf, gf, of, lse_c);
     head_stage<HD>(XI, kb, a.k_st, a.Tk, prow, tid, nthr);
@@ -937,7 +946,13 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
                 }
                 if (FLAGS && a.drop_p > 0.f) {
                     float dm[4];
-                    attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+                    if (use_bits) {
+                        const unsigned nib = ((pp < 4 ? mw.x : mw.y) >> (8 * (pp & 3) + 4 * hf)) & 15u;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dm[r] = (nib >> r) & 1u ? inv_keep : 0.f;
+                    } else {
+                        attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+                    }
                     d0 *= (f32x2){dm[0], dm[1]};
                     d1 *= (f32x2){dm[2], dm[3]};
                 }
@@ -967,10 +982,21 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
     __syncthreads();
     head_stage<HD>(XI, qb, a.q_st, a.Tq, prow, tid, nthr);
     head_stage<HD>(YI, gb, a.do_st, a.Tq, prow, tid, nthr);
+    if (use_bits) {   // the head's mask bytes, transposed so that the four query rows of a lane are four consecutive bytes
+        for (int i = tid; i < a.Tq * 4; i += nthr) {
+            const int row = i >> 2, gg = i & 3;
+            const uint2 w = *reinterpret_cast<const uint2*>(a.drop_bits + ((long)bh * a.Tq * 4 + i) * 8);
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) MB[(gg * 8 + pp) * prow + row] = (unsigned char)(((pp < 4 ? w.x : w.y) >> (8 * (pp & 3))) & 255u);
+        }
+    }
     __syncthreads();
     for (int j0 = wave * 16; j0 < a.Tk; j0 += nw * 16) {
         const int kj = j0 + li;
         const bool jok = KB[kj] == 0.f;
+        // this lane's key in the forward pass's byte layout: tile pair, 4-key group, bit position
+        const unsigned char* mcol = MB + ((((kj & 15) >> 2) * 8 + (kj >> 5)) * prow);
+        const int mbit = 4 * ((kj >> 4) & 1) + (kj & 3);
         f32x4 dk[HD / 16], dv[HD / 16];   // [dt][r] = dK / dV[j = j0+li][d = dt*16 + 4g + r]
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -994,7 +1020,13 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
                 f32x2 p1 = hexp2((f32x2){s[2], s[3]} * sc - (f32x2){lse4[2], lse4[3]});
                 if (FLAGS && a.drop_p > 0.f) {
                     float dm[4];
-                    attn_drop4_col(a, (uint64_t)bh * a.Tq + (it * 16 + 4 * g), kj, li, inv_keep, dm);
+                    if (use_bits) {
+                        const unsigned m4 = *reinterpret_cast<const unsigned*>(mcol + it * 16 + 4 * g) >> mbit;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dm[r] = (m4 >> (8 * r)) & 1u ? inv_keep : 0.f;
+                    } else {
+                        attn_drop4_col(a, (uint64_t)bh * a.Tq + (it * 16 + 4 * g), kj, li, inv_keep, dm);
+                    }
                     const f32x2 m0 = {dm[0], dm[1]}, m1 = {dm[2], dm[3]};
                     d0 *= m0; d1 *= m1;
                     pdp[2 * hf] = hpk(p0 * m0);
@@ -1076,7 +1108,8 @@ static bool head_fwd(const AttnArgs& a, hipStream_t st) {
 template <int HD>
 static bool head_bwd(const AttnArgs& a, hipStream_t st) {
     const int nkt = (a.Tk + 15) / 16, nqt = (a.Tq + 15) / 16, nkp = (nkt + 1) / 2, nqp = (nqt + 1) / 2, prow = (nkp > nqp ? nkp : nqp) * 32;
-    const size_t shm = (size_t)2 * prow * HeadCfg<HD>::RB + (size_t)3 * prow * sizeof(float);
+    const bool bits = a.drop_bits != nullptr && a.drop_p > 0.f;
+    const size_t shm = (size_t)2 * prow * HeadCfg<HD>::RB + (size_t)3 * prow * sizeof(float) + (bits ? (size_t)32 * prow : 0);
     if (!head_enabled() || shm > LDS_MAX) return false;
     const dim3 grid(a.B * a.H);
     // four waves: two (hd = 128: the register file) to five workgroups share a CU and one's staging overlaps another's tile loops
@@ -1129,6 +1162,14 @@ static void bwd16(const AttnArgs& a, hipStream_t st) {
     dim3 grid2(ceil_div(a.Tk, 64), a.B * a.H);
     size_t shm2 = 2 * TileCfg<HD>::BYTES + 8 * 2048 + 128 * sizeof(float);
     hipLaunchKernelGGL((attn16_bwd_dkv_kernel<HD>), grid2, block, shm2, st, a);
+}
+bool attn_bf16_head_path(int Tq, int Tk, int hd, bool backward) {
+    const int nkt = (Tk + 15) / 16, nqt = (Tq + 15) / 16, nkp = (nkt + 1) / 2, nqp = (nqt + 1) / 2;
+    const size_t rb = hd == 32 ? HeadCfg<32>::RB : hd == 64 ? HeadCfg<64>::RB : HeadCfg<128>::RB;
+    size_t shm;
+    if (backward) { const size_t prow = (size_t)(nkp > nqp ? nkp : nqp) * 32; shm = 2 * prow * rb + 3 * prow * sizeof(float) + 32 * prow; }
+    else { const size_t prow = (size_t)nkp * 32; shm = 2 * prow * rb + prow * sizeof(float); }
+    return head_enabled() && shm <= LDS_MAX;
 }
 void attn_bf16_fwd(const AttnArgs& a, int hd, hipStream_t st) {
     if (hd == 32) fwd16<32>(a, st); else if (hd == 64) fwd16<64>(a, st); else fwd16<128>(a, st);

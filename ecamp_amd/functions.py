@@ -414,18 +414,18 @@ def _self_attn_fwd(m, att, out, h, B, S, key_mask, pa, ph, tape):
     st = (S * 3 * H, 3 * H, hd)
     f = qkv.view(-1)
     s1, o1 = m.next_rng()
-    a, lse = ops.attn_fwd(f, f[H:], f[2 * H:], B, heads, S, S, hd, st, st, st, 1.0 / math.sqrt(hd), key_mask, pa, s1, o1)
+    a, lse, bits = ops.attn_fwd(f, f[H:], f[2 * H:], B, heads, S, S, hd, st, st, st, 1.0 / math.sqrt(hd), key_mask, pa, s1, o1, want_mask=True)
     a = a.view(B * S, H)
     y = ops.linear_fwd(a, A.w(out.dense.weight), out.dense.bias.data)
     s2, o2 = m.next_rng()
     ln = out.LayerNorm
     o, z, mean, rstd = ops.layernorm_fwd(y, ln.weight.data, ln.bias.data, ln.eps, residual=h, drop_p=ph, seed=s2, offset=o2)
-    tape.append((att, out, h, qkv, a, lse, z, mean, rstd, (s1, o1), (s2, o2)))
+    tape.append((att, out, h, qkv, a, lse, z, mean, rstd, (s1, o1), (s2, o2), bits))
     return o
 
 
 def _self_attn_bwd(m, rec, dout, B, S, key_mask, pa, ph):
-    att, out, h, qkv, a, lse, z, mean, rstd, (s1, o1), (s2, o2) = rec
+    att, out, h, qkv, a, lse, z, mean, rstd, (s1, o1), (s2, o2), bits = rec
     A = m.arena
     G = A.grad
     H = h.shape[1]
@@ -442,7 +442,7 @@ def _self_attn_bwd(m, rec, dout, B, S, key_mask, pa, ph):
     st = (S * 3 * H, 3 * H, hd)
     f, df = qkv.view(-1), dqkv.view(-1)
     ops.attn_bwd(f, f[H:], f[2 * H:], a.view(B, S, H), da.view(B, S, H), lse, df, df[H:], df[2 * H:], B, heads, S, S, hd, st, st, st,
-                 st, st, st, 1.0 / math.sqrt(hd), key_mask, pa, s1, o1)
+                 st, st, st, 1.0 / math.sqrt(hd), key_mask, pa, s1, o1, drop_bits=bits)
     qkvp = _qkv_params(att)
     _wgrad(A, dqkv, h, [l.weight for l in qkvp], shape=(3 * H, H), gb=A.fused_grad([l.bias for l in qkvp], (3 * H,)))
     dh = ops.linear_dgrad(dqkv, A.fused_w([l.weight for l in qkvp], (3 * H, H)), residual=dz)
@@ -518,7 +518,7 @@ class FusionFn(torch.autograd.Function):
         f = kv.view(-1)
         qs, ks = (S * H, H, hd), (T * 2 * H, 2 * H, hd)
         s1, o1 = m.next_rng()
-        c, lse = ops.attn_fwd(q, f[2 * H:], f[3 * H:], B, heads, S, T - 1, hd, qs, ks, ks, 1.0 / math.sqrt(hd), None, pa, s1, o1)
+        c, lse, cbits = ops.attn_fwd(q, f[2 * H:], f[3 * H:], B, heads, S, T - 1, hd, qs, ks, ks, 1.0 / math.sqrt(hd), None, pa, s1, o1, want_mask=True)
         gp = ops.linear_fwd(gap, A.w(fl.gap_mlp.weight), fl.gap_mlp.bias.data)
         c2 = ops.bcast_add(c, gp).view(B * S, H)
         ol = fl.out_layer
@@ -527,12 +527,12 @@ class FusionFn(torch.autograd.Function):
         a2, z, mean, rstd = ops.layernorm_fwd(y, ol.LayerNorm.weight.data, ol.LayerNorm.bias.data, ol.LayerNorm.eps, residual=a1,
                                               drop_p=ph, seed=s2, offset=o2)
         out = _ffn_fwd(m, fl.intermediate, fl.output, a2, ph, tape)
-        ctx.s = (tape, e, lat, gap, fl, m, B, S, T, key_mask, pa, ph, a1, q, kv, c, lse, c2, z, mean, rstd, (s1, o1), (s2, o2))
+        ctx.s = (tape, e, lat, gap, fl, m, B, S, T, key_mask, pa, ph, a1, q, kv, c, lse, c2, z, mean, rstd, (s1, o1), (s2, o2), cbits)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (tape, e, lat, gap, fl, m, B, S, T, key_mask, pa, ph, a1, q, kv, c, lse, c2, z, mean, rstd, (s1, o1), (s2, o2)) = ctx.s
+        (tape, e, lat, gap, fl, m, B, S, T, key_mask, pa, ph, a1, q, kv, c, lse, c2, z, mean, rstd, (s1, o1), (s2, o2), cbits) = ctx.s
         A = m.arena
         G = A.grad
         H = e.shape[1]
@@ -557,7 +557,7 @@ class FusionFn(torch.autograd.Function):
         f, df = kv.view(-1), dkv.view(-1)
         qs, ks = (S * H, H, hd), (T * 2 * H, 2 * H, hd)
         ops.attn_bwd(q, f[2 * H:], f[3 * H:], c, dc2.view(B, S, H), lse, dq, df[2 * H:], df[3 * H:], B, heads, S, T - 1, hd, qs, ks, ks,
-                     qs, ks, ks, 1.0 / math.sqrt(hd), None, pa, s1, o1)
+                     qs, ks, ks, 1.0 / math.sqrt(hd), None, pa, s1, o1, drop_bits=cbits)
         _wgrad(A, dkv, lat, [ca.key.weight, ca.value.weight], shape=(2 * H, H), gb=A.fused_grad([ca.key.bias, ca.value.bias], (2 * H,)))
         dlat = ops.linear_dgrad(dkv, A.fused_w([ca.key.weight, ca.value.weight], (2 * H, H)))
         _wgrad(A, dq, a1, ca.query.weight, gb=G(ca.query.bias))

@@ -222,14 +222,20 @@ def _st(t3):
     return _I64x3(*t3)
 
 
-def attn_fwd(q, k, v, B, H, Tq, Tk, hd, qs, ks, vs, scale, key_mask=None, drop_p=0.0, seed=0, offset=0):
-    """q/k/v: tensors whose storage is addressed with element strides (batch, token, head); returns (o [B,Tq,H*hd], lse)."""
+def attn_fwd(q, k, v, B, H, Tq, Tk, hd, qs, ks, vs, scale, key_mask=None, drop_p=0.0, seed=0, offset=0, want_mask=False):
+    """q/k/v: tensors whose storage is addressed with element strides (batch, token, head); returns (o [B,Tq,H*hd], lse) and, with
+    `want_mask`, the dropout keep-mask as bits (uint8 tensor, or None where the bit form does not apply) for `attn_bwd`."""
     _chk(q, k, v)
     o = torch.empty((B, Tq, H * hd), device=q.device, dtype=q.dtype)
     lse = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    bits = None
+    if want_mask and drop_p > 0.0:
+        nb = int(_lib.load().ecamp_attn_mask_bytes(B, H, Tq, Tk, hd, code(q.dtype)))
+        if nb > 0:
+            bits = torch.empty((nb,), device=q.device, dtype=torch.uint8)
     call("ecamp_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_mask), B, H, Tq, Tk, hd, _st(qs), _st(ks), _st(vs),
-         _st((Tq * H * hd, H * hd, hd)), float(scale), float(drop_p), seed, offset, code(q.dtype), stream())
-    return o, lse
+         _st((Tq * H * hd, H * hd, hd)), float(scale), float(drop_p), seed, offset, code(q.dtype), ptr(bits), stream())
+    return (o, lse, bits) if want_mask else (o, lse)
 
 
 def attn_probs(q, k, B, H, Tq, Tk, hd, qs, ks, scale, key_mask=None):
@@ -241,13 +247,13 @@ def attn_probs(q, k, B, H, Tq, Tk, hd, qs, ks, scale, key_mask=None):
 
 
 def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, H, Tq, Tk, hd, qs, ks, vs, dqs, dks, dvs, scale, key_mask=None, drop_p=0.0,
-             seed=0, offset=0):
+             seed=0, offset=0, drop_bits=None):
     delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
     os_ = (Tq * H * hd, H * hd, hd)
     assert do.is_contiguous() and o.is_contiguous()
     call("ecamp_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(key_mask),
          B, H, Tq, Tk, hd, _st(qs), _st(ks), _st(vs), _st(os_), _st(os_), _st(dqs), _st(dks), _st(dvs), float(scale), float(drop_p),
-         seed, offset, code(q.dtype), stream())
+         seed, offset, code(q.dtype), ptr(drop_bits), stream())
 
 
 # --------------------------------------------------------------------------------------------- misc

@@ -112,17 +112,22 @@ int ecamp_layernorm_bwd(const void* dy, const void* z, const float* mean, const 
 
 /* ---- attention (timm Attention.forward: softmax(q k^T * hd^-1/2) v; HF BertSelfAttention 4.42.4 incl. the
  * cross-attention mode of context_fusion.py:45-53).  strides = {batch, token, head} in elements, head_dim contiguous.
- * key_mask: int32 [B,Tk], nonzero = attend (the additive finfo.min mask of bert_modeling.py:92), or NULL. */
+ * key_mask: int32 [B,Tk], nonzero = attend (the additive finfo.min mask of bert_modeling.py:92), or NULL.
+ * drop_mask (optional, ecamp_attn_mask_bytes(...) bytes): the dropout keep-mask of the probabilities as bits, written by the forward
+ * call and read by the backward call that is given the same buffer -- the Philox stream is then evaluated once per score instead of
+ * three times (forward, dQ pass, dK/dV pass).  NULL (or a size of 0: shapes the bit form does not serve): the backward pass
+ * regenerates the mask from (seed, offset); both forms give bit-identical results. */
+int64_t ecamp_attn_mask_bytes(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t dtype);
 int ecamp_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* key_mask, int32_t B,
                    int32_t H, int32_t Tq, int32_t Tk, int32_t hd, const int64_t* q_strides, const int64_t* k_strides,
                    const int64_t* v_strides, const int64_t* o_strides, float scale, float drop_p, uint64_t seed, uint64_t offset,
-                   int32_t dtype, ecampStream_t stream);
+                   int32_t dtype, void* drop_mask, ecampStream_t stream);
 int ecamp_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    float* delta_ws, void* dq, void* dk, void* dv, const int32_t* key_mask, int32_t B, int32_t H, int32_t Tq,
                    int32_t Tk, int32_t hd, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                    const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
                    const int64_t* dv_strides, float scale, float drop_p, uint64_t seed, uint64_t offset, int32_t dtype,
-                   ecampStream_t stream);
+                   const void* drop_mask, ecampStream_t stream);
 /* Attention probabilities softmax(scale * q k^T + mask), f32 [B,H,Tq,Tk] (Tk <= 1024): the tensor the reference's Visualization
  * model returns from the fusion layer's cross-attention (Visualization/module/context_fusion.py:45-57,
  * Visualization/module/model_ecamp.py:308-319).  Evaluation only. */

@@ -53,7 +53,7 @@ def test_argument_errors_are_reported_without_a_device(lib):
     rc = lib.ecamp_gemm(one, one, one, 8, 30, 30, 1, 30, 1, 30, 30, None, None, 0, None, 0, None, 0, 0, 1.0, None, 1, 0, 0, 1, None, None, None)
     assert rc < 0 and b"multiple of 4" in lib.ecamp_last_error()
     st = (ctypes.c_int64 * 3)(64, 64, 64)
-    rc = lib.ecamp_attn_fwd(one, one, one, one, one, None, 1, 1, 8, 300, 48, st, st, st, st, 1.0, 0.0, 0, 0, 0, None)
+    rc = lib.ecamp_attn_fwd(one, one, one, one, one, None, 1, 1, 8, 300, 48, st, st, st, st, 1.0, 0.0, 0, 0, 0, None, None)
     assert rc < 0 and b"head_dim 48" in lib.ecamp_last_error()  # (Tk > 256 in f32 is served by the long-key kernels since round 2)
 
 

@@ -294,6 +294,43 @@ def test_attention_head_kernels_match_streaming_kernels(dev, B, H, Tq, Tk, hd, m
         assert (out0.float().cpu() - res[0][0]).abs().max().item() > 1e-3
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,hd,masked,p", [(2, 6, 128, 128, 128, True, 0.1), (2, 6, 128, 49, 128, False, 0.1), (1, 4, 250, 256, 64, True, 0.1),
+                                                   (2, 3, 33, 17, 32, True, 0.3), (2, 12, 50, 50, 64, False, 0.2)])
+def test_attention_saved_dropout_bits_equal_regenerated_mask(dev, B, H, Tq, Tk, hd, masked, p):
+    """The forward pass can leave the dropout keep-mask as bits (ecamp_attn_mask_bytes / drop_mask) so that the backward pass does not
+    evaluate Philox again: the gradients must be BIT-IDENTICAL to the backward pass that regenerates the mask from (seed, offset), for
+    key masks, an odd key count (per-element Philox path), partial last tile pairs and the longest head-resident sequence."""
+    o = ops()
+    D = H * hd
+    dt = torch.bfloat16
+    q = rnd(gen(B, Tq, D, seed=21), dt).to(dev, dt)
+    k = rnd(gen(B, Tk, D, seed=22), dt).to(dev, dt)
+    v = rnd(gen(B, Tk, D, seed=23), dt).to(dev, dt)
+    do = rnd(gen(B, Tq, D, seed=24), dt).to(dev, dt)
+    km = None
+    if masked:
+        lens = torch.randint(max(1, Tk // 3), Tk + 1, (B,), generator=torch.Generator().manual_seed(6))
+        km = (torch.arange(Tk)[None, :] < lens[:, None]).int().to(dev)
+    qs, ks = (Tq * D, D, hd), (Tk * D, D, hd)
+    out, lse, bits = o.attn_fwd(q, k, v, B, H, Tq, Tk, hd, qs, ks, ks, hd ** -0.5, km, p, 91, 3, want_mask=True)
+    out2, lse2 = o.attn_fwd(q, k, v, B, H, Tq, Tk, hd, qs, ks, ks, hd ** -0.5, km, p, 91, 3)
+    assert bits is not None and bits.dtype == torch.uint8 and bits.numel() == B * H * Tq * 32
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    grads = []
+    for b_ in (bits, None):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        o.attn_bwd(q, k, v, out, do, lse, dq, dk, dv, B, H, Tq, Tk, hd, qs, ks, ks, qs, ks, ks, hd ** -0.5, km, p, 91, 3, drop_bits=b_)
+        grads.append((dq.clone(), dk.clone(), dv.clone()))
+    for name, a, b in zip(("dq", "dk", "dv"), grads[0], grads[1]):
+        assert torch.isfinite(a.float()).all(), name
+        assert torch.equal(a, b), "%s: saved bits differ from the regenerated mask (max diff %.3e)" % (name, (a.float() - b.float()).abs().max().item())
+    # the share of kept probabilities recorded in the bits is 1 - p
+    nkp = ((Tk + 15) // 16 + 1) // 2
+    kept = sum(bin(int(x)).count("1") for x in bits.view(B * H * Tq, 4, 8)[:, :, :nkp].flatten().cpu().tolist()[:20000])
+    total = min(B * H * Tq * 4 * nkp, 20000) * 8
+    assert abs(kept / total - (1 - p)) < 0.02
+
+
 # ------------------------------------------------------------------------------------------------ image side
 def test_bicubic(dev):
     o = ops()

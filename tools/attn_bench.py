@@ -23,11 +23,14 @@ for name, B, H, T, hd, km, p in SHAPES:
     f = qkv.view(-1)
     st = (T * 3 * D, 3 * D, hd)
     mask = (torch.arange(T, device=dev)[None] < torch.randint(T // 4, T + 1, (B, 1), device=dev)).int().contiguous() if km else None
-    out, lse = o.attn_fwd(f, f[D:], f[2 * D:], B, H, T, T, hd, st, st, st, hd ** -0.5, mask, p, 1, 2)
+    out, lse, bits = o.attn_fwd(f, f[D:], f[2 * D:], B, H, T, T, hd, st, st, st, hd ** -0.5, mask, p, 1, 2, want_mask=True)
     do = torch.randn_like(out)
     dqkv = torch.empty_like(qkv); df = dqkv.view(-1)
-    t1 = timeit(lambda: o.attn_fwd(f, f[D:], f[2 * D:], B, H, T, T, hd, st, st, st, hd ** -0.5, mask, p, 1, 2))
-    t2 = timeit(lambda: o.attn_bwd(f, f[D:], f[2 * D:], out, do, lse, df, df[D:], df[2 * D:], B, H, T, T, hd, st, st, st, st, st, st, hd ** -0.5, mask, p, 1, 2))
+    t1 = timeit(lambda: o.attn_fwd(f, f[D:], f[2 * D:], B, H, T, T, hd, st, st, st, hd ** -0.5, mask, p, 1, 2, want_mask=True))
+    t2 = timeit(lambda: o.attn_bwd(f, f[D:], f[2 * D:], out, do, lse, df, df[D:], df[2 * D:], B, H, T, T, hd, st, st, st, st, st, st, hd ** -0.5, mask, p, 1, 2, drop_bits=bits))
+    if bits is not None:   # the same backward pass regenerating the mask from the Philox counters (three evaluations per score in all)
+        t3 = timeit(lambda: o.attn_bwd(f, f[D:], f[2 * D:], out, do, lse, df, df[D:], df[2 * D:], B, H, T, T, hd, st, st, st, st, st, st, hd ** -0.5, mask, p, 1, 2))
+        name = name + " (bwd with Philox regenerated: %.1f us)" % t3
     fl = 4.0 * B * H * T * T * hd
     e = B * T * D * 2
     print("%s | fwd %6.1fus %5.0f TF %5.0f GB/s(4 tensors) | bwd %6.1fus %5.0f TF %5.0f GB/s(8 tensors)" %
