@@ -1280,12 +1280,39 @@ static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, c
     for (int p = 0; p < n; ++p)
         for (int mb = 0; mb < ceil_div(n_out[p], 256); ++mb)
             for (int nb = 0; nb < ceil_div(k_in[p], 256); ++nb) tiles.push_back({p, mb * 256, nb * 256, 0, 0});
+    std::vector<Q8ItemRec>& items = pl.items;
+    std::vector<int>& first = pl.first;
+    // ECAMP_WGRAD_PLAN=0: the round-2 dealing (K tiles of all tiles dealt out evenly in tile order; ranges run across tile boundaries)
+    static const int plan_mode = getenv("ECAMP_WGRAD_PLAN") ? atoi(getenv("ECAMP_WGRAD_PLAN")) : 1;
+    const long T = (long)tiles.size();
+    long S = (ncu + T / 2) / T;                       // K segments per tile: one (tile, segment) piece per workgroup
+    while (S > 1 && (T * S > p8_num_cu() || KT / S < 4)) --S;
+    if (plan_mode == 1 && S >= 1 && T * S >= ncu / 2 && T * S <= p8_num_cu()) {
+        // Segment-major plan: every output tile is cut into the same S contiguous K segments and each workgroup owns ONE piece.  The
+        // pieces are ordered (segment, tile) and workgroup w -- which the hardware places on XCD w % 8 -- takes piece
+        // (w % 8) * P/8 + w / 8: the ~P/8 workgroups of an XCD start together on neighbouring tiles of the SAME K segment, walk the
+        // contraction in step and share the dY / X strips of each K tile in that XCD's L2 (a dY strip is common to all tiles of an
+        // M-block row, an X strip to a column): with the dealing above every workgroup streamed its own two strips, 4x the operands.
+        const long P = T * S;
+        for (long t = 0; t < T; ++t) { tiles[t].first = (int)(t * S); tiles[t].count = (int)S; }
+        std::vector<long> order(P);                   // order[j] = piece (segment-major) of the j-th position in XCD-contiguous order
+        for (long j = 0; j < P; ++j) order[j] = j;
+        const long q8 = P / 8, r8 = P % 8;
+        for (long w = 0; w < P; ++w) {
+            const long xcd = w % 8, slot = w / 8;
+            const long j = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;   // bijective for any P (xcd_remap)
+            const long seg = order[j] / T, t = order[j] % T;
+            const long k0 = KT * seg / S, k1 = KT * (seg + 1) / S;
+            const long kend = k1 * 64 < rows ? k1 * 64 : rows;
+            WgTile& Tt = tiles[t];
+            first.push_back((int)items.size());
+            items.push_back({Tt.prob, Tt.m0, Tt.n0, (int)(k0 * 64), (int)kend, (int)(t * S + seg), (Tt.n0 == 0 && has_bias[Tt.prob]) ? 1 : 0, 0});
+        }
+    } else {
     const long units = (long)tiles.size() * KT;
     long q = (units + ncu - 1) / ncu;
     q += q & 1;                                   // even quota, even KT (rows % 128 == 0): every piece has >= 2 K tiles
     if (q < 2) q = 2;
-    std::vector<Q8ItemRec>& items = pl.items;
-    std::vector<int>& first = pl.first;
     long u = 0;
     while (u < units) {
         first.push_back((int)items.size());
@@ -1299,6 +1326,7 @@ static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, c
             items.push_back({T.prob, T.m0, T.n0, (int)(k0 * 64), (int)kend, (int)items.size(), (T.n0 == 0 && has_bias[T.prob]) ? 1 : 0, 0});
             u += len; take -= len;
         }
+    }
     }
     first.push_back((int)items.size());
     pl.nitems = (int)items.size(); pl.nwg = (int)first.size() - 1; pl.ntiles = (int)tiles.size();
