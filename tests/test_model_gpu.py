@@ -620,7 +620,7 @@ def test_production_kernel_selection_matches_oracle_bf16(dev, B):
     want = np.array([t.item() for t in ref])
     print("B=%d: Q8 launches %d, grouped weight-gradient launches %d; oracle fwd+bwd %.1f s" % (B, nq, nw, time.time() - t0))
     print("  losses hip", got, "oracle", want, "rel", np.abs(got - want) / want)
-    assert nq > 150 and nw >= 30, (nq, nw)     # the persistent kernel and the grouped launches are what ran
+    assert nq > 150 and nw >= 20, (nq, nw)     # the persistent kernel and the grouped launches (one per transformer block) are what ran
     assert (np.abs(got - want) / want).max() < 3e-2
     names = [n for n in names if P[n].grad is not None]     # the two pooler tensors have no gradient in the reference
     ref_n = np.array([P[n].grad.double().norm().item() for n in names])
