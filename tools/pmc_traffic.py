@@ -2,7 +2,7 @@
 """HBM-side traffic of the GEMM family per launch, from two SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the bench step.
 
     gpurun -- 'bash tools/pmc_traffic.sh'          # runs the passes on the GPU box (nothing else traced), then this script
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r02_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r03_pmc_traffic.json
 
 Correction per MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> doubled; WRITE_SIZE as
 reported; both counters are in KB."""
