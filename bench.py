@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU (configs[1] = 256)")
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--image-u8", action="store_true", help="compact image schema: uint8 [B,448,448] grayscale crops (51 MB per 256 pairs over PCIe instead "
+                    "of 616 MB of f32 [B,3,448,448]); the default stays the reference's f32 schema")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--only-value", action="store_true", help="time the K steps of `value` and nothing else (kernel traces of the production step)")
@@ -219,7 +221,7 @@ def main():
     opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
     scaler = NativeScalerWithGradNormCount()
     from ecamp_amd.data import DevicePrefetcher
-    host_batch = {k: v.pin_memory() for k, v in synthetic_batch(args.batch, args.seq, 448, seed=rank, device="cpu").items()}   # what a
+    host_batch = {k: v.pin_memory() for k, v in synthetic_batch(args.batch, args.seq, 448, seed=rank, device="cpu", image_u8=args.image_u8).items()}   # what a
     # pin_memory DataLoader yields (main_pretrain.py:232-240); it crosses PCIe inside the timed region, one step ahead of its use
     batch = {k: v.to(dev) for k, v in host_batch.items()}   # resident copy for the side measurements
     net.train()
@@ -336,7 +338,8 @@ def main():
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[1]: ViT-B/16 MAE enc/dec + SR head + reference BERT (6L/6H/1536, vocab 30000) "
                                       "+ context fusion; full train step (fwd+bwd+grad-norm+AdamW, dropout on)",
-                          "pairs_per_gpu": args.batch, "global_batch": args.batch * world, "image": "448^2 -> 224^2 encoder input",
+                          "pairs_per_gpu": args.batch, "global_batch": args.batch * world,
+                          "image": "448^2 -> 224^2 encoder input" + (", uint8 grayscale crops normalised on the device" if args.image_u8 else ""),
                           "seq_len": args.seq, "mask_ratio": 0.75, "accum_iter": 1, "parallelism": "dp%d" % world,
                           "last_losses_mim_res_mlm": [round(x, 5) for x in losses]},
                "input": "pinned host memory -> HBM inside the timed region: every timed step issues the copy of the next batch on a copy "

@@ -81,6 +81,122 @@ __global__ __launch_bounds__(256) void bicubic_half_kernel(const float* __restri
         *reinterpret_cast<float4*>(dst + (pl * Hd + y) * (long)Wd + 4 * tx) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
+// ---- uint8 single-channel images (the dataset's item is a grayscale crop replicated to three channels and normalised
+// with ONE mean / std, pretrain_datasets.py:47-52): the f32 [B,3,H,W] schema carries 12 bytes per pixel over PCIe and through every
+// read, the crop itself 1.  The kernels normalise through the caller's 256-entry table lut[u] = ((float)u / 255 - mean) / std -- ToTensor +
+// Normalize evaluated once per byte value in their f32 arithmetic -- so they see bit for bit the values the f32 schema would hold.
+// the SR loss target: f32 [B,3,2R,2R], or u8 [B,2R,2R] normalised on the fly (every channel reads the same byte)
+struct BigSrc {
+    const float* f;
+    const unsigned char* u8;
+    const float* lut;
+    __device__ __forceinline__ bool any() const { return f != nullptr || u8 != nullptr; }
+    __device__ __forceinline__ float at(long b, int o, int Y, int X, int R2) const {
+        return u8 ? lut[u8[(b * R2 + Y) * (long)R2 + X]] : f[((b * 3 + o) * (long)R2 + Y) * R2 + X];
+    }
+    __device__ __forceinline__ float2 at2(long b, int o, int Y, int X, int R2) const {   // pixels X, X + 1 (X even)
+        if (u8) {
+            const unsigned short w = *reinterpret_cast<const unsigned short*>(u8 + (b * R2 + Y) * (long)R2 + X);
+            return make_float2(lut[w & 255u], lut[w >> 8]);
+        }
+        return *reinterpret_cast<const float2*>(f + ((b * 3 + o) * (long)R2 + Y) * R2 + X);
+    }
+};
+// exact 2x down-resize of a u8 image into the three identical f32 planes of the model's `imgs`: the arithmetic of bicubic_half_kernel
+// on the normalised pixels (identical bits), one twelfth of its source bytes
+__global__ __launch_bounds__(256) void bicubic_half_u8_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long B, int Hd, int Wd,
+                                                              const float* __restrict__ lut_g) {
+    const int Ws = 2 * Wd, Hs = 2 * Hd, W4 = Wd >> 2;
+    const long n = B * Hd * W4;
+    __shared__ float lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    float w[4];
+    cubic_coeffs(0.5f, w);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int tx = (int)(i % W4), y = (int)((i / W4) % Hd);
+        const long b = i / ((long)W4 * Hd);
+        const unsigned char* p = src + b * (long)Hs * Ws;
+        const int c0 = 8 * tx;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(2 * y - 1 + a, 0), Hs - 1);
+            const unsigned char* r = p + (long)yy * Ws;
+            const uint2 m = *reinterpret_cast<const uint2*>(r + c0);            // columns c0 .. c0+7 (8-byte aligned: Ws % 8 == 0)
+            const unsigned left = c0 > 0 ? r[c0 - 1] : r[0];
+            const unsigned r0 = c0 + 8 < Ws ? r[c0 + 8] : r[Ws - 1], r1 = c0 + 8 < Ws ? r[c0 + 9] : r[Ws - 1];
+            const unsigned u[11] = {left, m.x & 255u, (m.x >> 8) & 255u, (m.x >> 16) & 255u, m.x >> 24, m.y & 255u, (m.y >> 8) & 255u, (m.y >> 16) & 255u,
+                                    m.y >> 24, r0, r1};
+            float v[11];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) v[k] = lut[u[k]];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float row = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) row += w[bb] * v[2 * o + bb];
+                acc[o] += w[a] * row;
+            }
+        }
+        const float4 out = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(dst + ((b * 3 + c) * Hd + y) * (long)Wd + 4 * tx) = out;
+    }
+}
+// any other ratio (or no resize at all: Hs == Hd copies the normalised image into the three planes)
+__global__ void bicubic_u8_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long B, int Hs, int Ws, int Hd, int Wd, float sy, float sx,
+                                  const float* __restrict__ lut) {
+    const long n = B * Hd * Wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wd), y = (int)((i / Wd) % Hd);
+        const long b = i / ((long)Wd * Hd);
+        const unsigned char* p = src + b * (long)Hs * Ws;
+        float acc;
+        if (Hs == Hd && Ws == Wd) {
+            acc = lut[p[(long)y * Ws + x]];
+        } else {
+            const float ry = sy * (y + 0.5f) - 0.5f, rx = sx * (x + 0.5f) - 0.5f;
+            const float fy = floorf(ry), fx = floorf(rx);
+            float wy[4], wx[4];
+            cubic_coeffs(ry - fy, wy);
+            cubic_coeffs(rx - fx, wx);
+            const int iy = (int)fy, ix = (int)fx;
+            acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int yy = min(max(iy - 1 + a, 0), Hs - 1);
+                float row = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int xx = min(max(ix - 1 + bb, 0), Ws - 1);
+                    row += wx[bb] * lut[p[(long)yy * Ws + xx]];
+                }
+                acc += wy[a] * row;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[((b * 3 + c) * Hd + y) * (long)Wd + x] = acc;
+    }
+}
+extern "C" int ecamp_bicubic_resize_u8(const unsigned char* src, float* dst, int64_t B, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd,
+                                       const float* lut, hipStream_t stream) {
+    ECAMP_CHECK_ARG(src && dst && lut && B > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "bicubic_u8: bad args");
+    if (Hs == 2 * Hd && Ws == 2 * Wd && (Wd & 3) == 0 && ((uintptr_t)src & 7) == 0 && ((uintptr_t)dst & 15) == 0) {
+        long n4 = B * Hd * (Wd >> 2);
+        int nb4 = (int)((n4 + 255) / 256);
+        if (nb4 > 16384) nb4 = 16384;
+        hipLaunchKernelGGL(bicubic_half_u8_kernel, dim3(nb4), dim3(256), 0, stream, src, dst, (long)B, Hd, Wd, lut);
+        ECAMP_LAUNCH_CHECK();
+        return 0;
+    }
+    long n = B * Hd * Wd;
+    int nb = (int)((n + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(bicubic_u8_kernel, dim3(nb), dim3(256), 0, stream, src, dst, (long)B, Hs, Ws, Hd, Wd, (float)Hs / (float)Hd, (float)Ws / (float)Wd, lut);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int ecamp_bicubic_resize(const float* src, float* dst, int64_t planes, int32_t Hs, int32_t Ws, int32_t Hd,
                                     int32_t Wd, hipStream_t stream) {
     ECAMP_CHECK_ARG(src && dst && planes > 0, "bicubic: bad args");
@@ -493,7 +609,7 @@ __device__ __forceinline__ void sr_conv_stage(float* dst, const float* src, cons
 // `sr_out` (optional, f32 [B,3,2R,2R]): the head's output image -- the reference's `self.super_res(pred_img)` (model_ecamp.py:28-46,
 // 285) -- for every tile, not only the loss window (parity checks / visualisation; the training step passes null and touches only
 // the window).  With `big` null only the image is produced.
-__global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+__global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restrict__ pred_img, BigSrc big,
                                                            const long* __restrict__ column, const long* __restrict__ row, SrP P,
                                                            float* __restrict__ loss_sum, long B, int R, int win, float* __restrict__ sr_out) {
     __shared__ SrW W;
@@ -507,7 +623,7 @@ __global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restri
         const long b = t / (G * G);
         const int ty = (int)((t / G) % G), tx = (int)(t % G);
         bool in_win = false;
-        if (big) {
+        if (big.any()) {
             const int c0 = (int)column[b], r0 = (int)row[b];
             in_win = !(ty < c0 || ty >= c0 + win || tx < r0 || tx >= r0 + win);
         }
@@ -537,7 +653,7 @@ __global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restri
                 const long at = ((b * 3 + o) * (long)R2 + Y0 + y) * R2 + X0 + x;
                 if (sr_out) sr_out[at] = s;
                 if (in_win) {
-                    float d = s - big[at];
+                    float d = s - big.at(b, o, Y0 + y, X0 + x, R2);
                     part += d * d;
                 }
             }
@@ -599,7 +715,7 @@ __device__ __forceinline__ int sr_tap_off(int tap, int E) {  // tap = (i*3 + ky)
     return (i * E + ky) * E + kx;
 }
 
-__global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+__global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __restrict__ pred_img, BigSrc big,
                                                            const long* __restrict__ column, const long* __restrict__ row, SrP P,
                                                            float* __restrict__ dsr, float* __restrict__ gw, long B, int R, int win) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -662,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __res
             }
             inw[j] = in;
 #pragma unroll
-            for (int o = 0; o < 3; ++o) bigv[j][o] = in ? big[((b * 3 + o) * (long)R2 + Y) * R2 + X] : 0.f;
+            for (int o = 0; o < 3; ++o) bigv[j][o] = in ? big.at(b, o, Y, X, R2) : 0.f;
         }
         __syncthreads();
         // (2) u on halo 5 from the patch
@@ -889,7 +1005,7 @@ __device__ __forceinline__ void sr_pair_conv(const unsigned char* p, const bf16x
 }
 // forward in the same pixel-pair form: u on rows / cols -2..33 from 2 x 2 blocks, c1 on rows -1..32 with column pairs from -1,
 // s on the tile with column pairs from 0.  The skip connection and the loss stay f32.
-__global__ __launch_bounds__(256) void sr_pair_fwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+__global__ __launch_bounds__(256) void sr_pair_fwd_kernel(const float* __restrict__ pred_img, BigSrc big,
                                                           const long* __restrict__ column, const long* __restrict__ row, SrP P,
                                                           float* __restrict__ loss_sum, long B, int R, int win) {
     __shared__ __attribute__((aligned(16))) unsigned char U16[36 * 36 * 8];   // u, rows / cols -2..33
@@ -975,7 +1091,7 @@ __global__ __launch_bounds__(256) void sr_pair_fwd_kernel(const float* __restric
             const int p = (wave + 4 * j) * 64 + lane, y = p >> 4, xq = p & 15;
             float2 bg[3];
 #pragma unroll
-            for (int o = 0; o < 3; ++o) bg[o] = *reinterpret_cast<const float2*>(big + ((b * 3 + o) * (long)R2 + Y0 + y) * R2 + X0 + 2 * xq);
+            for (int o = 0; o < 3; ++o) bg[o] = big.at2(b, o, Y0 + y, X0 + 2 * xq, R2);
             f32x4_t oA, oB;
             sr_pair_conv<34, false>(C16 + (y * 34 + 2 * xq) * 8, a2, bias2, oA, oB);
 #pragma unroll
@@ -991,7 +1107,7 @@ __global__ __launch_bounds__(256) void sr_pair_fwd_kernel(const float* __restric
 }
 
 #define SRP_LDS_BYTES (44 * 44 * 8 + 40 * 42 * 8 + 38 * 40 * 8 + 36 * 38 * 8 + 3 * 34 * 36 * 4 + 4 * 9 * 4 * 8)
-__global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __restrict__ pred_img, const float* __restrict__ big,
+__global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __restrict__ pred_img, BigSrc big,
                                                              const long* __restrict__ column, const long* __restrict__ row, SrP P,
                                                              float* __restrict__ dsr, float* __restrict__ gw, long B, int R, int win) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];   // the only LDS object (16-B aligned carve)
@@ -1077,7 +1193,7 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
             inw[j] = in;
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
-                const float2 v = in ? *reinterpret_cast<const float2*>(big + ((b * 3 + o) * (long)R2 + Y) * R2 + X) : make_float2(0.f, 0.f);
+                const float2 v = in ? big.at2(b, o, Y, X, R2) : make_float2(0.f, 0.f);
                 bigv[j][o][0] = v.x;
                 bigv[j][o][1] = v.y;
             }
@@ -1307,20 +1423,29 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
     if (threadIdx.x < 168) atomicAdd(gw + threadIdx.x, RED[threadIdx.x] + RED[168 + threadIdx.x] + RED[336 + threadIdx.x] + RED[504 + threadIdx.x]);
 }
 
-extern "C" int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
-                            const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B, int32_t R,
-                            int32_t super_patch, int32_t window, int32_t mode, hipStream_t stream) {
+static BigSrc big_src(const void* big, const float* lut) {   // lut != null: `big` is the uint8 crop
+    BigSrc s;
+    s.f = lut ? nullptr : reinterpret_cast<const float*>(big);
+    s.u8 = lut ? reinterpret_cast<const unsigned char*>(big) : nullptr;
+    s.lut = lut;
+    return s;
+}
+extern "C" int ecamp_sr_fwd(const float* pred_img, const void* big, const float* big_lut, const int64_t* column,
+                            const int64_t* row, const float* w1, const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B,
+                            int32_t R, int32_t super_patch, int32_t window, int32_t mode, hipStream_t stream) {
     ECAMP_CHECK_ARG(pred_img && big && column && row && w1 && b1 && w2 && b2 && loss_sum, "sr_fwd: null pointer");
+    ECAMP_CHECK_ARG(!big_lut || ((uintptr_t)big & 1) == 0, "sr_fwd: the uint8 target must be 2-byte aligned");
+    const BigSrc bs = big_src(big, big_lut);
     ECAMP_CHECK_ARG(super_patch == SRT && (2 * R) % SRT == 0, "sr_fwd: the fused SR head is built for 32-px super-patches (patch 16)");
     ECAMP_CHECK_ARG(mode == 0 || mode == 1, "sr_fwd: mode must be 0 (f32 VALU) or 1 (bf16 matrix cores)");
     SrP W = {w1, b1, w2, b2};
     long tiles = B * (2 * R / SRT) * (2 * R / SRT);
     int nb = (int)(tiles < 2048 ? tiles : 2048);
     if (mode == 1)
-        hipLaunchKernelGGL(sr_pair_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
+        hipLaunchKernelGGL(sr_pair_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, bs, (const long*)column, (const long*)row, W, loss_sum,
                            (long)B, R, window);
     else
-        hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big, (const long*)column, (const long*)row, W, loss_sum,
+        hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, bs, (const long*)column, (const long*)row, W, loss_sum,
                            (long)B, R, window, (float*)nullptr);
     ECAMP_LAUNCH_CHECK();
     return 0;
@@ -1336,7 +1461,7 @@ extern "C" int ecamp_sr_image(const float* pred_img, const float* w1, const floa
     SrP W = {w1, b1, w2, b2};
     long tiles = B * (2 * R / SRT) * (2 * R / SRT);
     int nb = (int)(tiles < 2048 ? tiles : 2048);
-    hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, (const float*)nullptr, (const long*)nullptr, (const long*)nullptr, W,
+    hipLaunchKernelGGL(sr_fused_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred_img, big_src(nullptr, nullptr), (const long*)nullptr, (const long*)nullptr, W,
                        (float*)nullptr, (long)B, R, 0, sr);
     ECAMP_LAUNCH_CHECK();
     return 0;
@@ -1347,10 +1472,12 @@ extern "C" int64_t ecamp_sr_bwd_workspace_bytes(void) { return 168 * 4; }
 
 // dsr: f32 [B,3,R,R] = d(0.5*res_sum)/d pred_img;  gw_ws[168] += {dW1[81], db1[3], dW2[81], db2[3]} (unscaled; the caller
 // folds g_res*2/N in when adding into the .grad views).
-extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
-                            const float* b1, const float* w2, const float* b2, float* dsr, float* gw_ws, int64_t B, int32_t R,
-                            int32_t super_patch, int32_t window, int32_t mode, hipStream_t stream) {
+extern "C" int ecamp_sr_bwd(const float* pred_img, const void* big, const float* big_lut, const int64_t* column,
+                            const int64_t* row, const float* w1, const float* b1, const float* w2, const float* b2, float* dsr, float* gw_ws,
+                            int64_t B, int32_t R, int32_t super_patch, int32_t window, int32_t mode, hipStream_t stream) {
     ECAMP_CHECK_ARG(pred_img && big && column && row && w1 && b1 && w2 && b2 && dsr && gw_ws, "sr_bwd: null pointer");
+    ECAMP_CHECK_ARG(!big_lut || ((uintptr_t)big & 1) == 0, "sr_bwd: the uint8 target must be 2-byte aligned");
+    const BigSrc bs = big_src(big, big_lut);
     ECAMP_CHECK_ARG(super_patch == SRT && (2 * R) % SRT == 0, "sr_bwd: the fused SR head is built for 32-px super-patches (patch 16)");
     ECAMP_CHECK_ARG(mode == 0 || mode == 1, "sr_bwd: mode must be 0 (f32 VALU) or 1 (bf16 matrix cores)");
     SrP W = {w1, b1, w2, b2};
@@ -1371,12 +1498,12 @@ extern "C" int ecamp_sr_bwd(const float* pred_img, const float* big, const int64
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sr_pair_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SRP_LDS_BYTES);
         }
         const int nb2 = (int)(tiles < nbp ? tiles : nbp);
-        hipLaunchKernelGGL(sr_pair_bwd_kernel, dim3(nb2), dim3(256), SRP_LDS_BYTES, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr,
+        hipLaunchKernelGGL(sr_pair_bwd_kernel, dim3(nb2), dim3(256), SRP_LDS_BYTES, stream, pred_img, bs, (const long*)column, (const long*)row, W, dsr,
                            gw_ws, (long)B, R, window);
         ECAMP_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(sr_fused_bwd_kernel, dim3(nb), dim3(256), shm, stream, pred_img, big, (const long*)column, (const long*)row, W, dsr, gw_ws,
+    hipLaunchKernelGGL(sr_fused_bwd_kernel, dim3(nb), dim3(256), shm, stream, pred_img, bs, (const long*)column, (const long*)row, W, dsr, gw_ws,
                        (long)B, R, window);
     ECAMP_LAUNCH_CHECK();
     return 0;

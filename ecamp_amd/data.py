@@ -7,9 +7,21 @@ from torch.utils.data import Dataset
 PAD, UNK, CLS, MASK, SEP = 0, 1, 2, 3, 4
 
 
-def synthetic_batch(B, S=256, img=448, vocab=30000, seed=0, device="cpu"):
+IMG_MEAN, IMG_STD = 0.4721, 0.3037   # pretrain_datasets.py:52
+
+
+def normalise_u8(image_u8):
+    """uint8 [B, H, W] grayscale crops -> the f32 [B, 3, H, W] tensor the reference's transform produces (Grayscale(3) + ToTensor +
+    Normalize, pretrain_datasets.py:50-52), in the same f32 arithmetic as the kernels that read the compact form."""
+    x = image_u8.to(torch.float32).div(255.0).sub(IMG_MEAN).div(IMG_STD)
+    return x.unsqueeze(1).expand(-1, 3, -1, -1).contiguous()
+
+
+def synthetic_batch(B, S=256, img=448, vocab=30000, seed=0, device="cpu", image_u8=False):
+    """image_u8: the compact image schema -- uint8 [B, img, img] grayscale crops (what the dataset's item is before ToTensor /
+    Normalize) instead of the normalised f32 [B, 3, img, img]; `normalise_u8` maps one onto the other."""
     g = torch.Generator().manual_seed(1234 + seed)
-    image = torch.randn(B, 3, img, img, generator=g)
+    image = torch.randint(0, 256, (B, img, img), generator=g, dtype=torch.uint8) if image_u8 else torch.randn(B, 3, img, img, generator=g)
     labels = torch.randint(5, vocab, (B, S), generator=g)
     lens = torch.randint(max(2, S // 4), S + 1, (B,), generator=g)
     am = (torch.arange(S)[None, :] < lens[:, None]).long()
@@ -34,14 +46,14 @@ class SyntheticContextBertDataset(Dataset):
     """`len` samples of the schema above; `collate_fn` stacks WITHOUT the reference's .squeeze() (which drops the batch
     dimension at B == 1, pretrain_datasets.py:218-225)."""
 
-    def __init__(self, length=1024, max_caption_length=256, img=448, vocab=30000, seed=0):
-        self.length, self.S, self.img, self.vocab, self.seed = length, max_caption_length, img, vocab, seed
+    def __init__(self, length=1024, max_caption_length=256, img=448, vocab=30000, seed=0, image_u8=False):
+        self.length, self.S, self.img, self.vocab, self.seed, self.image_u8 = length, max_caption_length, img, vocab, seed, image_u8
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, index):
-        b = synthetic_batch(1, self.S, self.img, self.vocab, seed=self.seed * 1000003 + index)
+        b = synthetic_batch(1, self.S, self.img, self.vocab, seed=self.seed * 1000003 + index, image_u8=self.image_u8)
         return {k: v[0] for k, v in b.items()}
 
     @staticmethod

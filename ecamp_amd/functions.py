@@ -104,7 +104,7 @@ class StemFn(torch.autograd.Function):
         R, p, D = m.img_size, m.patch_size, m.embed_dim
         L = m.num_patches
         Lk = int(L * (1 - mask_ratio))
-        imgs = ops.bicubic_resize(big, R, R) if big.shape[-1] != R else big
+        imgs = ops.bicubic_resize(big, R, R) if (big.shape[-1] != R or ops.is_u8_image(big)) else big
         if noise is None:
             seed, off = m.next_rng()
             noise = ops.uniform((B, L), big.device, seed, off)

@@ -320,8 +320,36 @@ def uniform(shape, device, seed, offset):
 
 
 # --------------------------------------------------------------------------------------------- image side
+IMG_MEAN, IMG_STD = 0.4721, 0.3037   # the reference's Normalize (pretrain_datasets.py:52): one value for the three identical channels
+
+
+_IMG_LUT = {}
+
+
+def image_lut(device):
+    """lut[u] = ((float)u / 255 - mean) / std: ToTensor + Normalize of every byte value in their own f32 arithmetic (256 floats, built once)."""
+    key = str(device)
+    t = _IMG_LUT.get(key)
+    if t is None:
+        t = _IMG_LUT[key] = torch.arange(256, dtype=torch.float32).div(255.0).sub(IMG_MEAN).div(IMG_STD).to(device)
+    return t
+
+
+def is_u8_image(t):
+    """The compact image schema: uint8 [B, H, W] (or [B, 1, H, W]) grayscale crops instead of normalised f32 [B, 3, H, W]."""
+    return t.dtype == torch.uint8
+
+
 def bicubic_resize(src, Hd, Wd):
+    """f32 [B,C,Hs,Ws] -> f32 [B,C,Hd,Wd]; a uint8 [B,Hs,Ws] / [B,1,Hs,Ws] crop -> the normalised, resized f32 [B,3,Hd,Wd]."""
     _chk(src)
+    if is_u8_image(src):
+        src = src.reshape(src.shape[0], src.shape[-2], src.shape[-1])
+        assert src.is_contiguous()
+        B, Hs, Ws = src.shape
+        dst = torch.empty((B, 3, Hd, Wd), device=src.device, dtype=torch.float32)
+        call("ecamp_bicubic_resize_u8", ptr(src), ptr(dst), B, Hs, Ws, Hd, Wd, ptr(image_lut(src.device)), stream())
+        return dst
     B, C, Hs, Ws = src.shape
     assert src.dtype == torch.float32 and src.is_contiguous()
     dst = torch.empty((B, C, Hd, Wd), device=src.device, dtype=torch.float32)
@@ -381,8 +409,8 @@ def img_loss_bwd(pred_img, imgs, mask, dsr, gm_gs, B, R, p, dtype):
 def sr_fwd(pred_img, big, column, row, w1, b1, w2, b2, loss_sum, super_patch, window, mode=0):
     """mode 0: f32 stencils (parity); 1: bf16 matrix cores."""
     B, _, R, _ = pred_img.shape
-    call("ecamp_sr_fwd", ptr(pred_img), ptr(big), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(loss_sum), B, R,
-         super_patch, window, int(mode), stream())
+    call("ecamp_sr_fwd", ptr(pred_img), ptr(big), ptr(image_lut(big.device) if is_u8_image(big) else None), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+         ptr(loss_sum), B, R, super_patch, window, int(mode), stream())
 
 
 def sr_image(pred_img, w1, b1, w2, b2):
@@ -396,8 +424,8 @@ def sr_image(pred_img, w1, b1, w2, b2):
 def sr_bwd(pred_img, big, column, row, w1, b1, w2, b2, gw_ws, super_patch, window, mode=0):
     B, _, R, _ = pred_img.shape
     dsr = torch.empty((B, 3, R, R), device=pred_img.device, dtype=torch.float32)
-    call("ecamp_sr_bwd", ptr(pred_img), ptr(big), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dsr), ptr(gw_ws), B, R,
-         super_patch, window, int(mode), stream())
+    call("ecamp_sr_bwd", ptr(pred_img), ptr(big), ptr(image_lut(big.device) if is_u8_image(big) else None), ptr(column), ptr(row), ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+         ptr(dsr), ptr(gw_ws), B, R, super_patch, window, int(mode), stream())
     return dsr
 
 

@@ -306,7 +306,13 @@ class ECAMP(nn.Module):
         from ..functions import DecStemFn, ImgLossFn, NormFn, StemFn, VitBlockFn
         A = self.prepare()
         dev = A.device
-        big = batch["image"].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        img = batch["image"]
+        if img.dtype == torch.uint8:
+            # compact schema (ecamp_amd.data / ContextBertDataset(image_u8=True)): the grayscale crop itself, [B, 2R, 2R] or [B, 1, 2R, 2R];
+            # the bicubic and SR-loss kernels normalise it on the fly -- same bits as the f32 [B, 3, 2R, 2R] image, a twelfth of the bytes
+            big = img.to(dev, non_blocking=True).reshape(img.shape[0], img.shape[-2], img.shape[-1]).contiguous()
+        else:
+            big = img.to(dev, dtype=torch.float32, non_blocking=True).contiguous()
         mv = lambda t, dt: t.to(dev, dtype=dt, non_blocking=True).contiguous()
         ids, labels = mv(batch["ids"], torch.int64), mv(batch["labels"], torch.int64)
         attention_mask, type_ids = mv(batch["attention_mask"], torch.int64), mv(batch["type_ids"], torch.int64)
@@ -315,8 +321,10 @@ class ECAMP(nn.Module):
         if ids.dim() == 1:  # the reference's collate_fn .squeeze()s a batch of one (pretrain_datasets.py:218-225)
             ids, labels, attention_mask, type_ids, weights = (t.unsqueeze(0) for t in (ids, labels, attention_mask, type_ids, weights))
         B = big.shape[0]
-        if big.shape[1:] != (3, 2 * self.img_size, 2 * self.img_size):
-            raise ValueError("image must be [B,3,%d,%d] (2x the encoder resolution), got %s" % (2 * self.img_size, 2 * self.img_size, tuple(big.shape)))
+        want = (2 * self.img_size, 2 * self.img_size) if big.dtype == torch.uint8 else (3, 2 * self.img_size, 2 * self.img_size)
+        if tuple(big.shape[1:]) != want:
+            raise ValueError("image must be f32 [B,3,%d,%d] or uint8 [B,%d,%d] (2x the encoder resolution), got %s %s"
+                             % (2 * self.img_size, 2 * self.img_size, 2 * self.img_size, 2 * self.img_size, big.dtype, tuple(batch["image"].shape)))
         if noise is not None:
             noise = noise.to(dev, dtype=torch.float32).contiguous()
 

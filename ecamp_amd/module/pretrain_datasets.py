@@ -156,10 +156,12 @@ def pil_loader(path: str):
         return img.convert('RGB')
 
 
-def default_image_transform(size=448):
+def default_image_transform(size=448, image_u8=False):
     """pretrain_datasets.py:47-52 (RandomResizedCrop(448, scale=(0.2,1), bicubic) / flip / grayscale x3 / normalise) with PIL and
     torch only (torchvision is not a dependency).  Draws from the torch RNG as torchvision's transforms do, so Python's `random`
-    stream -- which the text half of the item consumes -- is left exactly as in the reference."""
+    stream -- which the text half of the item consumes -- is left exactly as in the reference.
+    image_u8: stop before ToTensor / Normalize and return the grayscale crop itself, uint8 [size, size] -- one byte per pixel instead
+    of twelve through the DataLoader, pinned memory, PCIe and HBM; the model's kernels normalise it on the fly to the same bits."""
     import math
 
     import numpy as np
@@ -187,6 +189,8 @@ def default_image_transform(size=448):
         img = img.crop(box).resize((size, size), Image.BICUBIC)
         if float(torch.rand(1).item()) < 0.5:
             img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        if image_u8:
+            return torch.from_numpy(np.array(img.convert('L'), dtype=np.uint8))
         g = np.asarray(img.convert('L'), dtype=np.float32) / 255.0
         t = torch.from_numpy((g - 0.4721) / 0.3037)
         return t[None].expand(3, size, size).contiguous()
@@ -199,7 +203,7 @@ class ContextBertDataset(Dataset):
     `mimic_wordpiece.json`, `mimic-cxr-2.0.0-entity-llm.csv` (img_path, report, llm_output) and
     `mimic-cxr-2.0.0-attn-label.csv` (label_i, label_j)."""
 
-    def __init__(self, data_root, max_caption_length: int = 256, transform=None):
+    def __init__(self, data_root, max_caption_length: int = 256, transform=None, image_u8=False):
         import tokenizers
         self.max_caption_length = max_caption_length
         self.data_root = data_root
@@ -208,7 +212,7 @@ class ContextBertDataset(Dataset):
         self.tokenizer.enable_truncation(max_length=self.max_caption_length)
         self.tokenizer.enable_padding(length=self.max_caption_length)
         self.vocab = MaskVocab.from_tokenizer(self.tokenizer)
-        self.transform = transform if transform is not None else default_image_transform(448)
+        self.transform = transform if transform is not None else default_image_transform(448, image_u8=image_u8)
 
     def __len__(self):
         return len(self.images_list)
@@ -260,3 +264,15 @@ class DeviceMasker:
         stream = torch.rand((B, 2 * L), generator=self.gen, device=ids.device, dtype=torch.float64)
         masked, mask_pos = context_mask(ids, self.vocab, stream)
         return masked, template_weights(ids, mask_pos)
+
+
+def measure_item_rate(dataset, seconds=2.0, max_items=256):
+    """Items per second ONE loader worker gets out of `dataset.__getitem__` (image decode + augmentation on PIL, tokenisation, the
+    masking arithmetic): what `--num_workers` has to be multiplied with to feed a GPU.  At ~6.8 k pairs/s per MI355X a node of
+    eight needs ~55 k items/s; main_pretrain.py prints this figure next to the step rate so that a loader-bound run is visible."""
+    import time
+    t0, n = time.time(), 0
+    while n < max_items and (n < 4 or time.time() - t0 < seconds):
+        dataset[n % len(dataset)]
+        n += 1
+    return n / max(time.time() - t0, 1e-9)

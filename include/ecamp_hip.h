@@ -154,6 +154,13 @@ int ecamp_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, ecampSt
 /* ---- image side ---- */
 int ecamp_bicubic_resize(const float* src, float* dst, int64_t planes, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd,
                          ecampStream_t stream); /* model_ecamp.py:318 */
+/* The same resize from the dataset's grayscale crop as uint8 [B,Hs,Ws] (pretrain_datasets.py:47-52: Grayscale(3) + ToTensor +
+ * Normalize with ONE mean / std, i.e. three identical channels): dst f32 [B,3,Hd,Wd] = resize(lut[src]), the three planes written
+ * from one evaluation.  lut: 256 f32 on the device, lut[u] = ((float)u / 255 - mean) / std in f32 arithmetic (ToTensor + Normalize
+ * per byte value), which makes the result bit for bit what ecamp_bicubic_resize gives on the f32 [B,3,Hs,Ws] image for the exact 2x
+ * ratio of the hot path and for Hs == Hd (the normalised image itself).  One byte per pixel crosses PCIe and is read instead of twelve. */
+int ecamp_bicubic_resize_u8(const uint8_t* src, float* dst, int64_t B, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd, const float* lut,
+                            ecampStream_t stream);
 int ecamp_mask_indices(const float* noise, int64_t B, int32_t L, int32_t len_keep, int32_t* ids_restore, int32_t* ids_keep,
                        float* mask, ecampStream_t stream); /* model_ecamp.py:168-193 */
 int ecamp_im2col_gather(const float* imgs, const int32_t* ids_keep, void* out, int64_t B, int32_t Lk, int32_t C, int32_t R,
@@ -168,17 +175,20 @@ int ecamp_unpatchify_mim(const void* pred, const float* imgs, const float* mask,
                          int32_t R, int32_t p, int32_t dtype, ecampStream_t stream); /* model_ecamp.py:153-165,288-298 */
 int ecamp_img_loss_bwd(const float* pred_img, const float* imgs, const float* mask, const float* dsr, const float* gm_gs,
                        void* dpred, int64_t B, int32_t R, int32_t p, int32_t dtype, ecampStream_t stream);
-int ecamp_sr_fwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
-                 const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B, int32_t R, int32_t super_patch,
-                 int32_t window, int32_t mode, ecampStream_t stream); /* model_ecamp.py:28-46,196-215,291-299; fused, LDS-resident.
-                 mode 0: f32 VALU stencils (parity); mode 1: bf16 matrix cores (4x4x4 MFMA per tap), f32 accumulate / skip / loss */
+int ecamp_sr_fwd(const float* pred_img, const void* big, const float* big_lut, const int64_t* column,
+                 const int64_t* row, const float* w1, const float* b1, const float* w2, const float* b2, float* loss_sum, int64_t B,
+                 int32_t R, int32_t super_patch, int32_t window, int32_t mode,
+                 ecampStream_t stream); /* model_ecamp.py:28-46,196-215,291-299; fused, LDS-resident.
+                 mode 0: f32 VALU stencils (parity); mode 1: bf16 matrix cores (4x4x4 MFMA per tap), f32 accumulate / skip / loss.
+                 big: the loss target, f32 [B,3,2R,2R] (big_lut = NULL) or the uint8 crop [B,2R,2R] normalised on the fly through
+                 big_lut[256] (see ecamp_bicubic_resize_u8; same bits as the f32 image) */
 /* The SR head's output image itself, f32 [B,3,2R,2R] = super_res(pred_img) (model_ecamp.py:28-46,285): never materialised by the
  * training step (ecamp_sr_fwd folds it into the loss); for parity checks against the reference's activation and visualisation. */
 int ecamp_sr_image(const float* pred_img, const float* w1, const float* b1, const float* w2, const float* b2, float* sr, int64_t B,
                    int32_t R, ecampStream_t stream);
-int ecamp_sr_bwd(const float* pred_img, const float* big, const int64_t* column, const int64_t* row, const float* w1,
-                 const float* b1, const float* w2, const float* b2, float* dsr, float* gw_ws, int64_t B, int32_t R,
-                 int32_t super_patch, int32_t window, int32_t mode, ecampStream_t stream);
+int ecamp_sr_bwd(const float* pred_img, const void* big, const float* big_lut, const int64_t* column,
+                 const int64_t* row, const float* w1, const float* b1, const float* w2, const float* b2, float* dsr, float* gw_ws,
+                 int64_t B, int32_t R, int32_t super_patch, int32_t window, int32_t mode, ecampStream_t stream);
 int ecamp_scaled_accum(const float* ws, float* grad, const float* scale_dev, int32_t idx, int32_t n, ecampStream_t stream);
 
 /* ---- report side ---- */

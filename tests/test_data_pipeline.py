@@ -99,3 +99,31 @@ def test_text_item_with_tokenizer_matches_reference_items():
         assert (masked[0].numpy() == g["item_masked"][k]).all() and np.array_equal(w[0].numpy(), g["item_weights"][k])
     batch = ds.collate_fn([(torch.zeros(3, 2, 2), ids, am, ty, masked, w, torch.tensor([1]), torch.tensor([2]))])
     assert batch["ids"].shape == (1, ds.max_caption_length) and batch["column"].shape == (1,)   # no .squeeze() at B == 1
+
+
+def test_uint8_image_item_is_the_f32_item_before_normalisation():
+    """ContextBertDataset(image_u8=True): the image half of an item stops before ToTensor / Normalize (pretrain_datasets.py:50-52) and
+    returns the uint8 grayscale crop; normalising it reproduces the default f32 item bit for bit (same crop, same flip: the transform
+    draws from the torch RNG exactly as before).  measure_item_rate reports a positive items/s figure."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from ecamp_amd.data import normalise_u8
+    from ecamp_amd.module.pretrain_datasets import default_image_transform, measure_item_rate
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 256, (300, 260, 3), dtype=np.uint8), "RGB")
+    torch.manual_seed(5)
+    f = default_image_transform(64)(img)
+    torch.manual_seed(5)
+    u = default_image_transform(64, image_u8=True)(img)
+    assert f.shape == (3, 64, 64) and f.dtype == torch.float32 and u.shape == (64, 64) and u.dtype == torch.uint8
+    assert torch.equal(normalise_u8(u[None])[0], f)
+
+    class Fake:
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            return default_image_transform(64, image_u8=True)(img)
+
+    assert measure_item_rate(Fake(), seconds=0.2, max_items=16) > 0

@@ -332,6 +332,26 @@ def test_attention_saved_dropout_bits_equal_regenerated_mask(dev, B, H, Tq, Tk, 
 
 
 # ------------------------------------------------------------------------------------------------ image side
+@pytest.mark.parametrize("Hs,Hd", [(448, 224), (64, 32), (48, 20), (40, 40)])
+def test_bicubic_from_uint8_crops_equals_the_f32_schema(dev, Hs, Hd):
+    """Compact image schema: ecamp_bicubic_resize_u8 on uint8 [B,Hs,Hs] grayscale crops gives, bit for bit, what ecamp_bicubic_resize
+    gives on the reference's f32 [B,3,Hs,Hs] image (Grayscale(3) + ToTensor + Normalize, pretrain_datasets.py:50-52): the exact-2x path,
+    an arbitrary ratio and no resize at all."""
+    from ecamp_amd.data import normalise_u8
+    o = ops()
+    u8 = torch.randint(0, 256, (3, Hs, Hs), generator=torch.Generator().manual_seed(Hs), dtype=torch.uint8)
+    u8[0, 0, :8] = torch.tensor([0, 255, 1, 254, 127, 128, 0, 255], dtype=torch.uint8)
+    f32 = normalise_u8(u8)
+    a = o.bicubic_resize(u8.to(dev), Hd, Hd)
+    b = o.bicubic_resize(f32.to(dev), Hd, Hd) if Hs != Hd else f32.to(dev)
+    assert a.shape == (3, 3, Hd, Hd) and a.dtype == torch.float32
+    if Hs == 2 * Hd or Hs == Hd:      # the hot path's ratio (and no resize): identical bits
+        assert torch.equal(a, b), float((a - b).abs().max())
+    else:                             # any other ratio: the same taps and weights; the compiler may contract the two kernels' sums differently
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    assert torch.equal(a[:, 0], a[:, 1]) and torch.equal(a[:, 0], a[:, 2])
+
+
 def test_bicubic(dev):
     o = ops()
     x = gen(3, 3, 64, 64, seed=1)

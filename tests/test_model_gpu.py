@@ -674,3 +674,35 @@ def test_b512_step_is_the_mean_of_its_sub_batches(dev, fp8):
     print("B=512 %s: losses full %s, mean of parts %s (rel %.2e); gradient rel l2 %.3e" % ("fp8" if fp8 else "bf16", full.tolist(), parts.tolist(), le, ge))
     assert torch.isfinite(full).all() and torch.isfinite(g_full).all() and float(g_full.abs().max()) > 0
     assert le < (1e-2 if fp8 else 2e-3) and ge < (8e-2 if fp8 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_uint8_image_schema_is_bit_identical_to_the_f32_schema(dev, dtype):
+    """The compact image schema (uint8 [B,448,448] grayscale crops, normalised by the bicubic and SR-loss kernels on the fly) against the
+    reference's f32 [B,3,448,448] schema holding the same pixels: identical losses and an identical gradient arena, in both compute
+    modes (f32: fused f32 SR stencils; bf16: the matrix-core SR head)."""
+    from ecamp_amd.data import normalise_u8, synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    torch.manual_seed(0)
+    model = me.ecamp_tiny(compute_dtype=dtype).to(dev)
+    model.eval()
+    B, S = 3, 64
+    b8 = synthetic_batch(B, S, 448, seed=31, image_u8=True)
+    assert b8["image"].dtype == torch.uint8 and tuple(b8["image"].shape) == (B, 448, 448)
+    bf = dict(b8, image=normalise_u8(b8["image"]))
+    noise = torch.rand(B, 196, generator=torch.Generator().manual_seed(9))
+    arena = model.prepare()
+    res = []
+    for batch in (b8, bf, dict(b8, image=b8["image"][:, None])):      # [B,1,448,448] is accepted too
+        arena.flat_g.zero_()
+        out = model(batch, noise=noise)
+        sum(out).backward()
+        torch.cuda.synchronize()
+        res.append((torch.stack([t.detach() for t in out]).cpu(), arena.flat_g.clone()))
+    # identical inputs to every kernel; the loss sums and the SR weight gradients leave their kernels through float atomics (summation
+    # order varies run to run), so "identical" is asserted to f32 rounding of those sums
+    for other in (res[1][0], res[2][0]):
+        assert float(((res[0][0] - other).abs() / other.abs()).max()) < 2e-6, (res[0][0], other)
+    d = float((res[0][1] - res[1][1]).abs().max() / res[1][1].abs().max())
+    print("u8 vs f32 image schema (%s): losses equal to summation order, gradient arena max rel diff %.2e" % (dtype, d))
+    assert d < 1e-5
