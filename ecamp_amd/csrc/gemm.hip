@@ -189,398 +189,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 }
 
 // =============================================================================================
-// "P8": persistent 256x256-tile kernel, 8 waves (2 x 4) of 128x64, one workgroup per CU, for GEMMs with enough tiles to fill
-// the chip.  Measured on MI355X the operand stream L2 -> LDS tops out near 12.5 TB/s (~21 B/clk/CU): the 128^2 kernel above
-// moves 2 x 128 x K operand bytes per 128^2 outputs and sits on that roof; a 256^2 tile halves the bytes per flop.
-//  * Operands arrive by direct L2 -> LDS DMA (global_load_lds_dwordx4) into a 5-stage ring of K=32 tiles (32 KB per stage: all 160 KB of a CU).
-//    The ring is ONE flat stream of K tiles over all the output tiles a workgroup processes: the DMA cursor runs four K tiles
-//    ahead of the MFMAs and simply moves on to the next output tile, so the next tile's first operands are already in LDS
-//    while the current tile's epilogue stores drain (with one resident workgroup per CU nothing else would hide them).
-//  * A DMA is issued in four pieces BETWEEN the MFMA groups of a K tile (an issue blocks the wave while the texture path is
-//    busy; the SIMD's other wave keeps the matrix pipe fed) and is only ever waited for with a COUNTED s_waitcnt vmcnt(8|4|0)
-//    followed by one raw s_barrier per K tile.  Stores and epilogue loads also count in vmcnt on gfx9; loads retire in order,
-//    so "at most 8 outstanding" still implies "this K tile's four DMAs have landed" -- the wait is conservative, never early.
-//  * LDS images are DMA-linear, so the bank swizzles are applied to each lane's SOURCE address (kc: 64-B rows, 16-B chunk ^
-//    key(row); strided: 512-B rows, 32-B unit ^ key(k-row)) and again on the fragment reads.
-//  * Fragment row i of the N-side operand is mapped to output column (i>>2)*8 + (tn&1)*4 + (i&3) of a 32-column group, so
-//    after the MFMA (N fragment as the A operand: a lane owns 4 consecutive D rows = columns) a lane holds 8 CONSECUTIVE
-//    output columns over two accumulators and every epilogue access is 16 B per lane.
-// =============================================================================================
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
-#define P8_STAGE_BYTES 32768
-#define GLDS16(SRC, DST) \
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(SRC), (void __attribute__((address_space(3)))*)(DST), 16, 0, 0)
-
-// one output tile (and split-K slice) of the persistent kernel; every field is wave-uniform
-struct P8Item {
-    int m0, n0, kbeg, kend, nt, z, ncol;
-};
-__device__ __forceinline__ P8Item p8_decode(const GemmArgs& g, int v, int total) {
-    const unsigned f = (unsigned)xcd_remap(v, total), ntile = (unsigned)(g.nbm * g.nbn);
-    // grouped order inside a split: 8 M-blocks are walked for one N-block before the next N-block, so the ~32 tiles an XCD works
-    // on at a time form an 8 x 4 patch (8 + 4 operand panels instead of 3 + 12) and consecutive rounds keep the 8 M panels in L2
-    const unsigned z = f / ntile, tile = f - z * ntile;
-    const unsigned gw = 8u * (unsigned)g.nbn, grp = tile / gw, in = tile - grp * gw, first = grp * 8u;
-    const unsigned gsz = min(8u, (unsigned)g.nbm - first);
-    const unsigned nb = in / gsz, mb = first + (in - nb * gsz);
-    P8Item it;
-    it.m0 = (int)mb * 256; it.n0 = (int)nb * 256; it.z = (int)z; it.ncol = (int)nb;
-    it.kbeg = (int)z * g.k_per_split;
-    it.kend = min(g.K, it.kbeg + g.k_per_split);
-    it.nt = (it.kend - it.kbeg + 31) >> 5;
-    return it;
-}
-
-// Rows mbase + 16*i (i < NM), columns n0 + 32*h + [0, 8) (h < 2): NM*2 groups of 8 consecutive outputs per lane.
-// All loads of the batch (gelu' operand, residual, old f32 value) are issued before the first store: written group by group,
-// every load would wait behind the previous group's store (they may alias as far as the compiler knows) and the epilogue
-// would be serialised on memory latency.
-template <int TM0, int NM>
-__device__ __forceinline__ void p8_epilogue_rows(const GemmArgs& g, const f32x4 (&acc)[8][4], int mbase, int n0, int z,
-                                                 const float (&bias)[2][8]) {
-    if (!g.wide || n0 + 40 > g.N) {   // ragged / unaligned: 4-column pieces
-#pragma unroll
-        for (int i = 0; i < NM; ++i)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-                epilogue4<bf16_t>(g, mbase + i * 16, n0 + (tn >> 1) * 32 + (tn & 1) * 4, acc[TM0 + i][tn], z);
-        return;
-    }
-    const float al = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
-    const bf16_t* gm = reinterpret_cast<const bf16_t*>(g.gmul);
-    const bf16_t* rs = reinterpret_cast<const bf16_t*>(g.residual);
-    const bool acc_old = !g.partial && g.out_f32 && g.accumulate;
-    uint4 qg[NM][2], qr[NM][2];
-    if (gm) {
-#pragma unroll
-        for (int i = 0; i < NM; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m = min(mbase + i * 16, g.M - 1);
-                qg[i][h] = *reinterpret_cast<const uint4*>(gm + (long)m * g.ldg + n0 + h * 32);
-            }
-    }
-    if (rs) {
-#pragma unroll
-        for (int i = 0; i < NM; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m = min(mbase + i * 16, g.M - 1);
-                qr[i][h] = *reinterpret_cast<const uint4*>(rs + (long)m * g.ldr + n0 + h * 32);
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < NM; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m = mbase + i * 16, n = n0 + h * 32;
-            if (m >= g.M) continue;
-            const f32x4 a0 = acc[TM0 + i][2 * h], a1 = acc[TM0 + i][2 * h + 1];
-            float v[8] = {a0[0] * al, a0[1] * al, a0[2] * al, a0[3] * al, a1[0] * al, a1[1] * al, a1[2] * al, a1[3] * al};
-            if (g.bias) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += bias[h][r];
-            }
-            if (g.pre_out) st8<bf16_t>(reinterpret_cast<bf16_t*>(g.pre_out) + (long)m * g.ldp + n, v);
-            if (g.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16_t>(g.pre_out ? rnd<bf16_t>(v[r]) : v[r]);
-            }
-            if (gm) {
-                const uint32_t w[4] = {qg[i][h].x, qg[i][h].y, qg[i][h].z, qg[i][h].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[2 * r] *= gelu_grad_t<bf16_t>(__uint_as_float(w[r] << 16));
-                    v[2 * r + 1] *= gelu_grad_t<bf16_t>(__uint_as_float(w[r] & 0xffff0000u));
-                }
-            }
-            if (rs) {
-                const uint32_t w[4] = {qr[i][h].x, qr[i][h].y, qr[i][h].z, qr[i][h].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[2 * r] += __uint_as_float(w[r] << 16);
-                    v[2 * r + 1] += __uint_as_float(w[r] & 0xffff0000u);
-                }
-            }
-            if (g.partial) {
-                st8<float>(g.partial + ((long)z * g.M + m) * g.N + n, v);
-            } else if (g.out_f32) {
-                float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n;
-                if (acc_old) {
-                    float o[8];
-                    ld8<float>(c, o);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += o[r];
-                }
-                st8<float>(c, v);
-            } else {
-                st8<bf16_t>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n, v);
-            }
-        }
-}
-
-// bank keys.  kc tiles (64-B rows, 4 rows per 256-B bank row): a ds_read_b128 lane group holds the fragment rows {0-3, 12-15}
-// at chunk c and {4-11} at chunk c^1, so the key must differ per 4-row group: (-(row >> KS)) & 3 with KS = 2 for the M side
-// (consecutive rows) and KS = 3 for the N side (whose 4-row groups lie 8 rows apart, see the column remap above).
-template <int KS> __device__ __forceinline__ int p8_kc_key(int row) { return (0 - (row >> KS)) & 3; }
-__device__ __forceinline__ int p8_key(int row) { return (row & 7) ^ (((row >> 3) & 1) << 2); }
-
-// one DMA piece = 512 lanes x 16 B = 8 KB = half an operand tile; i in {0, 1}
-template <int KS>
-__device__ __forceinline__ void p8_dma_kc(const bf16_t* P, long ld, int row0, int nrows, int k0, int kend, unsigned char* tile, int i,
-                                          int wave, int lane) {
-    const long zoff = reinterpret_cast<const bf16_t*>(g_zero16) - P;  // element offset from P to the 16-B zero word
-    int c = (i * 8 + wave) * 64 + lane;               // 1024 chunks of 16 B: row = c>>2 (256 rows), 4 chunks per 64-B row
-    int row = c >> 2, kc = (c & 3) ^ p8_kc_key<KS>(row);
-    int gr = min(row0 + row, nrows - 1), gk = k0 + kc * 8;
-    // one DMA instruction per lane whatever the predicate (a ?: between two pointers compiles to two exec-masked DMAs)
-    const long off = gk < kend ? (long)gr * ld + gk : zoff;
-    GLDS16(P + off, tile + (i * 8 + wave) * 1024);
-}
-__device__ __forceinline__ void p8_dma_oc(const bf16_t* P, long ld, int row0, int nrows, int k0, int kend, unsigned char* tile, int i,
-                                          int wave, int lane) {
-    const long zoff = reinterpret_cast<const bf16_t*>(g_zero16) - P;
-    int c = (i * 8 + wave) * 64 + lane;               // 32 k-rows x 32 chunks (512-B rows)
-    int kr = c >> 5, oc = (c & 31) ^ (p8_key(kr) << 1);
-    int gk = k0 + kr, gr = min(row0 + oc * 8, nrows - 8);
-    const long off = gk < kend ? (long)gk * ld + gr : zoff;
-    GLDS16(P + off, tile + (i * 8 + wave) * 1024);
-}
-template <int KS>
-__device__ __forceinline__ bf16x8 p8_frag_kc(const unsigned char* tile, int row, int lk) {
-    return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((lk ^ p8_kc_key<KS>(row)) << 4));
-}
-// 16 outputs x 32 k from a strided tile: lane i = 4r+q of a 16-lane group supplies 4 outputs at o0 + q*QS (QS = 4: 16
-// consecutive outputs; QS = 8: the N-side column remap, 2-way bank conflicts accepted -- LDS is not the bottleneck), k-row r
-template <int QS>
-__device__ __forceinline__ bf16x8 p8_frag_oc(const unsigned char* tile, int o0, int lane) {
-    const int i = lane & 15, g = lane >> 4;
-    const int r0 = g * 8 + (i >> 2), r1 = r0 + 4;
-    const int col = o0 + (i & 3) * QS, ch = col >> 3, within = (col & 7) * 2;
-    const unsigned char* p0 = tile + r0 * 512 + ((ch ^ (p8_key(r0) << 1)) << 4) + within;
-    const unsigned char* p1 = tile + r1 * 512 + ((ch ^ (p8_key(r1) << 1)) << 4) + within;
-    v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p0));
-    v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(p1));
-    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-template <bool A_KC, bool B_KC, bool ROWSUM>
-__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 5 stages x {A 16 KB, B 16 KB}; the ONLY LDS object
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int total = g.nbm * g.nbn * g.nsplit, G = (int)gridDim.x;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
-    const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
-    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-    const int lrow = lane & 15, lk = lane >> 4;
-    const int nrow = (lrow >> 2) * 8 + (lrow & 3);   // N-side fragment row -> column within a 32-column group (+ (tn&1)*4)
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // bias gradient inside the weight-gradient GEMM: the first wave column of the first N-tile column also multiplies its
-    // M-side fragments by an all-ones fragment (compile-time flag: 32 more accumulator registers)
-    f32x4 accr[ROWSUM ? 8 : 1];
-#pragma unroll
-    for (int i = 0; i < (ROWSUM ? 8 : 1); ++i) accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-
-    // ---- DMA cursor: (output tile pit, K tile pt of it), stream position pg (ring stage = pg & 3)
-    int pv = (int)blockIdx.x;
-    P8Item pit = p8_decode(g, pv, total);
-    int pt = 0, pg = 0, ps = 0;   // ps = pg % 5, the ring stage the cursor fills next
-    bool pdone = false;
-#define P8_PIECE(PC)                                                                                                \
-    do {                                                                                                            \
-        unsigned char* sA_ = lds + ps * P8_STAGE_BYTES;                                                              \
-        unsigned char* sB_ = sA_ + 16384;                                                                           \
-        const int k0_ = pit.kbeg + pt * 32;                                                                         \
-        if ((PC) < 2) {                                                                                             \
-            if (A_KC) p8_dma_kc<2>(A, g.lda, pit.m0, g.M, k0_, pit.kend, sA_, (PC), wave, lane);                     \
-            else p8_dma_oc(A, g.lda, pit.m0, g.M, k0_, pit.kend, sA_, (PC), wave, lane);                             \
-        } else {                                                                                                    \
-            if (B_KC) p8_dma_kc<3>(B, g.ldb, pit.n0, g.N, k0_, pit.kend, sB_, (PC) - 2, wave, lane);                 \
-            else p8_dma_oc(B, g.ldb, pit.n0, g.N, k0_, pit.kend, sB_, (PC) - 2, wave, lane);                         \
-        }                                                                                                           \
-    } while (0)
-#define P8_ADVANCE()                                                                                                \
-    do {                                                                                                            \
-        ++pg;                                                                                                       \
-        ps = ps == 4 ? 0 : ps + 1;                                                                                  \
-        if (++pt == pit.nt) {                                                                                       \
-            pt = 0;                                                                                                 \
-            pv += G;                                                                                                \
-            if (pv < total) pit = p8_decode(g, pv, total); else pdone = true;                                       \
-        }                                                                                                           \
-    } while (0)
-
-    // prologue: up to four K tiles in flight
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i)
-        if (!pdone) {
-            P8_PIECE(0); P8_PIECE(1); P8_PIECE(2); P8_PIECE(3);
-            P8_ADVANCE();
-        }
-
-#define P8_WAIT_DMA(AHEAD)                                                     \
-    do {                                                                       \
-        const int ah_ = (AHEAD);                                               \
-        if (ah_ >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");        \
-        else if (ah_ == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    \
-        else if (ah_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
-    } while (0)
-#define P8_READ_FN(DST, SB)                                                                                          \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
-            const int o = wn + (i >> 1) * 32 + (i & 1) * 4;                                                          \
-            DST[i] = B_KC ? p8_frag_kc<3>((SB), o + nrow, lk) : p8_frag_oc<8>((SB), o, lane);                        \
-        }                                                                                                            \
-    } while (0)
-#define P8_READ_FM(I, SA) (fm[(I)] = A_KC ? p8_frag_kc<2>((SA), wm + (I) * 16 + lrow, lk) : p8_frag_oc<4>((SA), wm + (I) * 16, lane))
-#define P8_MFMA_GROUP(GRP)                                                                                           \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int tm = 2 * (GRP); tm < 2 * (GRP) + 2; ++tm)                                         \
-            _Pragma("unroll") for (int tn = 0; tn < 4; ++tn)                                                         \
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                               \
-                    __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fn[tn]),                          \
-                    __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), acc[tm][tn], 0, 0, 0);   \
-    } while (0)
-#define P8_ROWSUM_MFMA()                                                                                             \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int tm = 0; tm < 8; ++tm)                                                             \
-            accr[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                      \
-                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ones),                                \
-                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), accr[tm], 0, 0, 0);          \
-    } while (0)
-    // epilogue of one output tile + reset of the accumulators
-    auto finish_tile = [&](const P8Item& it, bool rowsum_here) {
-        if (!(g.dbg & 4)) {
-            const int nb = it.n0 + wn + lk * 8;
-            float bias[2][8];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) bias[h][r] = 0.f;
-            if (g.bias && g.wide && nb + 40 <= g.N) {
-                ld8<float>(g.bias + nb, bias[0]);
-                ld8<float>(g.bias + nb + 32, bias[1]);
-            }
-            p8_epilogue_rows<0, 4>(g, acc, it.m0 + wm + lrow, nb, it.z, bias);
-            p8_epilogue_rows<4, 4>(g, acc, it.m0 + wm + 64 + lrow, nb, it.z, bias);
-            if (ROWSUM && rowsum_here && lk == 0) {  // every row of the ones-product is the same sum; lane (lk = 0, r = 0) owns column lrow
-                const float al = g.alpha_dev_out ? g.alpha_out * g.alpha_dev_out[0] : g.alpha_out;
-#pragma unroll
-                for (int tm = 0; tm < 8; ++tm) {
-                    int m = it.m0 + wm + tm * 16 + lrow;
-                    if (m < g.M) atomicAdd(g.rowsum + m, al * accr[tm][0]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (ROWSUM) {
-#pragma unroll
-            for (int i = 0; i < (ROWSUM ? 8 : 1); ++i) accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-
-    int cg = 0;
-    bf16x8 fm[8], fn[4];
-    // One barrier per K tile; the DMA pieces of K tile cg+4 go between the MFMA groups of K tile cg (5-stage ring).
-    //  * contraction-contiguous M operand (forward, data gradient): the second half of the M-side fragments is read one MFMA
-    //    group ahead of its use (into registers the first groups have freed), so only eight of the twelve fragment reads of a
-    //    K tile are exposed: -10% loop time.  Going further -- publishing K tile cg+1 at the barrier of cg and reading its first
-    //    fragments during the MFMAs of cg -- measured 5-30% SLOWER (LDS reads between MFMA groups cost more than they hide).
-    //  * strided M operand (weight gradient; LDS transpose reads): all twelve fragments are read after the barrier -- spreading
-    //    the transpose reads between the MFMA groups measured 40% slower.
-    // (A two-barrier schedule with the two M halves running one phase apart -- one wave of a SIMD multiplying while its
-    // neighbour reads and issues DMAs -- measured 20% slower; waiting for the next tile's DMAs before the epilogue so that
-    // later counted waits do not also wait for the stores made no difference: DESIGN.md, rejected experiments.)
-    int cs = 0;   // cg % 5
-    for (int cv = (int)blockIdx.x; cv < total; cv += G) {
-        const P8Item cit = p8_decode(g, cv, total);
-        const bool do_rowsum = ROWSUM && g.rowsum != nullptr && cit.ncol == 0 && (wave & 3) == 0;
-        for (int t = 0; t < cit.nt; ++t, ++cg) {
-            const int cs1 = cs == 4 ? 0 : cs + 1;
-            const unsigned char* sA = lds + cs * P8_STAGE_BYTES;
-            const unsigned char* sB = sA + 16384;
-            if (A_KC) {
-                P8_WAIT_DMA(pg - cg - 1);                    // this K tile's DMAs have landed (mine); younger tiles stay in flight
-                __builtin_amdgcn_s_barrier();                // ... everyone's have, and everyone is done reading K tile cg-1
-                const bool more = !pdone;
-                P8_READ_FN(fn, sB);
-                P8_READ_FM(0, sA); P8_READ_FM(1, sA); P8_READ_FM(2, sA); P8_READ_FM(3, sA);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-                P8_MFMA_GROUP(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(0);                       // K tile cg+4 into the stage K tile cg-1 vacated
-                P8_READ_FM(4, sA); P8_READ_FM(5, sA);
-                __builtin_amdgcn_sched_barrier(0);
-                P8_MFMA_GROUP(1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(1);
-                P8_READ_FM(6, sA); P8_READ_FM(7, sA);
-                __builtin_amdgcn_sched_barrier(0);
-                P8_MFMA_GROUP(2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(2);
-                __builtin_amdgcn_sched_barrier(0);
-                P8_MFMA_GROUP(3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(3);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(0);
-                if (more) P8_ADVANCE();
-            } else {
-                P8_WAIT_DMA(pg - cg - 1);                    // this K tile's DMAs have landed (mine); younger tiles stay in flight
-                __builtin_amdgcn_s_barrier();                // ... everyone's have, and everyone is done reading K tile cg-1
-                const bool more = !pdone;
-                P8_READ_FN(fn, sB);
-                P8_READ_FM(0, sA); P8_READ_FM(1, sA); P8_READ_FM(2, sA); P8_READ_FM(3, sA);
-                P8_READ_FM(4, sA); P8_READ_FM(5, sA); P8_READ_FM(6, sA); P8_READ_FM(7, sA);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-                P8_MFMA_GROUP(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(0);
-                __builtin_amdgcn_sched_barrier(0);
-                P8_MFMA_GROUP(1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(1);
-                __builtin_amdgcn_sched_barrier(0);
-                P8_MFMA_GROUP(2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(2);
-                __builtin_amdgcn_sched_barrier(0);
-                P8_MFMA_GROUP(3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P8_PIECE(3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ROWSUM && do_rowsum) P8_ROWSUM_MFMA();
-                __builtin_amdgcn_s_setprio(0);
-                if (more) P8_ADVANCE();
-            }
-            cs = cs1;
-        }
-        // the DMA cursor is already up to four K tiles into the next output tile
-        finish_tile(cit, do_rowsum);
-    }
-#undef P8_WAIT_DMA
-#undef P8_READ_FN
-#undef P8_READ_FM
-#undef P8_MFMA_GROUP
-#undef P8_ROWSUM_MFMA
-#undef P8_PIECE
-#undef P8_ADVANCE
-}
-
-// =============================================================================================
 // f32 (parity mode): v_mfma_f32_16x16x4_f32, BK = 16, LDS tiles stored [k][row] with row pitch 144
 // =============================================================================================
 #define FK 16
@@ -895,15 +503,6 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
 // host entry
 // =============================================================================================
 // ---- kernel selection ------------------------------------------------------------------------------------------
-// ECAMP_GEMM_P8: unset = automatic, 0 = never, 2 = always (development).  Automatic: the persistent 256^2 kernel takes the
-// forward (both operands contraction-contiguous) and weight-gradient (both strided) forms when there are enough 256^2 work
-// items to give ~every CU one; the data-gradient form only when its output is at least as wide as its contraction (fc2, BERT
-// output dense), where it measured 3-15 % faster -- elsewhere the 128^2 kernel is equal or better.
-static int g_p8_mode = -2;   // -2: not set by ecamp_set_option("p8_mode", ...) -> the environment decides
-static int p8_env() {
-    static const int v = getenv("ECAMP_GEMM_P8") ? atoi(getenv("ECAMP_GEMM_P8")) : -1;
-    return g_p8_mode != -2 ? g_p8_mode : v;
-}
 static int p8_num_cu() {
     static int ncu = 0;
     if (!ncu) {
@@ -922,18 +521,8 @@ static int p8_num_cu() {
 // persistent workgroup.  The data-parallel wrapper sets the reserve; the forward pass has no communication beside it.
 static int g_p8_wgrad = 1;
 static int g_p8_wgrad_reserve = 0;
-static bool p8_selected(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc, int dtype, int split_k) {
-    const int env = p8_env();
-    if (dtype != ECAMP_BF16 || env == 0) return false;
-    if (env == 2) return true;
-    if (!a_kc && !b_kc && !g_p8_wgrad) return false;
-    const long items = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
-    if (items < (long)(0.75 * p8_num_cu())) return false;
-    if (a_kc && !b_kc) return N >= K;   // data gradient: measured faster only when the output is at least as wide as the contraction
-    return (a_kc != 0) == (b_kc != 0);
-}
 
-// ---- Q8 (gemm_q8.h): the round-2 persistent kernel.  ECAMP_GEMM_Q8 / option "q8_mode": -1 automatic (default), 0 never, 2 whenever legal.
+// ---- Q8 (gemm_q8.h): the persistent 256x256x64 kernel.  ECAMP_GEMM_Q8 / option "q8_mode": -1 automatic (default), 0 never, 2 whenever legal.
 static int g_q8_mode = -2;
 static int q8_env() {
     static const int v = getenv("ECAMP_GEMM_Q8") ? atoi(getenv("ECAMP_GEMM_Q8")) : -1;
@@ -984,7 +573,6 @@ static bool q8_legal(const void* A, const void* B, const void* C, int64_t M, int
 
 extern "C" int ecamp_set_option(const char* name, int32_t value) {
     ECAMP_CHECK_ARG(name != nullptr, "set_option: null name");
-    if (strcmp(name, "p8_mode") == 0) { g_p8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 always
     if (strcmp(name, "q8_mode") == 0) { g_q8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 whenever legal
     if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
@@ -1015,7 +603,7 @@ extern "C" int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_k
     if (s_old < 1) s_old = 1;
     const long cap = (K + 255) / 256;
     if (s_old > cap) s_old = cap;
-    if (dtype != ECAMP_BF16 || p8_env() == 0 || (a_kc != 0) != (b_kc != 0)) return (int)s_old;
+    if (dtype != ECAMP_BF16 || q8_env() == 0 || (a_kc != 0) != (b_kc != 0) || (!a_kc && !b_kc && !g_p8_wgrad)) return (int)s_old;
     // persistent 256^2 kernel: one workgroup per CU walks the work items; pick the split count whose item count fills whole
     // rounds of the chip, preferring fewer splits (each split writes and re-reads an M x N f32 slab)
     const long t8 = (long)ceil_div(M, 256) * ceil_div(N, 256);
@@ -1029,9 +617,7 @@ extern "C" int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_k
         const double score = (double)items / (double)(rounds * tgt) - 0.012 * (sp - 1);
         if (score > best_score + 1e-9) { best_score = score; best = sp; }
     }
-    if (q8_env() != 0 && t8 * best >= q8_min_items()) return best;
-    if (!p8_selected(M, N, K, a_kc, b_kc, dtype, best)) return (int)s_old;
-    return best;
+    return t8 * best >= q8_min_items() ? best : (int)s_old;
 }
 
 // Workspace of ecamp_gemm(..., split_k, splitk_ws, ...): split_k stacked M x N f32 slabs (0 when split_k <= 1).  The split count is
@@ -1115,7 +701,7 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     {
         const int q8m = q8_env();
         const long items8 = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
-        if (q8m != 0 && (q8m == 2 || items8 >= q8_min_items()) &&
+        if (q8m != 0 && (q8m == 2 || items8 >= q8_min_items()) && (a_kc || b_kc || g_p8_wgrad) &&
             q8_legal(A, B, C, M, N, K, a_kc, lda, b_kc, ldb, ldc, bias, residual, ldr, pre_out, ldp, gmul, ldg, act, dtype, g.out_f32, split_k, splitk_ws, rowsum)) {
             const int epi = q8_epi(bias, residual, pre_out, gmul, act, g.out_f32);
             q8_fn fn = q8_pick(a_kc, b_kc, epi, rowsum != nullptr);
@@ -1137,52 +723,6 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
             if (prof8) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream);
             hipLaunchKernelGGL(fn, dim3((unsigned)(total8 < ncu ? total8 : ncu)), dim3(512), shm, stream, g);
             ++g_q8_launches;
-            if (split_k > 1) {
-                long n4 = M * N / 4;
-                int nb = (int)((n4 + 255) / 256);
-                if (nb > 2048) nb = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, splitk_ws, reinterpret_cast<float*>(C), (long)M, (long)N,
-                                   (long)ldc, split_k, alpha, alpha_dev, accumulate);
-            }
-            if (prof8) ecamp_prof_end(stream);
-            ECAMP_LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    if (p8_selected(M, N, K, a_kc, b_kc, dtype, split_k)) {
-        const int nbm8 = ceil_div(M, 256), nbn8 = ceil_div(N, 256);
-        {
-            g.nbm = nbm8; g.nbn = nbn8;
-            static const int p8_dbg = getenv("ECAMP_P8_DBG") ? atoi(getenv("ECAMP_P8_DBG")) : 0;
-            g.dbg = p8_dbg;
-            long kps8 = ((long)g.k_per_split + 31) / 32 * 32;
-            g.k_per_split = (int)kps8;
-            auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-            g.wide = (ldc % 8 == 0 || g.partial) && al16(C) && (!pre_out || (ldp % 8 == 0 && al16(pre_out))) &&
-                     (!gmul || (ldg % 8 == 0 && al16(gmul))) && (!residual || (ldr % 8 == 0 && al16(residual))) && (!bias || al16(bias)) &&
-                     (!g.partial || (N % 4 == 0 && al16(g.partial)));
-            g.nsplit = split_k;
-            int ncu = p8_num_cu();
-            // the reserve applies to the backward-only forms (weight gradient, data gradient): RCCL runs beside the backward pass
-            if (!(a_kc && b_kc) && g_p8_wgrad_reserve > 0 && ncu - g_p8_wgrad_reserve >= 64) ncu -= g_p8_wgrad_reserve;
-            const long total8 = (long)nbm8 * nbn8 * split_k;
-            dim3 grid8((unsigned)(total8 < ncu ? total8 : ncu), 1, 1);
-            const size_t shm8 = 5 * P8_STAGE_BYTES;  // the whole 160 KB LDS of a CU
-            typedef void (*p8_fn)(GemmArgs);
-            const p8_fn fn8 = rowsum ? gemm_bf16_p8_kernel<false, false, true>
-                                     : a_kc ? (b_kc ? gemm_bf16_p8_kernel<true, true, false> : gemm_bf16_p8_kernel<true, false, false>)
-                                            : (b_kc ? gemm_bf16_p8_kernel<false, true, false> : gemm_bf16_p8_kernel<false, false, false>);
-            static p8_fn attr_done[16];
-            static int n_attr = 0;
-            bool seen = false;
-            for (int i = 0; i < n_attr; ++i) seen = seen || attr_done[i] == fn8;
-            if (!seen) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8);
-                if (n_attr < 16) attr_done[n_attr++] = fn8;
-            }
-            const bool prof8 = ecamp_prof_active();
-            if (prof8) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream);
-            hipLaunchKernelGGL(fn8, grid8, dim3(512), shm8, stream, g);
             if (split_k > 1) {
                 long n4 = M * N / 4;
                 int nb = (int)((n4 + 255) / 256);

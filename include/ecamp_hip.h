@@ -75,10 +75,10 @@ int64_t ecamp_wgrad_group_launches(void);
 int64_t ecamp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int32_t split_k);
 int64_t ecamp_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq);
 int64_t ecamp_sr_bwd_workspace_bytes(void);
-/* Process-wide switches with no reference counterpart.  "p8_mode": -1 automatic kernel selection (default), 0 never / 2 always the
- * persistent 256^2 kernel (overrides ECAMP_GEMM_P8; used by the tests to exercise both kernels on every shape).  "p8_wgrad" (default 1): 0 keeps weight-gradient GEMMs off the persistent
- * one-workgroup-per-CU kernel.  "p8_wgrad_reserve_cus" (default 0): launch that kernel with this many fewer workgroups than CUs --
- * set by the data-parallel wrapper, whose all-reduce kernels share the CUs during backward. */
+/* Process-wide switches with no reference counterpart (the "p8_" prefix is historical: the persistent one-workgroup-per-CU GEMM).
+ * "p8_wgrad" (default 1): 0 keeps weight-gradient GEMMs off the persistent kernel.  "p8_wgrad_reserve_cus" (default 0): launch the
+ * backward-pass forms of that kernel with this many fewer workgroups than CUs -- set by the data-parallel wrapper, whose all-reduce
+ * kernels share the CUs during backward. */
 int ecamp_set_option(const char* name, int32_t value);
 /* "q8_mode" (ecamp_set_option): -1 automatic (default), 0 never, 2 whenever its alignment / size conditions hold -- the
  * persistent 256x256x64 kernel (csrc/gemm_q8.h) that serves the forward, data-gradient and weight-gradient forms.

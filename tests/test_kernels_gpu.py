@@ -691,30 +691,9 @@ def test_attention_long_sequence_bf16(dev, B, H, Tq, Tk, hd, masked):
 
 # ------------------------------------------------------------------------------------------------ persistent 256^2 GEMM kernel
 @pytest.fixture
-def p8_always():
-    """Force the persistent 256x256-tile kernel for every bf16 GEMM (the automatic rule only picks it from ~192 tiles up)."""
-    o = ops()
-    o.set_option("p8_mode", 2)
-    yield o
-    o.set_option("p8_mode", -1)
-
-
-@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 2304, 768), (512, 128, 3072), (256, 30000, 768), (37 * 4, 512, 64), (1000, 1004, 40)])
-def test_gemm_persistent_kernel_fwd_epilogues_ragged(dev, p8_always, M, N, K):
-    """Same checks as test_gemm_fwd_epilogues, on the persistent kernel: ragged M (not a multiple of 256), N not a multiple of 8
-    (4-column epilogue path), K not a multiple of the 32-wide K tile, one or many tiles per workgroup."""
-    test_gemm_fwd_epilogues(dev, torch.bfloat16, M, N, K)
-
-
-@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 3072, 768), (256, 30000, 768), (1000, 520, 264)])
-def test_gemm_persistent_kernel_dgrad_wgrad_ragged(dev, p8_always, M, N, K):
-    test_gemm_dgrad_wgrad(dev, torch.bfloat16, M, N, K)
-
-
-@pytest.fixture
 def q8_always():
     """Route every bf16 GEMM that meets its alignment / size conditions to the round-2 persistent kernel (gemm_q8.h); the automatic
-    rule only picks it from ~192 tiles of 256x256 up."""
+    rule only picks it from 128 tiles of 256x256 up."""
     o = ops()
     o.set_option("q8_mode", 2)
     yield o
@@ -755,17 +734,15 @@ def test_gemm_full_size_kernels_agree(dev):
     b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
     dy = torch.randn(M, N, generator=torch.Generator().manual_seed(4)).to(dev, torch.bfloat16)
     res = {}
-    for mode in (0, 2, 8):   # 128^2 kernel, round-1 persistent kernel, round-2 persistent kernel (Q8)
-        o.set_option("p8_mode", 2 if mode == 2 else 0)
+    for mode in (0, 8):   # 128^2 kernel, persistent 256^2 kernel (Q8)
         o.set_option("q8_mode", 2 if mode == 8 else 0)
         y, pre = o.linear_fwd(x, w, b, act=1, save_pre=True)
         dx = o.linear_dgrad(dy, w)
         gw, gb = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
         o.linear_wgrad(dy, x, gw, gb=gb)
         res[mode] = (y.float(), pre.float(), dx.float(), gw, gb)
-    o.set_option("p8_mode", -1)
     o.set_option("q8_mode", -1)
-    for other, label in ((2, "P8"), (8, "Q8")):
+    for other, label in ((8, "Q8"),):
         for name, a, c, tol in zip(("y", "pre", "dx", "gw", "gb"), res[0], res[other], (1e-2, 1e-2, 1e-2, 2e-3, 2e-3)):
             err = float((a - c).abs().max() / c.abs().max())
             print("  full-size %-3s 128^2 vs %s rel %.3e" % (name, label, err))

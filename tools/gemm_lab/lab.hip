@@ -1,5 +1,5 @@
 // Development lab for the persistent 8-phase GEMM (ecamp_amd/csrc/gemm_q8.h): a torch-free binary that compiles the SAME kernel
-// header as the product, checks it against the product's 128^2 kernel (ecamp_gemm with p8_mode = 0) and times variants.
+// header as the product, checks it against the product's 128^2 kernel (ecamp_gemm with q8_mode = 0) and times variants.
 //   make -C tools/gemm_lab        (cross-compiles here)          gpurun -- tools/gemm_lab/lab [shape-substr ...]
 #include "../../ecamp_amd/csrc/gemm_q8.h"
 #include "../../include/ecamp_hip.h"
@@ -86,8 +86,8 @@ static void launch_q8(const Run& r, int nslot, int dbg, int grid_override, hipSt
     hipLaunchKernelGGL(fn, grid, dim3(512), shm, s, g);
 }
 
-static int launch_ref(const Run& r, int p8, hipStream_t s) {
-    ecamp_set_option("p8_mode", p8);
+static int launch_ref(const Run& r, int /*unused*/, hipStream_t s) {   // the product's 128^2 kernel
+    ecamp_set_option("q8_mode", 0);
     return ecamp_gemm(r.A, r.B, r.C, r.M, r.N, r.K, r.a_kc, r.lda, r.b_kc, r.ldb, r.ldc, r.bias, r.residual, r.N, r.pre, r.N, r.gmul, r.N, r.act, 1.0f,
                       nullptr, ECAMP_BF16, r.out_f32, r.accumulate, r.split, r.ws, nullptr, (ecampStream_t)s);
 }
@@ -159,10 +159,8 @@ int main(int argc, char** argv) {
             CK(hipMemset(y1, 0xff, (size_t)M * N * 2));
             if (launch_ref(r, 0, s)) { printf("ref failed: %s\n", ecamp_last_error()); return 1; }
             float t_ref = quick ? 0.f : time_us([&] { launch_ref(r, 0, s); });
-            float t_p8 = quick ? 0.f : time_us([&] { launch_ref(r, 2, s); });
             launch_ref(r, 0, s);
             printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f\n", sh.name, "fwd", M, N, K, "128^2 (r1)", t_ref, fl / t_ref / 1e6);
-            printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f\n", sh.name, "fwd", M, N, K, "P8 (r1)", t_p8, fl / t_p8 / 1e6);
             for (int ns : nslots)
                 for (int dbg : dbgs) {
                     CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s));
@@ -195,10 +193,8 @@ int main(int argc, char** argv) {
             Run q = r; q.C = dx1;
             if (launch_ref(r, 0, s)) { printf("ref failed: %s\n", ecamp_last_error()); return 1; }
             float t_ref = quick ? 0.f : time_us([&] { launch_ref(r, 0, s); });
-            float t_p8 = quick ? 0.f : time_us([&] { launch_ref(r, 2, s); });
             launch_ref(r, 0, s);
             printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f\n", sh.name, "dgrad", M, K, N, "128^2 (r1)", t_ref, fl / t_ref / 1e6);
-            printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f\n", sh.name, "dgrad", M, K, N, "P8 (r1)", t_p8, fl / t_p8 / 1e6);
             for (int ns : nslots) {
                 CK(hipMemsetAsync(dx1, 0xff, (size_t)M * K * 2, s));
                 launch_q8(q, ns, 0, grid_override, s);
@@ -216,9 +212,7 @@ int main(int argc, char** argv) {
             Run r = {N, K, M, 0, 0, N, K, K, dy, x, gw0, nullptr, nullptr, 0, nullptr, nullptr, 1, 0, split, ws};
             Run q = r; q.C = gw1;
             if (launch_ref(r, 0, s)) { printf("ref failed: %s\n", ecamp_last_error()); return 1; }
-            float t_p8 = quick ? 0.f : time_us([&] { launch_ref(r, 2, s); });
             launch_ref(r, 0, s);
-            printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f   split %d (incl. reduce)\n", sh.name, "wgrad", N, K, M, "P8 (r1)", t_p8, fl / t_p8 / 1e6, split);
             for (int ns : nslots) {
                 Run q1 = q; q1.split = 1;     // unsplit: direct f32 store, comparable with the reference
                 CK(hipMemsetAsync(gw1, 0xff, (size_t)N * K * 4, s));

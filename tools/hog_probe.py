@@ -39,7 +39,7 @@ def run(n, hog_streams, blocks=1, threads=64):
     torch.cuda.synchronize()
     return dt
 nh = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-print("P8 env:", os.environ.get("ECAMP_GEMM_P8", "auto"), "p8_wgrad:", os.environ.get("P8_WGRAD", "1"), "reserve:", os.environ.get("P8_RESERVE", "0"))
+print("p8_wgrad:", os.environ.get("P8_WGRAD", "1"), "reserve:", os.environ.get("P8_RESERVE", "0"))
 print("no hog      : %.2f ms/step" % run(5, []))
 s1 = torch.cuda.Stream()
 print("1 x 1 wave        : %.2f ms/step" % run(5, [s1]))
