@@ -812,6 +812,7 @@ static std::map<std::string, WgPlan> g_wg_plans;
 static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, const unsigned* has_bias, int64_t rows, int ncu) {
     std::string key((const char*)n_out, n * sizeof(int64_t));
     key.append((const char*)k_in, n * sizeof(int64_t)).append((const char*)has_bias, n * sizeof(unsigned)).append((const char*)&rows, 8).append((const char*)&ncu, 4);
+    key.append((const char*)&g_p8_wgrad_reserve, sizeof(int));   // the reserve caps the piece count
     auto it = g_wg_plans.find(key);
     if (it != g_wg_plans.end()) return &it->second;
     const long KT = (rows + 63) / 64;
@@ -825,9 +826,11 @@ static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, c
     // ECAMP_WGRAD_PLAN=0: the round-2 dealing (K tiles of all tiles dealt out evenly in tile order; ranges run across tile boundaries)
     static const int plan_mode = getenv("ECAMP_WGRAD_PLAN") ? atoi(getenv("ECAMP_WGRAD_PLAN")) : 1;
     const long T = (long)tiles.size();
+    int cap = p8_num_cu();                            // workgroups the launch may use: every CU, minus the data-parallel reserve
+    if (g_p8_wgrad_reserve > 0 && cap - g_p8_wgrad_reserve >= 64) cap -= g_p8_wgrad_reserve;
     long S = (ncu + T / 2) / T;                       // K segments per tile: one (tile, segment) piece per workgroup
-    while (S > 1 && (T * S > p8_num_cu() || KT / S < 4)) --S;
-    if (plan_mode == 1 && S >= 1 && T * S >= ncu / 2 && T * S <= p8_num_cu()) {
+    while (S > 1 && (T * S > cap || KT / S < 4)) --S;
+    if (plan_mode == 1 && S >= 1 && T * S >= ncu / 2 && T * S <= cap) {
         // Segment-major plan: every output tile is cut into the same S contiguous K segments and each workgroup owns ONE piece.  The
         // pieces are ordered (segment, tile) and workgroup w -- which the hardware places on XCD w % 8 -- takes piece
         // (w % 8) * P/8 + w / 8: the ~P/8 workgroups of an XCD start together on neighbouring tiles of the SAME K segment, walk the

@@ -99,12 +99,14 @@ def linear_dgrad(dy, w, gmul=None, alpha=1.0, alpha_dev=None, residual=None):
 
 
 _SPLIT_CACHE = {}
+_WG_TABLES = {}   # (device, shapes, has_bias, rows, workgroups) -> device image of a weight-gradient group's item table (uploaded once, kept)
 
 
 def set_option(name, value):
     """ecamp_set_option + invalidation of the split-count cache (the suggested split depends on the kernel selection)."""
     call("ecamp_set_option", name.encode(), int(value))
     _SPLIT_CACHE.clear()
+    _WG_TABLES.clear()     # the grouped weight gradients' item tables depend on the CU reserve
 
 
 def _split_k(n_out, k_in, m, dtype=torch.bfloat16):
@@ -142,9 +144,6 @@ def wgrad_group_supported(items):
     no = (ctypes.c_int64 * n)(*[it[0].shape[1] for it in items])
     ki = (ctypes.c_int64 * n)(*[it[1].shape[1] for it in items])
     return bool(_lib.load().ecamp_wgrad_group_supported(n, ctypes.cast(no, ctypes.c_void_p), ctypes.cast(ki, ctypes.c_void_p), rows))
-
-
-_WG_TABLES = {}   # (device, shapes, has_bias, rows, workgroups) -> device image of the group's item table (uploaded once, kept)
 
 
 def _wgrad_group_table(dev, n, no, ki, hb, rows, workgroups):

@@ -82,3 +82,51 @@ def test_gemm_planning_helpers_are_pure_host_arithmetic(lib):
     assert lib.ecamp_set_option(b"p8_wgrad", 0) == 0 and lib.ecamp_set_option(b"p8_wgrad", 1) == 0
     assert lib.ecamp_set_option(b"no_such_option", 1) < 0 and b"unknown option" in lib.ecamp_last_error()
     assert lib.ecamp_set_option(None, 1) < 0
+
+
+def test_wgrad_group_item_table_covers_every_k_tile_once(lib):
+    """ecamp_wgrad_group_table is pure host arithmetic: for the four linear layers of a ViT-B encoder block (12800 rows) and of a
+    BERT layer (32768 rows) every (output tile, K tile) unit is covered by exactly one piece, each workgroup owns one piece, a tile's
+    slabs are consecutive, the workgroups of one XCD (w mod 8) hold neighbouring tiles of one K segment, and the data-parallel CU
+    reserve caps the piece count."""
+    import numpy as np
+    import torch
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    for rows, shapes in ((12800, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (32768, [(768, 1536), (1536, 768), (768, 768), (2304, 768)])):
+        for reserve in (0, 32):
+            assert lib.ecamp_set_option(b"p8_wgrad_reserve_cus", reserve) == 0
+            n = len(shapes)
+            no = (ctypes.c_int64 * n)(*[s[0] for s in shapes])
+            ki = (ctypes.c_int64 * n)(*[s[1] for s in shapes])
+            hb = (ctypes.c_int32 * n)(*([1] * n))
+            assert lib.ecamp_wgrad_group_supported(n, cv(no), cv(ki), rows) == 1
+            cap = lib.ecamp_wgrad_group_table_bytes(n, cv(no), cv(ki), rows)
+            host = torch.zeros((cap,), dtype=torch.uint8)
+            used = lib.ecamp_wgrad_group_table(n, cv(no), cv(ki), cv(hb), rows, 0, ctypes.c_void_p(host.data_ptr()))
+            assert 0 < used <= cap
+            T = sum(((a + 255) // 256) * ((b + 255) // 256) for a, b in shapes)
+            P = next(p for p in range(1, 1025) if 32 * p + (4 * (p + 1) + 31) // 32 * 32 + 20 * T == used)   # one piece per workgroup
+            assert P <= 256 - reserve and P >= 96
+            raw = host.numpy()
+            items = raw[:32 * P].view(np.int32).reshape(P, 8)
+            first = raw[32 * P:32 * P + 4 * (P + 1)].view(np.int32)
+            off_t = 32 * P + (4 * (P + 1) + 31) // 32 * 32
+            tiles = raw[off_t:off_t + 20 * T].view(np.int32).reshape(T, 5)
+            assert (first == np.arange(P + 1)).all()
+            KT = rows // 64
+            cover = {}
+            for prob, m0, n0, kbeg, kend, slab, flags, _ in items:
+                assert 0 <= prob < n and m0 % 256 == 0 and n0 % 256 == 0 and kbeg % 64 == 0 and kend - kbeg >= 128
+                assert flags == (1 if n0 == 0 else 0)
+                for k in range(kbeg // 64, (kend + 63) // 64):
+                    key = (int(prob), int(m0), int(n0), k)
+                    assert key not in cover
+                    cover[key] = int(slab)
+            assert len(cover) == T * KT
+            for prob, m0, n0, f, c in tiles:
+                slabs = sorted({cover[(int(prob), int(m0), int(n0), k)] for k in range(KT)})
+                assert slabs == list(range(int(f), int(f) + int(c)))
+            # XCD locality: the pieces of workgroups w = x, x + 8, x + 16, ... start at no more than two distinct K offsets
+            for x in range(8):
+                assert len({int(items[w][3]) for w in range(x, P, 8)}) <= 2
+    assert lib.ecamp_set_option(b"p8_wgrad_reserve_cus", 0) == 0
