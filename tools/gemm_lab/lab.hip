@@ -92,6 +92,23 @@ static int launch_ref(const Run& r, int /*unused*/, hipStream_t s) {   // the pr
                       nullptr, ECAMP_BF16, r.out_f32, r.accumulate, r.split, r.ws, nullptr, (ecampStream_t)s);
 }
 
+// order-independent checksum of a device buffer (race screen: a deterministic kernel must reproduce it bit for bit)
+__global__ void checksum_kernel(const unsigned* __restrict__ x, size_t n, unsigned long long* out) {
+    unsigned long long a = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += (unsigned long long)x[i] * (2 * (i & 1023) + 1);
+    atomicAdd(out, a);
+}
+static unsigned long long checksum(const void* p, size_t bytes, hipStream_t s) {
+    static unsigned long long* d = nullptr;
+    if (!d) CK(hipMalloc(&d, 8));
+    CK(hipMemsetAsync(d, 0, 8, s));
+    hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, s, (const unsigned*)p, bytes / 4, d);
+    unsigned long long h = 0;
+    CK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    return h;
+}
+
 template <typename F> static float time_us(F f, int n = 20) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); f(); CK(hipDeviceSynchronize());
@@ -126,8 +143,10 @@ int main(int argc, char** argv) {
     bool quick = false;
     std::vector<int> dbgs = {0};
     std::vector<int> nslots = {4};
-    int grid_override = 0;
+    int grid_override = 0, stress = 0, hog = 0;   // --hog: a small spinning kernel on a second stream beside every launch (uneven load)
     for (int i = 1; i < argc; ++i) {
+        if (!strncmp(argv[i], "--stress=", 9)) { stress = atoi(argv[i] + 9); continue; }
+        if (!strcmp(argv[i], "--hog")) { hog = 1; continue; }
         if (!strncmp(argv[i], "--forms=", 8)) forms = atoi(argv[i] + 8);
         else if (!strcmp(argv[i], "--quick")) quick = true;
         else if (!strncmp(argv[i], "--grid=", 7)) grid_override = atoi(argv[i] + 7);
@@ -152,6 +171,30 @@ int main(int argc, char** argv) {
         fill_bf16(x, (size_t)M * K, 1.0f); fill_bf16(w, (size_t)N * K, 1.0f / sqrtf((float)K)); fill_bf16(dy, (size_t)M * N, 1.0f);
         { std::vector<float> hb(N); for (auto& v : hb) v = frand(); CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice)); }
         const double fl = 2.0 * M * N * K;
+        if (stress > 0) {
+            // race screen: the forward (GELU + pre), data-gradient and unsplit weight-gradient kernels are deterministic (no atomics):
+            // every repetition must reproduce the first run's outputs bit for bit, whatever the DMA / barrier timing was
+            Run rf = {M, N, K, 1, 1, K, K, N, x, w, y1, bias, pre1, 1, nullptr, nullptr, 0, 0, 1, nullptr};
+            Run rd = {M, K, N, 1, 0, N, K, K, dy, w, dx1, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 1, nullptr};
+            Run rw = {N, K, M, 0, 0, N, K, K, dy, x, gw1, nullptr, nullptr, 0, nullptr, nullptr, 1, 0, 1, nullptr};
+            unsigned long long h0[4] = {0, 0, 0, 0};
+            int bad = 0;
+            hipStream_t s2; CK(hipStreamCreate(&s2));
+            for (int it = 0; it < stress; ++it) {
+                if (hog) ecamp_dev_spin(16 + 8 * (it % 13), 64, 20000 + 7000 * (it % 7), (ecampStream_t)s2);   // a different set of CUs held for 10-30 us each time
+                CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(pre1, 0xff, (size_t)M * N * 2, s));
+                CK(hipMemsetAsync(dx1, 0xff, (size_t)M * K * 2, s)); CK(hipMemsetAsync(gw1, 0xff, (size_t)N * K * 4, s));
+                launch_q8(rf, 4, 0, grid_override, s); launch_q8(rd, 4, 0, grid_override, s); launch_q8(rw, 4, 0, grid_override, s);
+                const unsigned long long h[4] = {checksum(y1, (size_t)M * N * 2, s), checksum(pre1, (size_t)M * N * 2, s), checksum(dx1, (size_t)M * K * 2, s),
+                                                 checksum(gw1, (size_t)N * K * 4, s)};
+                for (int j = 0; j < 4; ++j) { if (it == 0) h0[j] = h[j]; else if (h[j] != h0[j]) { ++bad; printf("  %s: repetition %d output %d differs\n", sh.name, it, j); } }
+            }
+            CK(hipStreamSynchronize(s2)); CK(hipStreamDestroy(s2));
+            printf("%-11s stress %d repetitions of fwd / dgrad / wgrad%s: %s\n", sh.name, stress, hog ? " beside a spinning co-tenant" : "", bad ? "MISMATCH" : "all bit-identical");
+            hipFree(x); hipFree(w); hipFree(dy); hipFree(y0); hipFree(y1); hipFree(pre0); hipFree(pre1); hipFree(dx0); hipFree(dx1);
+            hipFree(bias); hipFree(gw0); hipFree(gw1);
+            continue;
+        }
         // ---- forward  Y = gelu(X W^T + b), pre saved
         if (forms & 1) {
             Run r = {M, N, K, 1, 1, K, K, N, x, w, y0, bias, pre0, 1, nullptr, nullptr, 0, 0, 1, nullptr};
