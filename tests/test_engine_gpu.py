@@ -38,6 +38,19 @@ def test_main_pretrain_tiny_three_epochs(dev, tmp_path):
     assert os.path.exists(os.path.join(tmp_path, "config.yaml"))
 
 
+def test_main_pretrain_with_uint8_images(dev, tmp_path):
+    """`--image_u8`: the synthetic dataset hands over uint8 grayscale crops, the DataLoader / pinned memory / prefetcher carry one byte
+    per pixel, and the epoch trains like the f32 schema (finite, falling losses)."""
+    from ecamp_amd import main_pretrain
+    args = _args(tmp_path, ["--image_u8", "--epochs", "2"])
+    main_pretrain.main(args)
+    lines = open(os.path.join(tmp_path, "log.txt")).read().strip().split("\n")
+    stats = [json.loads(l) for l in lines[1:]]
+    assert [s["epoch"] for s in stats] == [0, 1]
+    assert all(s[k] == s[k] for s in stats for k in ("train_mim_loss", "train_res_loss", "train_mlm_loss"))
+    assert stats[-1]["train_mlm_loss"] < stats[0]["train_mlm_loss"]
+
+
 def test_checkpoint_round_trip_and_torch_adamw_compat(dev, tmp_path):
     from ecamp_amd import optim
     from ecamp_amd.data import synthetic_batch
