@@ -9,8 +9,8 @@ head + reference BERT (6L/6H/1536, vocab 30000) with context fusion, B=256 pairs
 images resized on device), reports of S=128 tokens, bf16 activations / f32 master weights, train mode (dropout
 active), host->HBM copy of the batch + forward + backward + grad all-reduce (N>1) + grad-norm + fused AdamW + zero_grad
 (accum_iter=1).  The batch starts in pinned HOST memory (what a DataLoader with pin_memory hands over) and crosses PCIe inside
-the timed region on a copy stream, beside the previous step's kernels (ecamp_amd.data.DevicePrefetcher; the pipeline runs through
-warm-up and timed steps alike, each timed step issues and consumes its own batch copy): `value` is the PCIe-inclusive rate;
+the timed region on a copy stream, two steps ahead of its use (ecamp_amd.data.DevicePrefetcher; the pipeline runs through warm-up and
+timed steps alike: each timed step issues one batch copy and consumes one issued two steps earlier): `value` is the PCIe-inclusive rate;
 `resident_pairs_per_s` (inputs already in HBM), forward-only and forward+backward-only rates are reported beside it.
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment launches its own N ranks (one child process per GPU,
@@ -244,10 +244,10 @@ def main():
             dist.barrier()
         return time.perf_counter() - t0
 
-    # ONE prefetch pipeline across warm-up and timed steps, as in a training run: asking it for batch i (after step i-1 has been
-    # queued) issues the copy of batch i on the copy stream, where it runs beside the GPU's step i-1.  Each of the K timed steps
-    # carries exactly its own host->HBM batch copy; the first one has no earlier step to hide behind (the clock starts on an idle GPU).
-    pipeline = iter(DevicePrefetcher([host_batch] * (args.warmup + args.steps), dev))
+    # ONE prefetch pipeline across warm-up and timed steps, as in a training run: asking it for a batch (after the previous step has
+    # been queued) issues the host->HBM copy of the batch two steps ahead on the copy stream, where it runs beside the GPU's current
+    # work.  Each of the K timed steps issues exactly one batch copy and consumes one issued two steps earlier (steady state).
+    pipeline = iter(DevicePrefetcher([host_batch] * (args.warmup + args.steps + 2), dev))
 
     def run_inclusive(n):
         nonlocal out
@@ -342,8 +342,8 @@ def main():
                           "image": "448^2 -> 224^2 encoder input" + (", uint8 grayscale crops normalised on the device" if args.image_u8 else ""),
                           "seq_len": args.seq, "mask_ratio": 0.75, "accum_iter": 1, "parallelism": "dp%d" % world,
                           "last_losses_mim_res_mlm": [round(x, 5) for x in losses]},
-               "input": "pinned host memory -> HBM inside the timed region: every timed step issues the copy of the next batch on a copy "
-                        "stream (steady-state pipeline, primed by the warm-up steps)",
+               "input": "pinned host memory -> HBM inside the timed region: every timed step issues the copy of the batch two steps ahead on a "
+                        "copy stream (steady-state pipeline, primed by the warm-up steps)",
                "resident_pairs_per_s": round(args.batch * world / dt_res, 2), "resident_ms_per_step": round(1e3 * dt_res, 3),
                "fwd_only_ms": round(1e3 * dt_fwd, 3), "fwd_only_pairs_per_s": round(args.batch * world / dt_fwd, 2),
                "fwd_bwd_ms": round(1e3 * dt_fb, 3), "fwd_bwd_pairs_per_s": round(args.batch * world / dt_fb, 2)}

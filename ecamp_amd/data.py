@@ -75,7 +75,8 @@ class DevicePrefetcher:
     def __len__(self):
         return len(self.loader)
 
-    NBUF = 3   # staging slots: batch i+1 is copied while step i computes; a slot is overwritten two steps after its batch was consumed
+    NBUF = 3    # staging slots: the batch being consumed + AHEAD staged ones
+    AHEAD = 2   # batches staged in front of the consumer
 
     def __iter__(self):
         dev = self.device
@@ -115,23 +116,27 @@ class DevicePrefetcher:
             cur = stage(next(it), 0)
         except StopIteration:
             return
-        i = 0
+        ahead, i, nstaged = [], 0, 1     # batches staged beyond `cur` (at most AHEAD), index of `cur`, batches staged so far
         try:
             while cur is not None:
                 batch, ev = cur
                 torch.cuda.current_stream(dev).wait_event(ev)
                 yield batch
                 # Resumed: the consumer has queued the whole of step i on the compute stream and asks for batch i+1.  Only now is
-                # the loader asked for it (the launch of step i never waits for the loader or for pin_memory()); its copy still runs
-                # beside the GPU's step i, which the host is ahead of.
+                # the loader asked for more (the launch of a step never waits for the loader or for pin_memory()).  Staging runs
+                # AHEAD batches in front of the consumer, so the copy of batch i+1 was issued a step ago and ran beside the GPU's
+                # step i-1 .. i: the compute stream's wait above finds it finished.
                 done[i % self.NBUF] = torch.cuda.Event()
                 done[i % self.NBUF].record(torch.cuda.current_stream(dev))
-                try:
-                    cur = stage(next(it), (i + 1) % self.NBUF)
-                except StopIteration:
-                    cur = None
+                while len(ahead) < self.AHEAD:
+                    try:
+                        ahead.append(stage(next(it), nstaged % self.NBUF))   # the slot of batch nstaged - NBUF, consumed by a step whose `done` is recorded
+                        nstaged += 1
+                    except StopIteration:
+                        break
+                cur = ahead.pop(0) if ahead else None
                 i += 1
         finally:
-            # an abandoned iterator (exception, early break) may leave a copy in flight into a slot: the slots go back to the compute
+            # an abandoned iterator (exception, early break) may leave copies in flight into slots: the slots go back to the compute
             # stream's allocator pool when this frame dies, so that stream must not touch them before the copy stream is done
             torch.cuda.current_stream(dev).wait_stream(side)
