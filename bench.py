@@ -268,7 +268,9 @@ def main():
         red = net.reducer
         rccl = {"world": world, "backend": dist.get_backend(), "buckets": len(red.buckets), "bucket_mb": round(max(hi - lo for lo, hi, _ in red.buckets) * 4 / 2 ** 20, 1),
                 "payload_mb_per_step": round(red.flat_g.numel() * 4 / 2 ** 20, 1), "op": "AVG" if red.use_avg else "SUM+div",
+                "tail_bucket_mb": round((red.buckets[-1][1] - red.buckets[-1][0]) * 4 / 2 ** 20, 1),
                 "p8_wgrad_reserve_cus": int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")),
+                "q8_bwd_grid": int(os.environ.get("ECAMP_DDP_Q8_BWD_GRID", str(1 << 20))),
                 "allreduce_ms_per_step": round(red.comm_ms() / args.steps, 3),
                 "note": "all-reduce of the f32 gradient arena in buckets on a side HIP stream, overlapped with backward; ms = sum of the "
                         "buckets' event-bracketed durations on that stream on rank 0 (they overlap compute, so this is not added step time)"}

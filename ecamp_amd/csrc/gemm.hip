@@ -521,6 +521,13 @@ static int p8_num_cu() {
 // persistent workgroup.  The data-parallel wrapper sets the reserve; the forward pass has no communication beside it.
 static int g_p8_wgrad = 1;
 static int g_p8_wgrad_reserve = 0;
+// "q8_bwd_grid" = n > 0 launches the DATA-GRADIENT form on min(items, n) workgroups instead of one per CU; n >= items gives one
+// output tile per workgroup, i.e. the hardware dispatcher hands tiles to whichever CU is free.  That is what the data-parallel
+// wrapper asks for: beside RCCL's all-reduce workgroups a persistent workgroup whose CU is taken starts late and holds its whole
+// static share of the tiles back, while one-tile workgroups simply flow around the occupied CUs.  Measured cost on a GPU of its
+// own (tools/grid_ab.sh): +0.15 ms per step for the data-gradient form (+0.4 ms if the forward form did the same, which it does not
+// need: nothing communicates during forward) -- the cross-tile DMA prefetch of the persistent loop is worth that much and no more.
+static int g_q8_bwd_grid = 0;
 
 // ---- Q8 (gemm_q8.h): the persistent 256x256x64 kernel.  ECAMP_GEMM_Q8 / option "q8_mode": -1 automatic (default), 0 never, 2 whenever legal.
 static int g_q8_mode = -2;
@@ -576,6 +583,7 @@ extern "C" int ecamp_set_option(const char* name, int32_t value) {
     if (strcmp(name, "q8_mode") == 0) { g_q8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 whenever legal
     if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
+    if (strcmp(name, "q8_bwd_grid") == 0) { g_q8_bwd_grid = value < 0 ? 0 : value; return 0; }
     if (strcmp(name, "attn_head") == 0) { attn_set_head_mode(value); return 0; }   // attention_bf16.hip: 1 head kernels (default), 0 streaming kernels
     return ecamp_set_error(-1, "set_option: unknown option '%s'", name);
 }
@@ -721,6 +729,11 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
             }
             const bool prof8 = ecamp_prof_active();
             if (prof8) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream);
+            {   // data-gradient form beside a co-tenant (see g_q8_bwd_grid): the hardware dispatcher deals the items
+                static const int env_bwd = getenv("ECAMP_Q8_BWD_GRID") ? atoi(getenv("ECAMP_Q8_BWD_GRID")) : 0;
+                const int bg = g_q8_bwd_grid > 0 ? g_q8_bwd_grid : env_bwd;
+                if (a_kc && !b_kc && bg > 0) ncu = bg;
+            }
             hipLaunchKernelGGL(fn, dim3((unsigned)(total8 < ncu ? total8 : ncu)), dim3(512), shm, stream, g);
             ++g_q8_launches;
             if (split_k > 1) {

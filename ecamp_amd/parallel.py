@@ -7,8 +7,9 @@ registration order == the order backward finishes them; the hand-written backwar
 parameters (`arena.ready`), and a bucket whose parameters are all done is all-reduced IN PLACE (zero-copy slice
 of the arena, op=AVG) on a side HIP stream while the remaining backward keeps the compute stream busy.  Unused
 parameters are known statically and never waited for; accumulation micro-steps skip communication.
-xGMI is point-to-point (7 links x ~153 GB/s): few large buckets (default 64 MiB) keep RCCL's rings/trees per-link
-efficient; the whole exchange is ~1-8 ms against >= 25 ms of backward at B=256.
+xGMI is point-to-point (7 links x ~153 GB/s): large buckets (default 32 MiB, 8 MiB for the parameters backward finishes last)
+keep RCCL's rings/trees per-link efficient; the whole exchange is ~2.5 ms (8 GPUs) to ~14 ms (2 GPUs, one link) of link time
+against 22 ms of backward at B=256, of which the first gradients are final after 2.6 ms (tools/bucket_timeline.py).
 """
 import contextlib
 import os
@@ -19,21 +20,33 @@ import torch.nn as nn
 
 
 class GradReducer:
-    def __init__(self, flat_g, offsets, sizes, unused=(), bucket_mb=64.0, group=None, force_comm=False):
+    def __init__(self, flat_g, offsets, sizes, unused=(), bucket_mb=32.0, group=None, force_comm=False, tail_bucket_mb=None,
+                 tail_span_mb=32.0):
         self.flat_g, self.offsets, self.sizes = flat_g, list(offsets), list(sizes)
         self.unused = set(unused)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.enabled = True
         self.force_comm = force_comm  # run the collectives even in a 1-rank group (exercises the RCCL / stream plumbing in tests)
-        cap = int(bucket_mb * 1024 * 1024) // flat_g.element_size()
+        # Bucket sizes follow the backward timeline (tools/bucket_timeline.py): a bucket is closed BEFORE a tensor that would
+        # take it past the cap (the 92 MB vocabulary-head weight, final 2.6 ms into backward, must not wait for the small fusion
+        # parameters registered after it, final at 11 ms), and the parameters registered FIRST -- the ones backward finishes
+        # last, whose exchange nothing can hide -- go in small buckets (`tail_bucket_mb` over the first `tail_span_mb` of the
+        # arena), so that the exposed tail of the exchange is one small message.
+        esz = flat_g.element_size()
+        cap = max(1, int(bucket_mb * 1024 * 1024) // esz)
+        tail_cap = cap if tail_bucket_mb is None else max(1, min(cap, int(tail_bucket_mb * 1024 * 1024) // esz))
+        tail_span = 0 if tail_bucket_mb is None else int(tail_span_mb * 1024 * 1024) // esz
         n = len(self.offsets)
-        ends = [self.offsets[i + 1] if i + 1 < n else flat_g.numel() for i in range(n)]
         self.buckets = []  # (lo, hi, [slots]) in the order backward completes them (last registered first)
         hi, slots = flat_g.numel(), []
         for i in range(n - 1, -1, -1):
+            c = tail_cap if self.offsets[i] < tail_span else cap
+            if slots and hi - self.offsets[i] > c:
+                self.buckets.append((self.offsets[i + 1], hi, slots))
+                hi, slots = self.offsets[i + 1], []
             slots.append(i)
-            if hi - self.offsets[i] >= cap or i == 0:
+            if hi - self.offsets[i] >= c or i == 0:
                 self.buckets.append((self.offsets[i], hi, slots))
                 hi, slots = self.offsets[i], []
         self.slot2bucket = {s: b for b, (_, _, sl) in enumerate(self.buckets) for s in sl}
@@ -163,8 +176,8 @@ class GradReducer:
 class DistributedDataParallel(nn.Module):
     """Minimal DDP surface used by main_pretrain.py (`.module`, forward passthrough, `no_sync`)."""
 
-    def __init__(self, module, device_ids=None, find_unused_parameters=False, bucket_cap_mb=64.0, process_group=None, force_comm=False,
-                 **_ignored):
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, bucket_cap_mb=32.0, process_group=None, force_comm=False,
+                 tail_bucket_mb=8.0, tail_span_mb=32.0, **_ignored):
         super().__init__()
         self.module = module
         arena = module.prepare()
@@ -177,10 +190,15 @@ class DistributedDataParallel(nn.Module):
                 dist.broadcast(arena.flat_p, src=0, group=process_group)  # C1: parameters rank0 -> all (one 733 MB message)
             arena.sync_shadow()
             # RCCL's all-reduce workgroups share the CUs with the backward pass, and a persistent one-workgroup-per-CU GEMM
-            # whose CU is taken starts that workgroup late (tools/hog_probe.py): leave 32 CUs to the communication kernels
+            # whose CU is taken starts that workgroup late and holds its static share of the tiles back (tools/hog_probe.py).
+            # The data-gradient GEMMs (the critical chain) therefore run one output tile per workgroup -- the dispatcher deals
+            # the tiles to whatever CUs are free, however many the collective takes (+0.15 ms per step on a GPU of its own,
+            # tools/grid_ab.sh) -- and the weight-gradient launches of the side stream leave 32 CUs to the communication kernels
             from . import hip_ops
             hip_ops.set_option("p8_wgrad_reserve_cus", int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")))
-        self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group, force_comm)
+            hip_ops.set_option("q8_bwd_grid", int(os.environ.get("ECAMP_DDP_Q8_BWD_GRID", str(1 << 20))))
+        self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group, force_comm,
+                                   tail_bucket_mb=tail_bucket_mb, tail_span_mb=tail_span_mb)
         arena.on_ready = self.reducer.mark_ready
         arena.reducer = self.reducer   # the loss scaler and the optimizer find it here
 

@@ -78,7 +78,10 @@ int64_t ecamp_sr_bwd_workspace_bytes(void);
 /* Process-wide switches with no reference counterpart (the "p8_" prefix is historical: the persistent one-workgroup-per-CU GEMM).
  * "p8_wgrad" (default 1): 0 keeps weight-gradient GEMMs off the persistent kernel.  "p8_wgrad_reserve_cus" (default 0): launch the
  * backward-pass forms of that kernel with this many fewer workgroups than CUs -- set by the data-parallel wrapper, whose all-reduce
- * kernels share the CUs during backward. */
+ * kernels share the CUs during backward.  "q8_bwd_grid" (default 0 = one workgroup per CU; env ECAMP_Q8_BWD_GRID): n > 0 launches the
+ * data-gradient form on min(output tiles, n) workgroups -- with n past the tile count every workgroup computes ONE tile and the
+ * hardware dispatcher deals the tiles to whichever CUs the communication kernels leave free (+0.15 ms per step alone on a GPU);
+ * set by the data-parallel wrapper as well. */
 int ecamp_set_option(const char* name, int32_t value);
 /* "q8_mode" (ecamp_set_option): -1 automatic (default), 0 never, 2 whenever its alignment / size conditions hold -- the
  * persistent 256x256x64 kernel (csrc/gemm_q8.h) that serves the forward, data-gradient and weight-gradient forms.

@@ -723,6 +723,35 @@ def test_gemm_q8_dgrad_wgrad_ragged(dev, q8_always, M, N, K):
     assert _q8_count() >= n0 + 5, "the Q8 kernel did not run"
 
 
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (1000, 520, 264), (50432, 512, 2048)])
+def test_gemm_q8_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q8_always, M, N, K):
+    """`q8_bwd_grid` (what the data-parallel wrapper sets): the data-gradient form on one workgroup per output tile, on half as many
+    workgroups as tiles and on the persistent grid computes every tile with the same instruction sequence -- the three outputs are
+    the same bits, with the gelu' / residual epilogues as well."""
+    o = q8_always
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(M, K, generator=g).to(dev, torch.bfloat16)          # dX[M, N] = dY[M, K] W[K, N]  (W stored [K, N]: strided operand)
+    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(dev, torch.bfloat16)
+    pre = torch.randn(M, N, generator=g).to(dev, torch.bfloat16)
+    res = torch.randn(M, N, generator=g).to(dev, torch.bfloat16)
+    outs = []
+    tiles = -(-M // 256) * -(-N // 256)
+    try:
+        for grid in (0, 1 << 20, max(1, tiles // 2)):
+            o.set_option("q8_bwd_grid", grid)
+            n0 = _q8_count()
+            a = o.linear_dgrad(dy, w)
+            b = o.linear_dgrad(dy, w, gmul=pre)
+            c = o.linear_dgrad(dy, w, residual=res)
+            assert _q8_count() >= n0 + 3, "the Q8 kernel did not run"
+            outs.append((a, b, c))
+    finally:
+        o.set_option("q8_bwd_grid", 0)
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
+
+
 def test_gemm_full_size_kernels_agree(dev):
     """BASELINE configs[1] sizes (timm Mlp.fc1 of the encoder at B=256: 12800 x 3072 x 768): forward with bias + GELU + saved
     pre-activation, data gradient through GELU', weight + bias gradient -- the persistent kernel against the 128^2 kernel on the

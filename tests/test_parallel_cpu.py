@@ -69,3 +69,37 @@ def test_bucketed_reducer_two_ranks_gloo():
     assert sorted(r[0] for r in res) == [0, 1]
     for r in res:
         assert all(r[1:]), r
+
+
+def test_bucket_plan_closes_before_a_large_tensor_and_keeps_the_tail_small():
+    """The bucket plan alone (no process group): buckets tile the arena without gaps, in reverse registration order; a tensor larger
+    than the cap gets a bucket of its own instead of holding the small parameters registered after it; the parameters registered
+    first (finished last by backward) sit in buckets of at most the tail cap (or one tensor)."""
+    from ecamp_amd.parallel import GradReducer
+    mib = 2 ** 20 // 4
+    sizes = [mib // 2, mib // 2, mib, mib, 3 * mib, 3 * mib, 40 * mib, mib // 4, mib // 4, 90 * mib, mib // 8, mib // 8]
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    class _Flat:   # only numel() / element_size() / is_cuda are read by the plan
+        is_cuda = False
+        def numel(self): return sum(sizes)
+        def element_size(self): return 4
+    red = GradReducer(_Flat(), offs, sizes, unused=[7], bucket_mb=32.0, tail_bucket_mb=2.0, tail_span_mb=4.0)
+    # tiling, order
+    assert red.buckets[0][1] == sum(sizes) and red.buckets[-1][0] == 0
+    for (lo, hi, sl), (lo2, hi2, sl2) in zip(red.buckets, red.buckets[1:]):
+        assert lo == hi2 and lo < hi and min(sl) > max(sl2)
+    assert sorted(s for _, _, sl in red.buckets for s in sl) == list(range(len(sizes)))
+    by_slot = {s: (lo, hi, sl) for lo, hi, sl in red.buckets for s in sl}
+    assert by_slot[9][2] == [9] and by_slot[11][2] == [11, 10]       # the 90 MiB tensor alone; the two small ones after it together
+    assert by_slot[6][2] == [6]                                      # 40 MiB > cap: alone as well
+    assert by_slot[8][2] == [8, 7]
+    # slots 0..3 start inside the first 4 MiB of the arena: tail buckets of <= 2 MiB
+    for s in (0, 1, 2, 3):
+        lo, hi, sl = by_slot[s]
+        assert hi - lo <= 2 * mib
+    assert by_slot[0][2] == [1, 0] and by_slot[2][2] == [3, 2]
+    assert by_slot[4][2] == [4] and by_slot[5][2] == [5]             # slot 4 starts inside the tail span: it does not join slot 5
+    assert red.pending == [sum(1 for s in sl if s != 7) for _, _, sl in red.buckets]
+    # the old call (no tail arguments) still gives plain capped buckets
+    red2 = GradReducer(_Flat(), offs, sizes, bucket_mb=64.0)
+    assert sum(hi - lo for lo, hi, _ in red2.buckets) == sum(sizes) and all(hi - lo <= 64 * mib or len(sl) == 1 for lo, hi, sl in red2.buckets)
