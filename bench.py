@@ -316,6 +316,7 @@ def main():
     prof_steps = 0
     if not args.no_prof:  # every rank runs it (the steps contain collectives)
         hip_ops.OVERLAP_WGRAD = False
+        branches, hip_ops.OVERLAP_BRANCHES = hip_ops.OVERLAP_BRANCHES, False   # one kernel at a time: no second stream of any kind
         step()
         torch.cuda.synchronize()
         lib.ecamp_prof_collect(-1, None, None, None)
@@ -328,6 +329,7 @@ def main():
         serial_ms = 1e3 * (time.perf_counter() - tp) / prof_steps
         lib.ecamp_prof_enable(0)
         hip_ops.OVERLAP_WGRAD = True
+        hip_ops.OVERLAP_BRANCHES = branches
     if world > 1:
         t = torch.tensor([dt, dt_res, dt_fwd, dt_fb], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -379,8 +381,9 @@ def main():
                                "attention_ms_per_step": round(ams.value / prof_steps, 3),
                                "serialized_ms_per_step": round(serial_ms, 3),
                                "note": "achieved = sum(2MNK) over every GEMM launch / sum of their HIP-event durations, taken in a "
-                                       "serialized pass of the same step (%d steps, wgrad GEMMs on the main stream); `value` is timed on the "
-                                       "production path where wgrad GEMMs overlap the dgrad chain on a side stream" % prof_steps}
+                                       "serialized pass of the same step (%d steps, wgrad GEMMs and the image-decoder branch on the main stream); `value` is timed "
+                                       "on the production path where wgrad GEMMs overlap the dgrad chain on a side stream and the image decoder runs "
+                                       "beside the report side on a branch stream" % prof_steps}
             # whole-step view with SURVEY.md 8(d)'s algorithmic FLOPs per pair
             gflop_pair = 88.99 if args.seq == 128 else 136.64
             res["roofline"]["whole_step_tflops"] = round(gflop_pair * 1e9 * args.batch / (dt / args.steps) / 1e12, 2)

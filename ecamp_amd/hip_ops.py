@@ -505,9 +505,11 @@ def _join_side():
 
 # The image decoder + pixel losses and the report side both hang off the encoder's latent and nothing else: run on two streams,
 # the workgroups of one fill the tail rounds of the other's persistent GEMMs (forward AND backward: autograd replays each
-# stage's backward on the stream its forward ran on).  Measured on MI355X at B=256: forward 14.59 -> 14.19 ms, whole step 40.64 ->
-# 40.49 ms -- the weight-gradient stream already fills most of the gaps in backward.  Off by default (ECAMP_OVERLAP_BRANCHES=1).
-OVERLAP_BRANCHES = __import__("os").environ.get("ECAMP_OVERLAP_BRANCHES", "0") != "0"
+# stage's backward on the stream its forward ran on).  Measured on MI355X at B=256, same-box A/B of 30-step runs on three boxes
+# (round 3, after the phase-schedule GEMM and the one-launch-per-block weight gradients): step 37.4-37.5 -> 36.6-36.65 ms, forward
+# 14.3 -> 14.0, forward+backward 35.9 -> 35.1 (in round 2 the same switch bought 0.15 ms: the slower GEMMs left fewer gaps that
+# the weight-gradient stream did not already fill).  On by default; ECAMP_OVERLAP_BRANCHES=0 serialises the two branches.
+OVERLAP_BRANCHES = __import__("os").environ.get("ECAMP_OVERLAP_BRANCHES", "1") != "0"
 
 
 def side_streams(device):

@@ -37,6 +37,28 @@ __global__ __launch_bounds__(512) void frag_store(unsigned char* out, long pitch
             }
     }
 }
+// The Q8 epilogue's store stream: wave (wr, wc) of 8 owns 128 rows x 128 B (one cache line per row) of a 256-row x 512-B tile.
+//   PAT 0  what gemm_q8.h issues: lane (l31, lh) writes 16 B at row tm*32 + l31, byte NH*64 + gq*32 + lh*16 -> 32 lines x 32 B per instruction
+//   PAT 1  whole lines: instruction i writes rows i*8 + lane/8, byte (lane%8)*16                              ->  8 lines x 128 B per instruction
+//   PAT 2  half lines:  instruction i writes rows (i/2)*16 + lane/4, byte (i%2)*64 + (lane%4)*16                -> 16 lines x 64 B per instruction
+template <int PAT>
+__global__ __launch_bounds__(512) void q8_store(unsigned char* out, long pitch, int tiles_per_row, int ntiles, int reps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    for (int rep = 0; rep < reps; ++rep)
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tr = t / tiles_per_row, tc = t % tiles_per_row;
+        unsigned char* base = out + ((long)tr * 256 + (wave >> 2) * 128) * pitch + (long)tc * 512 + (wave & 3) * 128;
+        u32x4 v = {(unsigned)t, 1u, 2u, (unsigned)rep};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            long row; int byte;
+            if (PAT == 0) { const int tm = i >> 2, nh = (i >> 1) & 1, gq = i & 1; row = tm * 32 + l31; byte = nh * 64 + gq * 32 + lh * 16; }
+            else if (PAT == 1) { row = i * 8 + (lane >> 3); byte = (lane & 7) * 16; }
+            else { row = (i >> 1) * 16 + (lane >> 2); byte = (i & 1) * 64 + (lane & 3) * 16; }
+            *reinterpret_cast<u32x4*>(base + row * pitch + byte) = v;
+        }
+    }
+}
 __global__ void linear_fill(u32x4* out, long n) {
     u32x4 v = {0u, 1u, 2u, 3u};
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = v;
@@ -54,6 +76,23 @@ int main() {
         long n = M * 60000 / 16;
         float ms = timeit([&] { linear_fill<<<2048, 256>>>((u32x4*)buf, n); });
         printf("linear fill                         : %.2f TB/s\n", n * 16.0 / ms / 1e9);
+    }
+    {   // the Q8 epilogue's stream by lane pattern: HBM-sized output (206 MB, one pass) and an Infinity-Cache-sized one (16 MB, 12 passes)
+        const char* pn[3] = {"32 lines x 32 B (gemm_q8.h)", " 8 lines x 128 B", "16 lines x 64 B"};
+        for (int big = 1; big >= 0; --big) {
+            const long pitch = big ? 4096 : 4096, rows = big ? 50432 : 4096;
+            const int tpr = (int)(pitch / 512), nt = (int)(rows / 256) * tpr, reps = big ? 1 : 12;
+            const double bytes = (double)nt * 256 * 512 * reps;
+            for (int pat = 0; pat < 3; ++pat) {
+                float ms = timeit([&] {
+                    if (pat == 0) q8_store<0><<<256, 512>>>(buf, pitch, tpr, nt, reps);
+                    if (pat == 1) q8_store<1><<<256, 512>>>(buf, pitch, tpr, nt, reps);
+                    if (pat == 2) q8_store<2><<<256, 512>>>(buf, pitch, tpr, nt, reps);
+                });
+                printf("Q8 tile stream, %s output, %-28s: %.2f TB/s  (%.1f us per 256-tile round)\n", big ? "206 MB" : " 16 MB x 12", pn[pat], bytes / ms / 1e9,
+                       ms * 1e3 / (bytes / (256.0 * 131072)));
+            }
+        }
     }
     for (int pi = 0; pi < 2; ++pi) {
         const long pitch = pitches[pi]; const long rowsM = pi == 0 ? M : 12800 * 8;  // keep ~2 GB / 0.63 GB
