@@ -59,6 +59,8 @@ class GradReducer:
         self._cb_queued = False
         self.main_stream = None   # the step's compute stream (set by the wrapper's forward); the collectives also wait for it
         self.timing = False       # record event pairs around every collective (bench.py's `rccl` record)
+        self.after_bucket = None  # callback(lo, hi, slots), run right behind a bucket's collective on the stream that carries it:
+        #                           the optimizer's in-backward update (optim.FusedAdamW.arm); also drives a 1-rank reducer
         self._timed = []
         self.dirty = False      # a backward pass has reported gradients that finalize() has not yet reduced
         self.reset()
@@ -70,11 +72,12 @@ class GradReducer:
         self._cb_queued = False
 
     def _launch(self, b):
-        if self.launched[b] or (self.world == 1 and not self.force_comm):
+        comm = not (self.world == 1 and not self.force_comm)
+        if self.launched[b] or (not comm and self.after_bucket is None):
             self.launched[b] = True
             return
         self.launched[b] = True
-        lo, hi, _ = self.buckets[b]
+        lo, hi, slots = self.buckets[b]
         buf = self.flat_g[lo:hi]
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         if self.host_staged:
@@ -86,7 +89,11 @@ class GradReducer:
                 cur.wait_stream(wst)
             host = buf.cpu()
             dist.all_reduce(host, op=op, group=self.group)
+            if not self.use_avg and self.world > 1:
+                host.div_(self.world)
             buf.copy_(host)
+            if self.after_bucket is not None:
+                self.after_bucket(lo, hi, slots)
             self.works.append((None, b))
             return
         if self.side is not None:
@@ -103,15 +110,22 @@ class GradReducer:
                 self.side.wait_stream(wst)
             with torch.cuda.stream(self.side):
                 t0 = None
-                if self.timing:
+                if self.timing and comm:
                     t0 = torch.cuda.Event(enable_timing=True)
                     t0.record(self.side)
-                w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
-                w.wait()       # stream-level: the SIDE stream waits for RCCL's stream (the host does not block)
-                done = torch.cuda.Event(enable_timing=self.timing)
-                done.record(self.side)
+                if comm:
+                    w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+                    w.wait()       # stream-level: the SIDE stream waits for RCCL's stream (the host does not block)
+                    if not self.use_avg and self.world > 1:
+                        buf.div_(self.world)
                 if t0 is not None:
-                    self._timed.append((t0, done))
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(self.side)
+                    self._timed.append((t0, t1))
+                if self.after_bucket is not None:
+                    self.after_bucket(lo, hi, slots)   # e.g. AdamW of exactly these parameters, behind their all-reduce
+                done = torch.cuda.Event()
+                done.record(self.side)
             self.works.append((done, b))
         else:
             w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
@@ -157,12 +171,12 @@ class GradReducer:
                 self._launch(b)
         for w, b in self.works:
             if isinstance(w, torch.cuda.Event):
-                torch.cuda.current_stream().wait_event(w)   # the compute stream sees the reduced bucket
+                torch.cuda.current_stream().wait_event(w)   # the compute stream sees the reduced (and, armed, updated) bucket
             elif w is not None:
                 w.wait()
-            if not self.use_avg and self.world > 1:
-                lo, hi, _ = self.buckets[b]
-                self.flat_g[lo:hi].div_(self.world)
+                if not self.use_avg and self.world > 1:      # host tensors over gloo (the device paths divide in _launch)
+                    lo, hi, _ = self.buckets[b]
+                    self.flat_g[lo:hi].div_(self.world)
         self.dirty = False
         self.reset()
 

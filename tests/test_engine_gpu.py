@@ -333,3 +333,59 @@ def test_device_prefetcher_delivers_every_batch_intact(dev):
         for b in DevicePrefetcher(host, dev):
             raise RuntimeError("consumer failed")
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("branches", [1, 0])
+def test_every_gradient_bucket_is_final_when_its_collective_may_start(dev, branches):
+    """The data-parallel contract of `arena.ready()`, checked on ONE GPU under the real stream concurrency (weight-gradient side
+    stream, image-decoder branch stream): a bucket's all-reduce is queued behind every stream that writes gradients at the moment
+    its last parameter is reported -- so nothing may write into the bucket afterwards.  A 1-rank reducer (no communication) runs a
+    hook in the collective's place that copies the bucket on the communication stream; after backward every copy must equal the
+    final gradient arena bit for bit.  ViT-B / reference BERT at B=32 (the streams really run apart), second backward pass (the
+    weight matrices are in overwrite mode), 4 MiB buckets (every layer boundary is a bucket boundary somewhere)."""
+    from ecamp_amd import hip_ops, optim
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.parallel import GradReducer
+    old = hip_ops.OVERLAP_BRANCHES
+    hip_ops.OVERLAP_BRANCHES = bool(branches)
+    try:
+        torch.manual_seed(0)
+        model = me.ecamp(compute_dtype=torch.bfloat16).to(dev)
+        model.train()
+        A = model.prepare()
+        opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-4, betas=(0.9, 0.95))
+        red = GradReducer(A.flat_g, A.offsets, A.sizes, A.unused, bucket_mb=4.0, tail_bucket_mb=1.0)
+        A.reducer, A.on_ready = red, red.mark_ready
+        assert red.world == 1 and len(red.buckets) > 100
+        batch = synthetic_batch(32, 128, 448, seed=1, device=dev)
+        snaps = []
+        order = []
+
+        def hook(lo, hi, slots):
+            snaps.append((lo, hi, A.flat_g[lo:hi].clone()))     # on the communication stream, where the all-reduce would read it
+            order.append(lo)
+
+        for it in range(2):
+            snaps.clear(); order.clear()
+            red.main_stream = torch.cuda.current_stream()
+            red.after_bucket = hook
+            mim, res, mlm = model(batch)
+            (mim + res + mlm).backward()
+            red.after_bucket = None
+            torch.cuda.synchronize()
+            assert len(snaps) == len(red.buckets) and not red.dirty
+            early = sum(1 for lo, hi, _ in snaps[:len(snaps) // 2] if lo > A.total // 3)
+            assert early > 10                                  # buckets really were launched during backward, in backward's order
+            if it == 0:
+                opt.zero_grad()                                # lazy from now on: weight matrices are overwritten, not zeroed
+        bad = []
+        for lo, hi, snap in snaps:
+            if not torch.equal(snap, A.flat_g[lo:hi]):
+                names = [A.names[i] for i in range(len(A.names)) if lo <= A.offsets[i] < hi]
+                d = (snap - A.flat_g[lo:hi]).abs()
+                bad.append((names[0], names[-1], float(d.max()), int((d > 0).sum())))
+        assert not bad, "written after their bucket was released: %s" % bad[:5]
+    finally:
+        hip_ops.OVERLAP_BRANCHES = old
