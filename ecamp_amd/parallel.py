@@ -59,8 +59,9 @@ class GradReducer:
         self._cb_queued = False
         self.main_stream = None   # the step's compute stream (set by the wrapper's forward); the collectives also wait for it
         self.timing = False       # record event pairs around every collective (bench.py's `rccl` record)
-        self.after_bucket = None  # callback(lo, hi, slots), run right behind a bucket's collective on the stream that carries it:
-        #                           the optimizer's in-backward update (optim.FusedAdamW.arm); also drives a 1-rank reducer
+        self.after_bucket = None  # callback(lo, hi, slots), run right behind a bucket's collective on the stream that carries it (with a
+        #                           callback set even a 1-rank reducer walks its buckets: tests copy them there to prove that a bucket
+        #                           is final when its collective may start)
         self._timed = []
         self.dirty = False      # a backward pass has reported gradients that finalize() has not yet reduced
         self.reset()
@@ -123,7 +124,7 @@ class GradReducer:
                     t1.record(self.side)
                     self._timed.append((t0, t1))
                 if self.after_bucket is not None:
-                    self.after_bucket(lo, hi, slots)   # e.g. AdamW of exactly these parameters, behind their all-reduce
+                    self.after_bucket(lo, hi, slots)
                 done = torch.cuda.Event()
                 done.record(self.side)
             self.works.append((done, b))
