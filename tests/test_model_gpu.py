@@ -318,6 +318,46 @@ def test_ragged_shapes_fp32_match_oracle(dev, B, S, mask_ratio):
         assert err < 1e-3, (n, err)
 
 
+def test_degenerate_reports_fp32_match_oracle(dev):
+    """Edge cases of the report side in one batch, fp32 parity against the oracle run live: a report that is [CLS] followed by padding
+    only (one unmasked key per attention row), a report with no [MASK] token at all, a report whose token weights are all zero, a
+    report at the full length with every non-CLS token masked; SR grid cells at both ends (0 and 2) on both axes."""
+    from ecamp_amd.module import model_ecamp as me
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    torch.set_num_threads(16)
+    cfg = orc.cfg_tiny()
+    state = recipe.recipe_state(cfg, seed=0)
+    B, S = 4, 128
+    batch = recipe.recipe_batch(cfg, B, S, seed=11)
+    ids, labels, am, w = batch["ids"], batch["labels"], batch["attention_mask"], batch["weights"]
+    am[0] = 0; am[0, 0] = 1; labels[0, 1:] = 0; ids[0] = labels[0]                      # [CLS] + padding
+    ids[1] = labels[1]                                                                     # nothing masked
+    w[2] = 0.0                                                                             # every token weight zero
+    am[3] = 1; labels[3, 1:] = torch.randint(5, cfg.bert.vocab_size, (S - 1,), generator=torch.Generator().manual_seed(5))
+    ids[3] = labels[3]; ids[3, 1:] = 3                                                     # full length, everything masked
+    batch["column"][:] = torch.tensor([0, 2, 0, 2]); batch["row"][:] = torch.tensor([0, 2, 2, 0])
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=11)
+    P = orc.set_requires_grad(orc.load_state(orc.new_params(cfg), state), cfg)
+    ref = orc.forward(P, cfg, batch, 0.75, noise)
+    sum(ref).backward()
+    model = me.ecamp_tiny(compute_dtype=torch.float32)
+    model.load_state_dict(state)
+    model.to(dev).eval()
+    out = model(batch, mask_ratio=0.75, noise=noise)
+    sum(out).backward()
+    for a, b in zip(out, ref):
+        assert torch.isfinite(a).all() and abs(a.item() - b.item()) / abs(b.item()) < 2e-4, (a.item(), b.item())
+    named = dict(model.named_parameters())
+    for n in ("blocks.0.attn.qkv.weight", "bert_encoder.model.bert.embeddings.word_embeddings.weight", "bert_encoder.model.bert.encoder.layer.0.attention.self.value.weight",
+              "bert_encoder.model.bert.context_fusion_layer.cross_self_attention.query.weight", "bert_encoder.model.cls.predictions.decoder.weight",
+              "bert_mlp.weight", "super_res.conv1.weight"):
+        g, gr = named[n].grad.float().cpu(), P[n].grad
+        assert torch.isfinite(g).all(), n
+        err = (g - gr).norm().item() / (gr.norm().item() + 1e-12)
+        assert err < 1e-3, (n, err)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
 def test_visualization_forward_matches_reference(dev, dtype, tol):
     """ECAMP.forward_visualization (mask_ratio=0, fusion cross-attention probabilities [B,6,S,196]) against
