@@ -272,6 +272,7 @@ def main():
                 "p8_wgrad_reserve_cus": int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")),
                 "q8_bwd_grid": int(os.environ.get("ECAMP_DDP_Q8_BWD_GRID", str(1 << 20))),
                 "allreduce_ms_per_step": round(red.comm_ms() / args.steps, 3),
+                "adamw": "bucket by bucket behind each bucket's all-reduce (%d of %d optimizer steps)" % (opt.bucketwise_steps, opt._step),
                 "note": "all-reduce of the f32 gradient arena in buckets on a side HIP stream, overlapped with backward; ms = sum of the "
                         "buckets' event-bracketed durations on that stream on rank 0 (they overlap compute, so this is not added step time)"}
         red.timing = False

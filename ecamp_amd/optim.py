@@ -36,6 +36,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._arena = None
         self._step = 0
         self.grad_scale = 1.0
+        self.bucketwise_steps = 0   # optimizer steps that ran bucket by bucket behind the gradient all-reduces
 
     @property
     def arena(self):
@@ -70,18 +71,35 @@ class FusedAdamW(torch.optim.Optimizer):
         self._arena = arena
         return arena
 
+    def _launch(self, A, lo, hi, grad_sumsq):
+        g0 = self.param_groups[0]
+        ops.adamw_grouped(A.flat_p[lo:hi], A.flat_g[lo:hi], self._m[lo:hi], self._v[lo:hi], A.flat_p16[lo:hi] if A.flat_p16 is not None else None,
+                          self._table[lo // 64:hi // 64], [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups],
+                          g0["betas"][0], g0["betas"][1], g0["eps"], self._step, self.grad_scale, grad_sumsq)
+
     @torch.no_grad()
     def step(self, closure=None, grad_sumsq=None):
         loss = closure() if closure is not None else None
         A = self._bind()
+        events = None
         if A.reducer is not None:
             A.reducer.assert_reduced()   # loud failure instead of a silent step on un-reduced gradients
-        A.flush_fresh()
+            events = A.reducer.take_bucket_events()
         self._step += 1
-        g0 = self.param_groups[0]
-        ops.adamw_grouped(A.flat_p, A.flat_g, self._m, self._v, A.flat_p16, self._table, [g["lr"] for g in self.param_groups],
-                          [g["weight_decay"] for g in self.param_groups], g0["betas"][0], g0["betas"][1], g0["eps"], self._step,
-                          self.grad_scale, grad_sumsq)
+        if events and not A._fresh:
+            # data parallel, lazy join (GradReducer.lazy): one slice of the fused kernel per gradient bucket, each behind its own
+            # all-reduce, in the order the collectives were issued -- the update of the early buckets runs while the last ones
+            # are still on the links
+            cur = torch.cuda.current_stream()
+            for lo, hi, ev in events:
+                cur.wait_event(ev)
+                self._launch(A, lo, hi, grad_sumsq)
+            self.bucketwise_steps += 1
+        else:
+            for _, _, ev in events or ():    # (a module did not run this window: zero its weights only behind every collective)
+                torch.cuda.current_stream().wait_event(ev)
+            A.flush_fresh()
+            self._launch(A, 0, A.total, grad_sumsq)
         A.version += 1   # the bf16 shadows changed: the fp8-forward mode re-quantises its weight copies on next use
         return loss
 

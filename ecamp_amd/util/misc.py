@@ -250,6 +250,7 @@ def get_grad_norm_(parameters, norm_type=2.0):
     return torch.norm(torch.stack([torch.norm(p.grad.detach(), norm_type).to(device) for p in parameters]), norm_type)
 
 
+_BUCKETWISE_ADAMW = os.environ.get("ECAMP_BUCKETWISE_ADAMW", "1") != "0"   # data parallel: AdamW bucket by bucket behind each bucket's all-reduce
 _FUSED_GRAD_NORM = os.environ.get("ECAMP_FUSED_GRAD_NORM", "1") != "0"   # 0: separate sum-of-squares pass, as the reference does
 
 
@@ -262,13 +263,30 @@ class NativeScalerWithGradNormCount:
         self._state = {"scale": 1.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
-        loss.backward(create_graph=create_graph)
+        arena = getattr(optimizer, "arena", None) if loss.is_cuda else None
+        reducer = getattr(arena, "reducer", None) if arena is not None else None
+        lazy = False
+        if (reducer is not None and update_grad and clip_grad is None and not create_graph and _FUSED_GRAD_NORM and _BUCKETWISE_ADAMW
+                and hasattr(optimizer, "step_with_grad_norm") and getattr(reducer, "side", None) is not None
+                and (reducer.world > 1 or reducer.force_comm) and not reducer.host_staged):
+            ps = list(parameters) if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]]
+            lazy = optimizer.covers(ps)
+        if lazy:
+            reducer.lazy = True    # the end-of-backward callback leaves the buckets' events to the optimizer (GradReducer.lazy)
+        try:
+            loss.backward(create_graph=create_graph)
+        finally:
+            if lazy:
+                reducer.lazy = False
         if not update_grad:
             return None
+        if lazy:
+            reducer.finalize()     # a no-op when the autograd callback has run (then the bucket events are waiting)
+            return optimizer.step_with_grad_norm()   # bucket by bucket behind the all-reduces; flushes unwritten weights itself
+        if reducer is not None and hasattr(reducer, "join"):
+            reducer.join()
         if hasattr(optimizer, "flush_grads"):
             optimizer.flush_grads()  # weights no GEMM wrote this window read as zero (lazy zero_grad)
-        arena = getattr(optimizer, "arena", None)
-        reducer = getattr(arena, "reducer", None) if arena is not None else None
         if reducer is not None:
             reducer.finalize()  # normally a no-op (the autograd callback has run); the safety net when no callback could be queued
         if clip_grad is not None:

@@ -389,3 +389,72 @@ def test_every_gradient_bucket_is_final_when_its_collective_may_start(dev, branc
         assert not bad, "written after their bucket was released: %s" % bad[:5]
     finally:
         hip_ops.OVERLAP_BRANCHES = old
+
+
+@pytest.mark.gpu
+def test_bucketwise_adamw_behind_the_allreduces_equals_the_plain_step(dev):
+    """Data-parallel path of the loss scaler: with a reducer that communicates (here a 1-rank RCCL group with the collectives forced
+    on), the end-of-backward callback leaves the buckets' completion events to FusedAdamW, which updates bucket by bucket, each
+    slice behind its own all-reduce.  Checked step by step on the SAME gradients (two training runs cannot be compared bit for bit:
+    atomically summed gradients differ in their last bits run to run and Adam's first steps amplify that): after every scaler call
+    the gradient arena, which the update does not modify, is fed to a one-pass AdamW starting from the saved pre-step parameters
+    and moments -- parameters, moments, bf16 shadow and the gradient norm must come out the same, bit for bit.  Three optimizer
+    steps, the second one over two accumulation micro-steps with no_sync on the first."""
+    import os
+
+    import torch.distributed as dist
+    from ecamp_amd import hip_ops, optim
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.parallel import DistributedDataParallel
+    from ecamp_amd.util import misc
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = orc.cfg_tiny()
+        state = recipe.recipe_state(cfg, seed=0)
+        batches = [recipe.recipe_batch(cfg, 4, 128, seed=s) for s in range(4)]
+        noise = recipe.recipe_noise(4, cfg.num_patches, seed=0)
+        plan = [(0, True, 1.0), (1, False, 0.5), (2, True, 0.5), (3, True, 1.0)]    # (batch, update_grad, loss scale)
+        torch.manual_seed(0)
+        model = me.ecamp_tiny(compute_dtype=torch.bfloat16)
+        model.load_state_dict(state, strict=True)
+        model.to(dev).eval()
+        A = model.prepare()
+        net = DistributedDataParallel(model, bucket_cap_mb=2.0, tail_bucket_mb=0.5, tail_span_mb=2.0, force_comm=True)
+        opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-3, betas=(0.9, 0.95))
+        scaler = misc.NativeScalerWithGradNormCount()
+        opt.zero_grad()
+        opt._bind()
+        g0 = opt.param_groups[0]
+        steps = 0
+        for bi, upd, sc in plan:
+            net.set_grad_sync(upd)
+            before = (A.flat_p.clone(), opt._m.clone(), opt._v.clone())
+            mim, res, mlm = net(batches[bi], mask_ratio=0.75, noise=noise)
+            n = scaler((mim + res + mlm) * sc, opt, parameters=model.parameters(), update_grad=upd)
+            if not upd:
+                assert n is None and torch.equal(A.flat_p, before[0])
+                continue
+            steps += 1
+            torch.cuda.synchronize()
+            assert opt.bucketwise_steps == steps and net.reducer.bucket_events is None and not net.reducer.lazy
+            p, m, v = before
+            s = torch.zeros(1, device=dev)
+            p16 = torch.empty_like(A.flat_p16)
+            hip_ops.adamw_grouped(p, A.flat_g, m, v, p16, opt._table, [g["lr"] for g in opt.param_groups], [g["weight_decay"] for g in opt.param_groups],
+                                  g0["betas"][0], g0["betas"][1], g0["eps"], steps, 1.0, s)
+            torch.cuda.synchronize()
+            assert torch.equal(p, A.flat_p) and torch.equal(m, opt._m) and torch.equal(v, opt._v)
+            used = opt._table.repeat_interleave(64) < 8          # the pooler is never updated (and its shadow never rewritten)
+            assert torch.equal(p16[used], A.flat_p16[used])
+            assert abs(float(s.sqrt()) - float(n)) <= 1e-3 * float(n)     # f32 sum of squares: one launch against one per bucket
+            opt.zero_grad()
+        assert steps == 3 and len(net.reducer.buckets) > 8
+    finally:
+        if created:
+            dist.destroy_process_group()
