@@ -114,14 +114,20 @@ def cpu_baseline(seq, budget_s=25.0):
                       "thread count)" % (n, seq, torch.__version__, cores)}
 
 
-def launch_ranks(cmd, n, poll_s=0.2, grace_s=5.0, check_devices=True):
+def launch_ranks(cmd, n, poll_s=0.2, grace_s=5.0, check_devices=True, limit_s=None):
     """Self-launch: `n` fresh child processes of `cmd`, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
-    environment), started BEFORE this process touches the GPU and never re-exec'ed.  The children are polled: when one exits
-    non-zero the others are terminated (they would otherwise sit in an RCCL collective until the driver's timeout), the parent says
-    which rank failed, shows the tail of its stderr and returns its code.  Returns 0 when every rank exited 0."""
+    environment), never re-exec'ed.  The children are polled: when one exits non-zero -- or when the whole job passes `limit_s`
+    seconds of wall clock (env ECAMP_BENCH_LIMIT_S, default 1500: a rank hung inside an RCCL collective never exits by itself) --
+    the others are terminated, the parent says which rank failed (or that the limit was hit, with every rank's stderr tail) and
+    returns non-zero.  Every rank's stderr is also teed to this process's stderr line by line while the job runs, so a hang is not
+    silent.  Returns 0 when every rank exited 0."""
     import tempfile
+    import threading
+    if limit_s is None:
+        limit_s = float(os.environ.get("ECAMP_BENCH_LIMIT_S", "1500"))
     if check_devices:
-        have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+        # (on ROCm this may call hipGetDeviceCount in the parent; harmless -- the ranks are fresh child processes, nothing is exec'ed)
+        have = torch.cuda.device_count()
         if have < n:
             print("bench.py: --gpus %d but this box has %d visible GPU(s): nothing launched" % (n, have), file=sys.stderr)
             return 2
@@ -130,15 +136,28 @@ def launch_ranks(cmd, n, poll_s=0.2, grace_s=5.0, check_devices=True):
     port = sock.getsockname()[1]
     sock.close()
     threads = max(1, (os.cpu_count() or n) // n)   # host threads per rank (pinning / copies / CPU-side torch ops): cores / N, not 256 each
-    procs, logs = [], []
+    procs, logs, tees = [], [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.setdefault("OMP_NUM_THREADS", str(min(threads, 32)))
+        for k, v in RCCL_ENV_DEFAULTS.items():
+            env.setdefault(k, v)
         log = tempfile.TemporaryFile(mode="w+")
         logs.append(log)
-        procs.append(subprocess.Popen(cmd, env=env, stderr=log))
+        pr = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(pr)
+
+        def tee(pr=pr, log=log, r=r):   # the child's stderr, line by line: kept for the failure report AND passed on as it comes
+            for line in pr.stderr:
+                log.write(line)
+                sys.stderr.write(line if n == 1 else "[rank %d] %s" % (r, line))
+            pr.stderr.close()
+        th = threading.Thread(target=tee, daemon=True)
+        th.start()
+        tees.append(th)
     failed = None
+    t_limit = time.time() + limit_s
     while failed is None:
         codes = [pr.poll() for pr in procs]
         for r, c in enumerate(codes):
@@ -146,6 +165,9 @@ def launch_ranks(cmd, n, poll_s=0.2, grace_s=5.0, check_devices=True):
                 failed = (r, c)
                 break
         if failed is None and all(c == 0 for c in codes):
+            break
+        if failed is None and time.time() > t_limit:
+            failed = (-1, 124)
             break
         time.sleep(poll_s)
     if failed is not None:
@@ -159,18 +181,21 @@ def launch_ranks(cmd, n, poll_s=0.2, grace_s=5.0, check_devices=True):
             except subprocess.TimeoutExpired:
                 pr.kill()
                 pr.wait()
-    for r, log in enumerate(logs):   # pass the children's stderr on (rank 0's warnings included), the failed rank's last
-        if failed is not None and r == failed[0]:
-            continue
-        log.seek(0)
-        sys.stderr.write(log.read())
+    for th in tees:
+        th.join(timeout=grace_s)
     if failed is not None:
         r, c = failed
-        logs[r].seek(0)
-        tail = logs[r].read().splitlines()[-25:]
-        print("bench.py: rank %d of %d exited with code %d; the other ranks were terminated.  Its stderr (tail):" % (r, n, c), file=sys.stderr)
-        for line in tail:
-            print("  [rank %d] %s" % (r, line), file=sys.stderr)
+        if r < 0:
+            print("bench.py: the %d-rank job passed its wall-clock limit of %.0f s (ECAMP_BENCH_LIMIT_S); every rank was terminated.  "
+                  "Stderr tails:" % (n, limit_s), file=sys.stderr)
+            show = range(n)
+        else:
+            print("bench.py: rank %d of %d exited with code %d; the other ranks were terminated.  Its stderr (tail):" % (r, n, c), file=sys.stderr)
+            show = [r]
+        for q in show:
+            logs[q].seek(0)
+            for line in logs[q].read().splitlines()[-25:]:
+                print("  [rank %d] %s" % (q, line), file=sys.stderr)
         return abs(c) or 1
     return 0
 
@@ -316,21 +341,23 @@ def main():
     from ecamp_amd import hip_ops
     prof_steps = 0
     if not args.no_prof:  # every rank runs it (the steps contain collectives)
-        hip_ops.OVERLAP_WGRAD = False
+        wgrad, hip_ops.OVERLAP_WGRAD = hip_ops.OVERLAP_WGRAD, False
         branches, hip_ops.OVERLAP_BRANCHES = hip_ops.OVERLAP_BRANCHES, False   # one kernel at a time: no second stream of any kind
-        step()
-        torch.cuda.synchronize()
-        lib.ecamp_prof_collect(-1, None, None, None)
-        lib.ecamp_prof_enable(1)
-        prof_steps = min(args.steps, 3)
-        tp = time.perf_counter()
-        for _ in range(prof_steps):
+        try:   # whatever happens in between, the process leaves the serialized mode
             step()
-        torch.cuda.synchronize()
-        serial_ms = 1e3 * (time.perf_counter() - tp) / prof_steps
-        lib.ecamp_prof_enable(0)
-        hip_ops.OVERLAP_WGRAD = True
-        hip_ops.OVERLAP_BRANCHES = branches
+            torch.cuda.synchronize()
+            lib.ecamp_prof_collect(-1, None, None, None)
+            lib.ecamp_prof_enable(1)
+            prof_steps = min(args.steps, 3)
+            tp = time.perf_counter()
+            for _ in range(prof_steps):
+                step()
+            torch.cuda.synchronize()
+            serial_ms = 1e3 * (time.perf_counter() - tp) / prof_steps
+        finally:
+            lib.ecamp_prof_enable(0)
+            hip_ops.OVERLAP_WGRAD = wgrad
+            hip_ops.OVERLAP_BRANCHES = branches
     if world > 1:
         t = torch.tensor([dt, dt_res, dt_fwd, dt_fb], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

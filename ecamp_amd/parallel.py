@@ -8,21 +8,66 @@ parameters (`arena.ready`), and a bucket whose parameters are all done is all-re
 of the arena, op=AVG) on a side HIP stream while the remaining backward keeps the compute stream busy.  Unused
 parameters are known statically and never waited for; accumulation micro-steps skip communication.
 xGMI is point-to-point (7 links x ~153 GB/s): large buckets (default 32 MiB, 8 MiB for the parameters backward finishes last)
-keep RCCL's rings/trees per-link efficient; the whole exchange is ~2.5 ms (8 GPUs) to ~14 ms (2 GPUs, one link) of link time
-against 22 ms of backward at B=256, of which the first gradients are final after 2.6 ms (tools/bucket_timeline.py).
+keep RCCL's rings/trees per-link efficient; priced with a serial communication stream at 70 % of (N-1) x 76 GB/s per GPU the whole
+f32 exchange is 4.8 ms (8 GPUs) / 8.3 ms (4) / 15.2 ms (2 GPUs, one link) of link time against 22 ms of backward at B=256, of which
+the first gradients are final after 3.3 ms (tools/bucket_timeline.py).  `grad_dtype=torch.bfloat16` halves the
+payload (a bucket is cast-packed into a bf16 mirror on the communication stream, all-reduced there and unpacked into the f32 arena);
+f32 stays the default.  RCCL's kernels share the CUs with the backward pass: `rccl_env_defaults()` caps their channel (= workgroup)
+count below the point where a co-tenant starts to cost the step more than it hides (profiles/r03_cotenant_ab.txt).
 """
 import contextlib
 import os
+import re
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+# RCCL runs one workgroup per channel beside the backward pass.  A spinning co-tenant of 16 / 32 / 64 / 96 workgroups costs the step
+# +1.6 / +1.7 / +1.9 / +2.9 ms and 128 workgroups +13 ms (a cliff: no CU is left without a resident stranger;
+# profiles/r03_cotenant_ab.txt, two boxes), while the exchange has 22 ms of backward to hide 4.8-15.2 ms of link time in -- so the
+# channel count is capped at 32, a quarter of the cliff and the reserve the weight-gradient launches leave free
+# (`p8_wgrad_reserve_cus` = 32).  Applied with setdefault: an explicit NCCL_* setting of the user wins, and the `rccl` record of
+# bench.py prints what was in force.
+RCCL_ENV_DEFAULTS = {"NCCL_MAX_NCHANNELS": "32", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def rccl_env_defaults(env=None):
+    """setdefault() RCCL_ENV_DEFAULTS into `env` (default: this process's environment; call before init_process_group)."""
+    env = os.environ if env is None else env
+    for k, v in RCCL_ENV_DEFAULTS.items():
+        env.setdefault(k, v)
+    return env
+
+
+def rccl_env_record(debug_file=None):
+    """What the `rccl` record of bench.py says about the communication kernels: every NCCL_* / RCCL_* variable in force and, when
+    RCCL wrote an INFO log (NCCL_DEBUG=INFO, NCCL_DEBUG_FILE), the channel count it reports."""
+    rec = {"env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_"))}}
+    rec["max_channels_cap"] = int(os.environ["NCCL_MAX_NCHANNELS"]) if os.environ.get("NCCL_MAX_NCHANNELS", "").isdigit() else None
+    if debug_file and os.path.exists(debug_file):
+        try:
+            txt = open(debug_file, errors="replace").read()
+        except OSError:
+            txt = ""
+        ch = [int(m) for m in re.findall(r"(\d+) coll channels", txt)]
+        ch += [int(b) for _, b in re.findall(r"Channel (\d+)/(\d+)", txt)]
+        rec["channels_reported"] = max(ch) if ch else None
+        rec["channel_lines"] = [ln.strip()[-160:] for ln in txt.splitlines() if "coll channels" in ln or "nChannels" in ln][:4]
+    return rec
+
 
 class GradReducer:
     def __init__(self, flat_g, offsets, sizes, unused=(), bucket_mb=32.0, group=None, force_comm=False, tail_bucket_mb=None,
-                 tail_span_mb=32.0):
+                 tail_span_mb=32.0, grad_dtype=None):
         self.flat_g, self.offsets, self.sizes = flat_g, list(offsets), list(sizes)
+        # payload dtype of the exchange: None / float32 = the arena itself, in place (the default, bit-identical to round 3);
+        # bfloat16 = a bucket is cast into its slice of a bf16 mirror of the arena on the communication stream, the mirror slice is
+        # all-reduced and cast back into the f32 arena -- half the bytes on the links (366 instead of 733 MB per step)
+        self.grad_dtype = None if grad_dtype in (None, torch.float32) else grad_dtype
+        if self.grad_dtype not in (None, torch.bfloat16):
+            raise ValueError("GradReducer: grad_dtype must be float32 or bfloat16")
+        self.pack = None   # the bf16 mirror, allocated on first use
         self.unused = set(unused)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -94,10 +139,10 @@ class GradReducer:
                 cur.wait_stream(self.main_stream)
             for wst in hip_ops.side_streams(self.flat_g.device):
                 cur.wait_stream(wst)
-            host = buf.cpu()
+            host = buf.cpu() if self.grad_dtype is None else buf.to(self.grad_dtype).cpu()
             dist.all_reduce(host, op=op, group=self.group)
             if not self.use_avg and self.world > 1:
-                host.div_(self.world)
+                host = host.float().div_(self.world)
             buf.copy_(host)
             if self.after_bucket is not None:
                 self.after_bucket(lo, hi, slots)
@@ -121,8 +166,14 @@ class GradReducer:
                     t0 = torch.cuda.Event(enable_timing=True)
                     t0.record(self.side)
                 if comm:
-                    w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+                    wire = buf
+                    if self.grad_dtype is not None:   # cast-pack on the communication stream
+                        wire = self._mirror()[lo:hi]
+                        wire.copy_(buf)
+                    w = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
                     w.wait()       # stream-level: the SIDE stream waits for RCCL's stream (the host does not block)
+                    if wire is not buf:
+                        buf.copy_(wire)
                     if not self.use_avg and self.world > 1:
                         buf.div_(self.world)
                 if t0 is not None:
@@ -135,8 +186,21 @@ class GradReducer:
                 done.record(self.side)
             self.works.append((done, b))
         else:
-            w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+            wire = buf
+            if self.grad_dtype is not None:
+                wire = self._mirror()[lo:hi]
+                wire.copy_(buf)
+            w = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
             self.works.append((w, b))
+
+    def _mirror(self):
+        if self.pack is None:
+            self.pack = torch.empty(self.flat_g.numel(), dtype=self.grad_dtype, device=self.flat_g.device)
+        return self.pack
+
+    def payload_bytes(self):
+        """Bytes one optimizer step puts on the links per rank (before the collective's own 2(N-1)/N factor)."""
+        return self.flat_g.numel() * (self.flat_g.element_size() if self.grad_dtype is None else 2)
 
     def comm_ms(self):
         """Sum of the all-reduce durations (ms, events on the communication stream) recorded since the last call; needs `timing`."""
@@ -185,8 +249,10 @@ class GradReducer:
                     torch.cuda.current_stream().wait_event(w)   # the compute stream sees the reduced bucket
                 elif w is not None:
                     w.wait()
+                    lo, hi, _ = self.buckets[b]
+                    if self.grad_dtype is not None:              # unpack the reduced bf16 slice into the f32 arena
+                        self.flat_g[lo:hi].copy_(self.pack[lo:hi])
                     if not self.use_avg and self.world > 1:      # host tensors over gloo (the device paths divide in _launch)
-                        lo, hi, _ = self.buckets[b]
                         self.flat_g[lo:hi].div_(self.world)
         self.dirty = False
         self.reset()
@@ -212,7 +278,7 @@ class DistributedDataParallel(nn.Module):
     """Minimal DDP surface used by main_pretrain.py (`.module`, forward passthrough, `no_sync`)."""
 
     def __init__(self, module, device_ids=None, find_unused_parameters=False, bucket_cap_mb=32.0, process_group=None, force_comm=False,
-                 tail_bucket_mb=8.0, tail_span_mb=32.0, **_ignored):
+                 tail_bucket_mb=8.0, tail_span_mb=32.0, grad_dtype=None, **_ignored):
         super().__init__()
         self.module = module
         arena = module.prepare()
@@ -233,7 +299,7 @@ class DistributedDataParallel(nn.Module):
             hip_ops.set_option("p8_wgrad_reserve_cus", int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")))
             hip_ops.set_option("q8_bwd_grid", int(os.environ.get("ECAMP_DDP_Q8_BWD_GRID", str(1 << 20))))
         self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group, force_comm,
-                                   tail_bucket_mb=tail_bucket_mb, tail_span_mb=tail_span_mb)
+                                   tail_bucket_mb=tail_bucket_mb, tail_span_mb=tail_span_mb, grad_dtype=grad_dtype)
         arena.on_ready = self.reducer.mark_ready
         arena.reducer = self.reducer   # the loss scaler and the optimizer find it here
 

@@ -24,9 +24,6 @@ typedef struct ihipStream_t* ecampStream_t; /* == hipStream_t */
 #define ECAMP_BF16 1
 
 int ecamp_abi_version(void);
-/* development aid (tools/hog_probe.py): `blocks` workgroups spinning for `cycles` shader clocks on `stream` -- a stand-in for a
- * communication kernel sharing the GPU with the training step; no reference counterpart */
-int ecamp_dev_spin(int32_t blocks, int32_t threads, int64_t cycles, ecampStream_t stream);
 const char* ecamp_last_error(void);
 
 /* ---- dense contractions -------------------------------------------------------------------------------------
@@ -37,8 +34,8 @@ const char* ecamp_last_error(void);
  * their autograd dgrad/wgrad.  Epilogue: +bias[n]; save pre-activation; exact-erf GELU; *gelu'(gmul[m,n]);
  * +residual[m,n].  out_f32/accumulate: f32 output added into C (weight gradients).  split_k > 1: the contraction is cut
  * into slabs written to `splitk_ws` (split_k*M*N floats) and combined by a deterministic reduce kernel (no atomics).
- * rowsum (optional, f32 [M]): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient, computed inside the wgrad GEMM by one
- * extra MFMA against an all-ones fragment instead of a separate pass over dY. */
+ * rowsum (optional, f32 [M]): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient, computed inside the wgrad GEMM from the
+ * M-side fragments it already holds (v_dot2c_f32_bf16 sums placed between the MFMAs) instead of a separate pass over dY. */
 int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int a_kc, int64_t lda, int b_kc,
                int64_t ldb, int64_t ldc, const float* bias, const void* residual, int64_t ldr, void* pre_out, int64_t ldp,
                const void* gmul, int64_t ldg, int act, float alpha, const float* alpha_dev, int dtype, int out_f32, int accumulate,
@@ -66,8 +63,6 @@ int ecamp_wgrad_group_workgroups(int32_t workgroups);
 int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* const* x, float* const* gw, float* const* gb, const int64_t* n_out,
                       const int64_t* k_in, int64_t rows, float alpha, const float* alpha_dev, const int32_t* accumulate, float* ws,
                       const void* table, int32_t workgroups, ecampStream_t stream);
-/* development aid: grouped launches issued so far (tests assert that the grouped path really ran) */
-int64_t ecamp_wgrad_group_launches(void);
 /* Workspace sizes (bytes) the caller allocates and passes in -- the library never allocates:
  *   ecamp_gemm_workspace_bytes      `splitk_ws` of ecamp_gemm for this split count (0 when split_k <= 1)
  *   ecamp_attn_bwd_workspace_bytes  `delta_ws` of ecamp_attn_bwd (one f32 per query row)
@@ -84,11 +79,9 @@ int64_t ecamp_sr_bwd_workspace_bytes(void);
  * set by the data-parallel wrapper as well. */
 int ecamp_set_option(const char* name, int32_t value);
 /* "q8_mode" (ecamp_set_option): -1 automatic (default), 0 never, 2 whenever its alignment / size conditions hold -- the
- * persistent 256x256x64 kernel (csrc/gemm_q8.h) that serves the forward, data-gradient and weight-gradient forms.
- * Development aid: number of GEMM calls the library has routed to that kernel so far (tests assert that it really ran). */
+ * persistent 256x256x64 kernel (csrc/gemm_q8.h) that serves the forward, data-gradient and weight-gradient forms. */
 /* "attn_head" (ecamp_set_option): 1 (default; env ECAMP_ATTN_HEAD) one workgroup per (batch, head) with everything resident in LDS
  * for sequences that fit (<= 256 tokens here), 0 the 64-row streaming kernels for every length, -1 back to the environment's choice */
-int64_t ecamp_gemm_q8_launches(void);
 
 /* ---- fp8 forward (BASELINE.json configs[4]: "fp8 MFMA forward (bf16 grads) for QKV/MLP GEMMs"; no reference counterpart -- the
  * reference runs these nn.Linear layers under torch.cuda.amp, main_pretrain.py:138).  Per-tensor scaling, OCP e4m3:
@@ -229,6 +222,18 @@ int ecamp_prof_collect(int category, double* total_ms, double* total_work, int64
 /* event pairs the timing facility currently holds: bounded (a pool of 4096 pairs whose finished records are folded into running
  * totals), however many steps run under `main_pretrain.py --profile` */
 int64_t ecamp_prof_live_events(void);
+
+/* ---- development ABI: NOT part of the drop-in boundary.  A C consumer sees these only with -DECAMP_DEV_ABI; the library always
+ * exports them and the Python binding (which parses this header) binds them for tests/ and tools/ only.  No reference counterpart.
+ *   ecamp_dev_spin              `blocks` workgroups spinning for `cycles` shader clocks on `stream` (tools/hog_probe.py: a stand-in
+ *                               for a communication kernel sharing the GPU with the training step)
+ *   ecamp_gemm_q8_launches      GEMM calls routed to the persistent 256x256x64 kernel so far (tests assert that it really ran)
+ *   ecamp_wgrad_group_launches  grouped weight-gradient launches issued so far (tests assert that the grouped path really ran) */
+#ifdef ECAMP_DEV_ABI
+int ecamp_dev_spin(int32_t blocks, int32_t threads, int64_t cycles, ecampStream_t stream);
+int64_t ecamp_gemm_q8_launches(void);
+int64_t ecamp_wgrad_group_launches(void);
+#endif
 
 #ifdef __cplusplus
 }
