@@ -123,6 +123,7 @@ def launch_ranks(cmd, n, poll_s=0.2, grace_s=5.0, check_devices=True, limit_s=No
     silent.  Returns 0 when every rank exited 0."""
     import tempfile
     import threading
+    from ecamp_amd.parallel import rccl_env_defaults
     if limit_s is None:
         limit_s = float(os.environ.get("ECAMP_BENCH_LIMIT_S", "1500"))
     if check_devices:
@@ -141,8 +142,7 @@ def launch_ranks(cmd, n, poll_s=0.2, grace_s=5.0, check_devices=True, limit_s=No
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.setdefault("OMP_NUM_THREADS", str(min(threads, 32)))
-        for k, v in RCCL_ENV_DEFAULTS.items():
-            env.setdefault(k, v)
+        rccl_env_defaults(env)   # the channel cap etc. (ecamp_amd/parallel.py); an explicit NCCL_* setting wins
         log = tempfile.TemporaryFile(mode="w+")
         logs.append(log)
         pr = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True, bufsize=1)
@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--image-u8", action="store_true", help="compact image schema: uint8 [B,448,448] grayscale crops (51 MB per 256 pairs over PCIe instead "
                     "of 616 MB of f32 [B,3,448,448]); the default stays the reference's f32 schema")
+    ap.add_argument("--grad-dtype", default=os.environ.get("ECAMP_DDP_GRAD_DTYPE", "f32"), choices=["f32", "bf16"],
+                    help="payload of the gradient all-reduce at N > 1 (f32 = the reference's; bf16 halves the bytes on the links)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--only-value", action="store_true", help="time the K steps of `value` and nothing else (kernel traces of the production step)")
@@ -228,21 +230,28 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_log = None
     if world > 1:
+        from ecamp_amd.parallel import rccl_env_defaults
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        rccl_env_defaults()   # the driver launches the ranks through torch.distributed.run, not through launch_ranks: set the caps here too
+        if rank == 0 and "NCCL_DEBUG" not in os.environ:   # RCCL's own account of its channels, for the `rccl` record
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), "ecamp_rccl_%d.log" % os.getpid())
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=rccl_log)
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     from ecamp_amd import _lib, optim
     from ecamp_amd.data import synthetic_batch
     from ecamp_amd.module import model_ecamp
-    from ecamp_amd.parallel import DistributedDataParallel
+    from ecamp_amd.parallel import DistributedDataParallel, rccl_env_record
     from ecamp_amd.util.misc import NativeScalerWithGradNormCount
 
     torch.manual_seed(42 + rank)  # main_pretrain.py:189
     cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = model_ecamp.ecamp(compute_dtype=cd).to(dev)
     model.prepare()
-    net = DistributedDataParallel(model) if world > 1 else model
+    net = DistributedDataParallel(model, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None) if world > 1 else model
     opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
     scaler = NativeScalerWithGradNormCount()
     from ecamp_amd.data import DevicePrefetcher
@@ -292,11 +301,13 @@ def main():
     if world > 1:
         red = net.reducer
         rccl = {"world": world, "backend": dist.get_backend(), "buckets": len(red.buckets), "bucket_mb": round(max(hi - lo for lo, hi, _ in red.buckets) * 4 / 2 ** 20, 1),
-                "payload_mb_per_step": round(red.flat_g.numel() * 4 / 2 ** 20, 1), "op": "AVG" if red.use_avg else "SUM+div",
+                "payload_mb_per_step": round(red.payload_bytes() / 2 ** 20, 1), "payload_dtype": "bf16" if red.grad_dtype is not None else "f32",
+                "op": "AVG" if red.use_avg else "SUM+div",
                 "tail_bucket_mb": round((red.buckets[-1][1] - red.buckets[-1][0]) * 4 / 2 ** 20, 1),
                 "p8_wgrad_reserve_cus": int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")),
                 "q8_bwd_grid": int(os.environ.get("ECAMP_DDP_Q8_BWD_GRID", str(1 << 20))),
                 "allreduce_ms_per_step": round(red.comm_ms() / args.steps, 3),
+                "channels": rccl_env_record(rccl_log),
                 "adamw": "bucket by bucket behind each bucket's all-reduce (%d of %d optimizer steps)" % (opt.bucketwise_steps, opt._step),
                 "note": "all-reduce of the f32 gradient arena in buckets on a side HIP stream, overlapped with backward; ms = sum of the "
                         "buckets' event-bracketed durations on that stream on rank 0 (they overlap compute, so this is not added step time)"}

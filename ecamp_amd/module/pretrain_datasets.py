@@ -11,6 +11,8 @@ Same constructor, same item tuple, same batch dict schema (:228-237).
 """
 import os
 import random
+
+import numpy as np
 from typing import List, Tuple
 
 import torch
@@ -271,8 +273,18 @@ def measure_item_rate(dataset, seconds=2.0, max_items=256):
     masking arithmetic): what `--num_workers` has to be multiplied with to feed a GPU.  At ~6.8 k pairs/s per MI355X a node of
     eight needs ~55 k items/s; main_pretrain.py prints this figure next to the step rate so that a loader-bound run is visible."""
     import time
-    t0, n = time.time(), 0
-    while n < max_items and (n < 4 or time.time() - t0 < seconds):
-        dataset[n % len(dataset)]
-        n += 1
-    return n / max(time.time() - t0, 1e-9)
+    # The probe runs a wall-clock-bounded number of items, and every item draws from Python's `random` (text masking), torch's global
+    # generator (crop / flip) and possibly numpy's: without the save / restore below, the state those generators are in when the model
+    # is initialised and the loader is built would depend on how fast this machine is -- and a fixed --seed would no longer fix the
+    # run (the reference derives item stream and initialisation from the seed alone, main_pretrain.py:188-191).
+    state = (random.getstate(), torch.get_rng_state(), np.random.get_state())
+    try:
+        t0, n = time.time(), 0
+        while n < max_items and (n < 4 or time.time() - t0 < seconds):
+            dataset[n % len(dataset)]
+            n += 1
+        return n / max(time.time() - t0, 1e-9)
+    finally:
+        random.setstate(state[0])
+        torch.set_rng_state(state[1])
+        np.random.set_state(state[2])

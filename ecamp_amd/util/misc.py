@@ -207,6 +207,8 @@ def init_distributed_mode(args):
     kw = {}
     if use_gpu:
         kw["device_id"] = torch.device("cuda", args.gpu)
+        from ..parallel import rccl_env_defaults
+        rccl_env_defaults()   # RCCL's channel (= workgroup) cap beside the backward pass; an explicit NCCL_* setting wins
     dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size, rank=args.rank, **kw)
     dist.barrier()
     setup_for_distributed(args.rank == 0)

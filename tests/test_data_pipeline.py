@@ -126,4 +126,10 @@ def test_uint8_image_item_is_the_f32_item_before_normalisation():
         def __getitem__(self, i):
             return default_image_transform(64, image_u8=True)(img)
 
+    import random
+    import numpy as np
+    random.seed(7); torch.manual_seed(7); np.random.seed(7)
+    before = (random.getstate(), torch.get_rng_state().clone(), np.random.get_state()[1].copy())
     assert measure_item_rate(Fake(), seconds=0.2, max_items=16) > 0
+    # the probe runs a machine-speed-dependent number of items; it must leave every generator where it found it
+    assert random.getstate() == before[0] and torch.equal(torch.get_rng_state(), before[1]) and (np.random.get_state()[1] == before[2]).all()

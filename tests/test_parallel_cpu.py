@@ -46,11 +46,27 @@ def _worker(rank, world, port, q):
         red2.mark_ready([0, 1, 2, 4, 5])  # arbitrary order
         red2.finalize()
         ok3 = torch.allclose(g2, torch.full((n,), sum(range(1, world + 1)) / world))
+        # bf16 gradient exchange (grad_dtype=torch.bfloat16): a bucket travels as bf16 (half the bytes) and lands back in the f32 arena
+        # within bf16 rounding of the exact mean (contract: 1e-2 relative); the f32 default stays EXACTLY today's in-place path
+        torch.manual_seed(3)
+        base = torch.randn(n) * 3.0
+        g3 = base * (rank + 1)
+        g3_f32 = g3.clone()
+        red3 = GradReducer(g3, offs, sizes, unused=[3], bucket_mb=64 * 8 * 4 / 2 ** 20, grad_dtype=torch.bfloat16)
+        red3.mark_ready([5, 4, 2, 1, 0])
+        red3.finalize()
+        red3f = GradReducer(g3_f32, offs, sizes, unused=[3], bucket_mb=64 * 8 * 4 / 2 ** 20, grad_dtype=torch.float32)
+        assert red3f.grad_dtype is None and red3f.payload_bytes() == 2 * red3.payload_bytes()
+        red3f.mark_ready([5, 4, 2, 1, 0])
+        red3f.finalize()
+        exact = base * (sum(range(1, world + 1)) / world)
+        ok5 = bool(torch.equal(g3_f32, exact)) and bool(((g3 - exact).norm() / exact.norm()) < 1e-2) and not torch.equal(g3, g3_f32) \
+            and g3.dtype == torch.float32 and red3.pack.dtype == torch.bfloat16
         # lazy logging all-reduce used by train_one_epoch
         from ecamp_amd.util import misc
         r = misc.all_reduce_mean(torch.tensor([1.0 * rank, 2.0, 3.0]))
         ok4 = torch.allclose(r, torch.tensor([(world - 1) / 2.0, 2.0, 3.0]))
-        q.put((rank, ok1, ok2, ok3, ok4))
+        q.put((rank, ok1, ok2, ok3, ok4, ok5))
     finally:
         dist.destroy_process_group()
 
@@ -103,3 +119,28 @@ def test_bucket_plan_closes_before_a_large_tensor_and_keeps_the_tail_small():
     # the old call (no tail arguments) still gives plain capped buckets
     red2 = GradReducer(_Flat(), offs, sizes, bucket_mb=64.0)
     assert sum(hi - lo for lo, hi, _ in red2.buckets) == sum(sizes) and all(hi - lo <= 64 * mib or len(sl) == 1 for lo, hi, sl in red2.buckets)
+
+
+def test_rccl_env_defaults_cap_the_channels_and_respect_explicit_settings():
+    """bench.py / init_distributed_mode setdefault() RCCL's channel cap (below the co-tenancy cliff of
+    profiles/r03_cotenant_ab.txt); a user's explicit NCCL_MAX_NCHANNELS wins; the `rccl` record reports what is in force and parses the
+    channel count out of an RCCL INFO log when there is one."""
+    import tempfile
+    from ecamp_amd.parallel import RCCL_ENV_DEFAULTS, rccl_env_defaults, rccl_env_record
+    env = rccl_env_defaults({})
+    assert env["NCCL_MAX_NCHANNELS"] == RCCL_ENV_DEFAULTS["NCCL_MAX_NCHANNELS"] and 0 < int(env["NCCL_MAX_NCHANNELS"]) < 96
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert rccl_env_defaults({"NCCL_MAX_NCHANNELS": "8"})["NCCL_MAX_NCHANNELS"] == "8"
+    with tempfile.NamedTemporaryFile("w", suffix=".log", delete=False) as f:
+        f.write("host:1:1 [0] NCCL INFO Channel 00/24 : 0 1 2 3\nhost:1:1 [0] NCCL INFO 24 coll channels, 24 collnet channels, 0 nvls channels, 32 p2p channels\n")
+    old = os.environ.get("NCCL_MAX_NCHANNELS")
+    os.environ["NCCL_MAX_NCHANNELS"] = "32"
+    try:
+        rec = rccl_env_record(f.name)
+    finally:
+        if old is None:
+            del os.environ["NCCL_MAX_NCHANNELS"]
+        else:
+            os.environ["NCCL_MAX_NCHANNELS"] = old
+        os.unlink(f.name)
+    assert rec["channels_reported"] == 24 and rec["max_channels_cap"] == 32 and rec["env"]["NCCL_MAX_NCHANNELS"] == "32" and rec["channel_lines"]
