@@ -546,7 +546,22 @@ static int q8_epi(const float* bias, const void* residual, const void* pre_out, 
 static long g_q8_launches = 0;
 extern "C" int64_t ecamp_gemm_q8_launches(void) { return g_q8_launches; }
 typedef void (*q8_fn)(GemmArgs);
+// "q8_sch" (development A/B; env ECAMP_Q8_SCH): bit 0 forward form, bit 1 data-gradient form, bit 2 weight-gradient form, bit 3 the
+// grouped weight gradients on the lean stream (gemm_q8.h SCH = 1) instead of the round-3 stream
+static int g_q8_sch = -1;
+static int q8_sch() {
+    static const int v = getenv("ECAMP_Q8_SCH") ? atoi(getenv("ECAMP_Q8_SCH")) : 7;
+    return g_q8_sch >= 0 ? g_q8_sch : v;
+}
 static q8_fn q8_pick(int a_kc, int b_kc, int epi, bool rowsum) {
+    const int sch = q8_sch();
+#define Q8S(A, B, E, R) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, R, 1>)
+    if (a_kc && b_kc && (sch & 1)) return epi == 0 ? Q8S(true, true, 0, false) : epi == 1 ? Q8S(true, true, 1, false) : epi == 2 ? Q8S(true, true, 2, false) : (q8_fn) nullptr;
+#define Q8D(E) ((q8_fn)gemm_bf16_q8_kernel<true, false, E, 0, false, 2>)
+    if (a_kc && !b_kc && (sch & 2)) return epi == 0 ? Q8D(0) : epi == 2 ? Q8D(2) : epi == 3 ? Q8D(3) : (q8_fn) nullptr;
+#undef Q8D
+    if (!a_kc && !b_kc && epi == 4 && (sch & 4)) return rowsum ? Q8S(false, false, 4, true) : Q8S(false, false, 4, false);
+#undef Q8S
     if (a_kc && b_kc) return epi == 0 ? gemm_bf16_q8_kernel<true, true, 0> : epi == 1 ? gemm_bf16_q8_kernel<true, true, 1> : epi == 2 ? gemm_bf16_q8_kernel<true, true, 2> : (q8_fn) nullptr;
     if (a_kc && !b_kc) return epi == 0 ? gemm_bf16_q8_kernel<true, false, 0> : epi == 2 ? gemm_bf16_q8_kernel<true, false, 2> : epi == 3 ? gemm_bf16_q8_kernel<true, false, 3> : (q8_fn) nullptr;
     if (!a_kc && !b_kc && epi == 4) return rowsum ? gemm_bf16_q8_kernel<false, false, 4, 0, true> : gemm_bf16_q8_kernel<false, false, 4, 0, false>;
@@ -584,6 +599,7 @@ extern "C" int ecamp_set_option(const char* name, int32_t value) {
     if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
     if (strcmp(name, "q8_bwd_grid") == 0) { g_q8_bwd_grid = value < 0 ? 0 : value; return 0; }
+    if (strcmp(name, "q8_sch") == 0) { g_q8_sch = value; return 0; }
     if (strcmp(name, "attn_head") == 0) { attn_set_head_mode(value); return 0; }   // attention_bf16.hip: 1 head kernels (default), 0 streaming kernels
     return ecamp_set_error(-1, "set_option: unknown option '%s'", name);
 }
@@ -986,18 +1002,20 @@ extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* c
     g.A = dy[0]; g.B = x[0]; g.C = ws; g.M = (int)n_out[0]; g.N = (int)k_in[0]; g.K = (int)rows; g.lda = n_out[0]; g.ldb = k_in[0]; g.ldc = k_in[0];
     g.out_f32 = 1; g.alpha = 1.0f; g.alpha_out = alpha; g.nbm = 1; g.nbn = 1; g.nsplit = 1; g.k_per_split = (int)rows; g.wide = 1; g.partial = ws;
     const size_t shm = 10 * Q8_HALF;
-    static bool attr[2] = {false, false};
-    if (!attr[any_bias]) {
-        if (any_bias) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_q8_items_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_q8_items_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr[any_bias] = true;
+    typedef void (*q8i_fn)(GemmArgs, Q8Group);
+    const bool lean = (q8_sch() & 8) != 0;
+    const q8i_fn fn = any_bias ? (lean ? (q8i_fn)gemm_bf16_q8_items_kernel<true, 2> : (q8i_fn)gemm_bf16_q8_items_kernel<true, 0>)
+                               : (lean ? (q8i_fn)gemm_bf16_q8_items_kernel<false, 2> : (q8i_fn)gemm_bf16_q8_items_kernel<false, 0>);
+    static bool attr[4] = {false, false, false, false};
+    if (!attr[any_bias + 2 * lean]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr[any_bias + 2 * lean] = true;
     }
     double work = 0.0;
     for (int p = 0; p < n; ++p) work += 2.0 * (double)n_out[p] * (double)k_in[p] * (double)rows;
     const bool prof = ecamp_prof_active();
     if (prof) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, work, stream);
-    if (any_bias) hipLaunchKernelGGL(gemm_bf16_q8_items_kernel<true>, dim3(pl->nwg), dim3(512), shm, stream, g, G);
-    else hipLaunchKernelGGL(gemm_bf16_q8_items_kernel<false>, dim3(pl->nwg), dim3(512), shm, stream, g, G);
+    hipLaunchKernelGGL(fn, dim3(pl->nwg), dim3(512), shm, stream, g, G);
     g_q8_launches += n;
     ++g_wg_launches;
     hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(pl->ntiles * 16), dim3(256), 0, stream, R);

@@ -61,6 +61,12 @@ __device__ __forceinline__ Q8Item q8_decode(const GemmArgs& g, int v, int total)
     it.kbeg = (int)z * g.k_per_split;
     it.kend = min(g.K, it.kbeg + g.k_per_split);
     it.nt = (it.kend - it.kbeg + 63) >> 6;
+    // the divisions above run on the VALU (v_rcp) and come back through v_readfirstlane; naming every result a scalar HERE keeps hipcc
+    // from moving the whole chain behind them (pointers, record counts: the buffer descriptors) into VGPRs, which costs a waterfall
+    // loop around every DMA instruction (cdna_hip_programming.md T20)
+    it.m0 = __builtin_amdgcn_readfirstlane(it.m0); it.n0 = __builtin_amdgcn_readfirstlane(it.n0); it.z = __builtin_amdgcn_readfirstlane(it.z);
+    it.ncol = __builtin_amdgcn_readfirstlane(it.ncol); it.kbeg = __builtin_amdgcn_readfirstlane(it.kbeg);
+    it.kend = __builtin_amdgcn_readfirstlane(it.kend); it.nt = __builtin_amdgcn_readfirstlane(it.nt);
     return it;
 }
 
@@ -149,7 +155,12 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
 // fragments by the first wave column of the tiles in the first N-tile column, added with 4 buffer atomics per wave and tile.
 // ITEMS (weight-gradient form only): the work items come from a table (Q8Group, gemm_args.h) instead of the tile x split arithmetic;
 // operands and leading dimensions change with the item's problem, every piece stores a dense f32 slab.
-template <bool A_KC, bool B_KC, int EPI, int DBG, bool ROWSUM, bool ITEMS>
+// SCH: 0 = the round-3 stream (descriptors rebuilt per half-tile, bookkeeping in the load interval; the data-gradient and item-table
+// forms), 1 = lean stream (the forward and weight-gradient forms).  Measured and removed again (profiles/r04_gemm_lab_sch.txt): the DMA
+// issue in the matrix interval as well (= sch 0), and wave-specialised producers -- 8 consumer + 4 producer waves, the whole operand
+// stream in waves of its own (tools/probes/gemm_producer_waves_fragment.hip.txt) -- which is within 3 % of this kernel on every shape:
+// the loop waits for the DATA (the L2 -> LDS path beside a power-limited MFMA stream), not for whoever issues the loads.
+template <bool A_KC, bool B_KC, int EPI, int DBG, bool ROWSUM, bool ITEMS, int SCH = 0>
 __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     static_assert(!ITEMS || (!A_KC && !B_KC && EPI == 4 && DBG == 0), "the item-table form is the weight-gradient form");
     static_assert(!ROWSUM || (!A_KC && !B_KC && EPI == 4), "rowsum is built for the weight-gradient form");
@@ -171,7 +182,10 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     Q8_PROB_FIELD(alpha_out); Q8_PROB_FIELD(alpha_dev_out);
 #undef Q8_PROB_FIELD
     float* const gr_slabs = GR.slabs;
-#define Q8_PROB(P_, F) ((P_) == 0 ? gp0_##F : (P_) == 1 ? gp1_##F : (P_) == 2 ? gp2_##F : gp3_##F)
+    // (prvalues on purpose: inside a by-reference lambda a ?: over the NAMES is a select between their addresses, and the four values
+    // end up as a table in scratch that every item set-up loads from)
+#define Q8_VAL_(X) static_cast<std::decay_t<decltype(X)>>(X)
+#define Q8_PROB(P_, F) ((P_) == 0 ? Q8_VAL_(gp0_##F) : (P_) == 1 ? Q8_VAL_(gp1_##F) : (P_) == 2 ? Q8_VAL_(gp2_##F) : Q8_VAL_(gp3_##F))
     auto item_at = [&](int i) {   // record i of the table, through scalar loads (constant address space, wave-uniform index)
         typedef int q8_i32x8 __attribute__((ext_vector_type(8)));
         typedef const q8_i32x8 __attribute__((address_space(4))) crec4;
@@ -288,6 +302,97 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
 #define Q8_STAGE_PART(PART) Q8_STAGE_PCS(PART, 3)
     // every DMA of mine has landed, except that the `N_` youngest vector-memory operations (issued after it) may be pending
 #define Q8_WAIT_DMA(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
+
+    // ---- LEAN STREAM (SCH >= 1; round 4).  Counter evidence (profiles/r04_vendor_vs_q8_pmc.txt): the load interval of a phase is the
+    // critical path -- the multiplying wave row waits at the barrier for the loading row, 37-49 % of all wave-cycles are parked -- and two
+    // thirds of its instructions were bookkeeping (3.3x the vendor kernel's SALU, 6x its barrier / wait instructions per tile step).  So:
+    //  * ONE descriptor per operand, valid for both half-tiles (the second half-tile is a per-lane offset), ADVANCED per K tile (two adds,
+    //    a clamped subtract) instead of rebuilt per half-tile;
+    //  * ring positions are LDS byte offsets (wave piece folded in): M0 is one move;
+    //  * no `pdone` tests: an exhausted stream keeps issuing through a descriptor of ZERO records -- nothing is fetched, the slots it
+    //    zero-fills have been consumed (same ring discipline), every counted wait keeps its count, and the kernel drains them before it ends;
+    //  * the partial-K lane mask is folded into the per-lane offsets when the stream enters / leaves a tail K tile (twice per item at
+    //    most), not evaluated in every part;
+    //  * every piece of bookkeeping -- ring advance, descriptor advance, item decodes (a division chain) -- runs in the MATRIX interval,
+    //    between the MFMAs, where 7 of 8 issue slots are free; the load interval is six fragment reads, two DMA instructions, the waits.
+    // (the data-gradient form -- one strided operand, twelve transpose reads per phase: its matrix interval is the longer one -- keeps
+    // the bookkeeping in the load interval, behind the DMA issue: SCH = 2)
+    constexpr bool ADV_MX = SCH != 2;
+    const unsigned char *qa = reinterpret_cast<const unsigned char*>(A), *qb = reinterpret_cast<const unsigned char*>(B);
+    int qa_rec = 0, qb_rec = 0, q_krem = 1 << 30, qv = it_beg;
+    bool q_tail = false;
+    unsigned cvA[4] = {0u, 0u, 0u, 0u}, cvB[4] = {0u, 0u, 0u, 0u};   // per-lane source offsets [half * 2 + piece]
+    int dA = wave * 1024, dB = NSLOT * Q8_HALF + wave * 1024;         // LDS byte offset the next A / B half-tile (this wave's first piece) goes to
+    long q_lda = ITEMS ? -1 : g.lda, q_ldb = ITEMS ? -1 : g.ldb;
+    auto q_cv = [&](bool tail) __attribute__((always_inline)) {   // (re)build the per-lane offsets for the current leading dimensions; tail: lanes past q_krem read as zero
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            cvA[i] = q8_voff<A_KC>(i, wave, lane, q_lda); cvA[2 + i] = cvA[i] + (unsigned)(A_KC ? q_lda * 256 : 256);
+            cvB[i] = q8_voff<B_KC>(i, wave, lane, q_ldb); cvB[2 + i] = cvB[i] + (unsigned)(B_KC ? q_ldb * 256 : 256);
+        }
+        if ((A_KC || B_KC) && tail) {
+            const int kc0 = (lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7);   // same key for all four pieces (they lie 64 / 128 rows apart)
+            if (kc0 * 8 >= q_krem) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { if (A_KC) cvA[i] = 0xFFFFFF00u; if (B_KC) cvB[i] = 0xFFFFFF00u; }
+            }
+        }
+    };
+    // the stream enters item qv.  (A macro, not a lambda: inside a by-reference lambda the Q8_PROB selects become selects between the
+    // ADDRESSES of the captured values, and the argument block ends up as a table in scratch that every item set-up loads from.)
+#define Q9_ITEM()                                                                                                        \
+    do {                                                                                                                 \
+        if (ITEMS) {                                                                                                     \
+            const Q8ItemRec r_ = item_at(qv);                                                                            \
+            const long la_ = Q8_PROB(r_.prob, lda), lb_ = Q8_PROB(r_.prob, ldb);                                         \
+            const bf16_t* A_ = reinterpret_cast<const bf16_t*>(uniform_ptr(Q8_PROB(r_.prob, A)));                        \
+            const bf16_t* B_ = reinterpret_cast<const bf16_t*>(uniform_ptr(Q8_PROB(r_.prob, B)));                        \
+            q_krem = r_.kend - r_.kbeg;                                                                                  \
+            qa = (const unsigned char*)(A_ + ((long)r_.kbeg * la_ + r_.m0)); qa_rec = (int)(((long)q_krem * la_ - r_.m0) * 2); \
+            qb = (const unsigned char*)(B_ + ((long)r_.kbeg * lb_ + r_.n0)); qb_rec = (int)(((long)q_krem * lb_ - r_.n0) * 2); \
+            a_step = (int)la_ * 128; b_step = (int)lb_ * 128;                                                            \
+            if (la_ != q_lda || lb_ != q_ldb) { q_lda = la_; q_ldb = lb_; q_cv(false); }                                 \
+        } else {                                                                                                         \
+            const Q8Item n_ = q8_decode(g, qv, total);                                                                   \
+            q_krem = n_.kend - n_.kbeg;                                                                                  \
+            if (A_KC) { qa = (const unsigned char*)(A + ((long)n_.m0 * g.lda + n_.kbeg)); qa_rec = (int)((((long)(g.M - n_.m0)) * g.lda - n_.kbeg) * 2); } \
+            else      { qa = (const unsigned char*)(A + ((long)n_.kbeg * g.lda + n_.m0)); qa_rec = (int)(((long)q_krem * g.lda - n_.m0) * 2); }             \
+            if (B_KC) { qb = (const unsigned char*)(B + ((long)n_.n0 * g.ldb + n_.kbeg)); qb_rec = (int)((((long)(g.N - n_.n0)) * g.ldb - n_.kbeg) * 2); } \
+            else      { qb = (const unsigned char*)(B + ((long)n_.kbeg * g.ldb + n_.n0)); qb_rec = (int)(((long)q_krem * g.ldb - n_.n0) * 2); }             \
+        }                                                                                                                \
+        qa_rec = max(qa_rec, 0); qb_rec = max(qb_rec, 0);                                                                \
+    } while (0)
+    // issue the two DMA instructions of part PART (0: A half 0, 1: B half 0, 2: A half 1, 3: B half 1) of the K tile being staged
+#define Q9_ISSUE(PART)                                                                                                   \
+    do {                                                                                                                 \
+        if (!(DBG & 2)) {                                                                                                \
+            typedef void __attribute__((address_space(3))) lds_void_;                                                    \
+            constexpr bool isA_ = (((PART) & 1) == 0);                                                                   \
+            constexpr int h_ = (PART) >> 1;                                                                              \
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(isA_ ? qa : qb), 0, isA_ ? qa_rec : qb_rec, 0x00020000); \
+            unsigned char* d_ = lds + (isA_ ? dA : dB);                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void_*)d_, 16, (int)(isA_ ? cvA[2 * h_] : cvB[2 * h_]), 0, 0, 0);               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void_*)(d_ + 8192), 16, (int)(isA_ ? cvA[2 * h_ + 1] : cvB[2 * h_ + 1]), 0, 0, 0); \
+        }                                                                                                                \
+    } while (0)
+    // the bookkeeping behind part PART: ring position; behind part 3 the stream moves on one K tile (and, at an item's end, one item)
+#define Q9_ADVANCE(PART)                                                                                                 \
+    do {                                                                                                                 \
+        if (((PART) & 1) == 0) { dA += Q8_HALF; if (dA >= NSLOT * Q8_HALF) dA -= NSLOT * Q8_HALF; }                      \
+        else                   { dB += Q8_HALF; if (dB >= 2 * NSLOT * Q8_HALF) dB -= NSLOT * Q8_HALF; }                  \
+        if ((PART) == 3) {                                                                                               \
+            q_krem -= 64;                                                                                                \
+            if (!(DBG & 64)) { qa += a_step; qb += b_step; qa_rec = max(qa_rec - a_step, 0); qb_rec = max(qb_rec - b_step, 0); } \
+            if (q_krem <= 0) {                                                                                           \
+                qv += G;                                                                                                 \
+                if (qv < total) Q9_ITEM(); else { qa_rec = 0; qb_rec = 0; q_krem = 1 << 30; }                             \
+            }                                                                                                            \
+            if (A_KC || B_KC) {                                                                                          \
+                const bool tl_ = q_krem < 64;                                                                            \
+                if (tl_ != q_tail) { q_tail = tl_; q_cv(tl_); }                                                          \
+            }                                                                                                            \
+        }                                                                                                                \
+    } while (0)
 
     Q8Frag<A_KC> xm[4];                               // the fragments of one phase (a k-step of 16): 4 M-side + 2 N-side
     Q8Frag<B_KC> xn[2];
@@ -546,14 +651,65 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
     } while (0)
 
+    // ---- the lean-stream phase: [load interval: six fragment reads, the part's two DMA instructions, the waits] barrier [matrix
+    // interval: MFMA 0-3, the bookkeeping behind the part (and MX_HOOK: the decode of the next output tile), MFMA 4-7] barrier.  The
+    // counted wait of phase 3 covers K tile t+1: in flight behind it are A_0 / B_0 of K tile t+2 (4 instructions).
+#define Q9_PHASE(KS, DPART, WAIT, ZERO, PRE_HOOK, MX_HOOK)                                                              \
+    do {                                                                                                                 \
+        if (PRE_HOOK) {                                                                                                  \
+            if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); } \
+            if (ROWSUM) { if (rsp_on) rowsum_flush(); }                                                                  \
+            Q8_SB();                                                                                                     \
+        }                                                                                                                \
+        Q8_READ_GROUP(xm, xn, sM, sN, KS); Q8_SB();                                                                      \
+        Q9_ISSUE(DPART); Q8_SB();                                                                                        \
+        if (!ADV_MX) { Q9_ADVANCE(DPART); Q8_SB(); }                                                                     \
+        if (WAIT) Q8_WAIT_DMA(4);                                                                                        \
+        if (!A_KC || !B_KC) { q8_wait4(xm); q8_wait2(xn); }                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); Q8_SB();                                                      \
+        if (!(DBG & 16)) __builtin_amdgcn_s_barrier();                                                                   \
+        Q8_SB();                                                                                                         \
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                                                   \
+        Q8_MFMA1(xm, xn, 0, ZERO); Q8_MFMA1(xm, xn, 1, ZERO); Q8_SB();                                                   \
+        Q8_MFMA1(xm, xn, 2, ZERO); Q8_MFMA1(xm, xn, 3, ZERO); Q8_SB();                                                   \
+        if (ADV_MX) Q9_ADVANCE(DPART);                                                                                   \
+        if (MX_HOOK) { if (cv + G < total) Q9_CDECODE(cv + G); }                                                           \
+        Q8_SB();                                                                                                         \
+        if (ROWSUM) { Q8_RS_ACC(xm); }   /* no scheduling fence behind it: the compiler spreads these between the MFMAs */ \
+        Q8_MFMA1(xm, xn, 4, ZERO); Q8_MFMA1(xm, xn, 5, ZERO); Q8_MFMA1(xm, xn, 6, ZERO); Q8_MFMA1(xm, xn, 7, ZERO);      \
+        Q8_SB();                                                                                                         \
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);                                                                   \
+        if (!(DBG & 16)) __builtin_amdgcn_s_barrier();                                                                   \
+        Q8_SB();                                                                                                         \
+    } while (0)
+#define Q9_KTILE(FIRST)                                                                                               \
+    do {                                                                                                                 \
+        const int ra_ = rA + wr, rb_ = rB + (wc >> 1);                                                                   \
+        const unsigned char* sM = lds + (ra_ >= NSLOT ? ra_ - NSLOT : ra_) * Q8_HALF;                                    \
+        const unsigned char* sN = lds + (NSLOT + (rb_ >= NSLOT ? rb_ - NSLOT : rb_)) * Q8_HALF;                          \
+        Q9_PHASE(0, 2, false, FIRST, FIRST, false);                                                                   \
+        Q9_PHASE(1, 3, false, false, false, FIRST);                                                                   \
+        Q9_PHASE(2, 0, false, false, false, false);                                                                   \
+        Q9_PHASE(3, 1, true, false, false, false);                                                                    \
+        rA = rA + 2 >= NSLOT ? rA + 2 - NSLOT : rA + 2;                                                                  \
+        rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
+    } while (0)
+
     if (DBG & 512) {   // probe: workgroups start in four phases ~9 us apart (are the lock-step epilogue bursts of a round the cost?)
         const long long t0 = wall_clock64();   // 100 MHz
         const long long d = (long long)(blockIdx.x & 3) * 900;
         while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
     }
     // prologue: K tile 0 and A_0 / B_0 of K tile 1 issued, K tile 0 landed and published
-    Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
-    Q8_STAGE_PART(0); Q8_STAGE_PART(1);
+    if constexpr (SCH == 0) {
+        Q8_STAGE_PART(0); Q8_STAGE_PART(1); Q8_STAGE_PART(2); Q8_STAGE_PART(3);
+        Q8_STAGE_PART(0); Q8_STAGE_PART(1);
+    } else {
+        if (!ITEMS) q_cv(false);
+        if (qv < total) Q9_ITEM();
+        Q9_ISSUE(0); Q9_ADVANCE(0); Q9_ISSUE(1); Q9_ADVANCE(1); Q9_ISSUE(2); Q9_ADVANCE(2); Q9_ISSUE(3); Q9_ADVANCE(3);
+        Q9_ISSUE(0); Q9_ADVANCE(0); Q9_ISSUE(1); Q9_ADVANCE(1);
+    }
     Q8_WAIT_DMA(4);    // in flight: A_0 and B_0 of the second K tile
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind (wave row 0 makes up for it at the end)
@@ -567,6 +723,38 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     // ---- main loop over this workgroup's output tiles (every tile has at least two K tiles: the host guarantees K/split >= 128)
     bool have_pend = false;
     int pm0 = 0, pn0 = 0, pz = 0;
+    // lean stream: the next output tile is decoded one tile ahead, in a matrix interval of the current tile's first K tile
+    int nm0 = 0, nn0 = 0, nz = 0, ncnt = 0;
+    bool nrs = false;
+#define Q9_CDECODE(V_)                                                                                                   \
+    do {                                                                                                                 \
+        if (ITEMS) {                                                                                                     \
+            const Q8ItemRec cr = item_at(V_);                                                                            \
+            nm0 = cr.m0; nn0 = cr.prob; nz = cr.slab; ncnt = (cr.kend - cr.kbeg + 63) >> 6;                              \
+            if (ROWSUM) nrs = (cr.flags & 1) != 0 && wc == 0 && Q8_PROB(cr.prob, rowsum) != nullptr;                     \
+        } else {                                                                                                         \
+            const Q8Item cit = q8_decode(g, V_, total);                                                                  \
+            nm0 = cit.m0; nn0 = cit.n0; nz = cit.z; ncnt = cit.nt;                                                       \
+            if (ROWSUM) nrs = g.rowsum != nullptr && wc == 0 && cit.ncol == 0;                                           \
+        }                                                                                                                \
+    } while (0)
+    if constexpr (SCH != 0) {
+        if (it_beg < total) Q9_CDECODE(it_beg);
+        for (int cv = it_beg; cv < total; cv += G) {
+            const int cm0 = nm0, cn0 = nn0, cz = nz, cnt = ncnt;
+            if (ROWSUM) { rs_on = nrs; rs_ones = rs_on ? 0x3f803f80u : 0u; }
+            Q9_KTILE(true);
+#pragma unroll 1
+            for (int t = 1; t < cnt; ++t) Q9_KTILE(false);
+            have_pend = true; pm0 = cm0; pn0 = cn0; pz = cz;
+            if (ROWSUM) {
+                rsp_on = rs_on; rsp_m0 = cm0; rsp_prob = cn0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { rsp[t] = rs[t]; rs[t] = 0.f; }
+            }
+        }
+        Q8_WAIT_DMA(0);   // the zero-length loads an exhausted stream keeps issuing still write their (zero) pieces into this workgroup's LDS
+    } else
     for (int cv = it_beg; cv < total; cv += G) {
         int cm0, cn0, cz, cnt;   // ITEMS: cn0 carries the problem index and cz the slab index into the epilogue
         if (ITEMS) {
@@ -601,18 +789,25 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
 #undef Q8_RS_ACC
 #undef Q8_KTILE
 #undef Q8_PHASE
+#undef Q9_KTILE
+#undef Q9_PHASE
+#undef Q9_ISSUE
+#undef Q9_ADVANCE
+#undef Q9_ITEM
+#undef Q9_CDECODE
 #undef Q8_NEXT_ITEM
 #undef Q8_WAIT_DMA
 }
 #undef Q8_PROB
+#undef Q8_VAL_
 
-template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false>
+template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false, int SCH = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     Q8Group none;   // never read in this form
-    q8_body<A_KC, B_KC, EPI, DBG, ROWSUM, false>(g, none);
+    q8_body<A_KC, B_KC, EPI, DBG, ROWSUM, false, SCH>(g, none);
 }
 // grouped weight gradients: `g` only supplies the fields the item-table form does not take from the group (none of the operands)
-template <bool ROWSUM>
+template <bool ROWSUM, int SCH = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_q8_items_kernel(GemmArgs g, Q8Group GR) {
-    q8_body<false, false, 4, 0, ROWSUM, true>(g, GR);
+    q8_body<false, false, 4, 0, ROWSUM, true, SCH>(g, GR);
 }

@@ -5,56 +5,110 @@
 // so no mask tensor is stored; `z = dropout(x) + residual` is written once because backward needs it.
 #include "common.h"
 
-template <typename T, int IT>
+// VEC elements per lane access: 4 (16 B of f32, 8 B of bf16) or, for bf16 rows whose length is a multiple of 8, 8 (16 B -- the
+// streaming optimum of this chip; a 768-column row is 96 such chunks = one full wave access and one half-filled one, instead of three
+// 8-byte ones).  Round 4: the 8-byte form ran at 3 TB/s inside the step (fwd 27.7 us, bwd 31.8 us on 12800 x 768).
+template <typename T, int VEC> struct LnVec;
+template <> struct LnVec<float, 4> {
+    typedef float4 raw_t;
+    static __device__ __forceinline__ void cvt(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ float4 pack(const float (&o)[4]) { return make_float4(o[0], o[1], o[2], o[3]); }
+};
+template <> struct LnVec<bf16_t, 4> {
+    typedef uint2 raw_t;
+    static __device__ __forceinline__ void cvt(const uint2& v, float (&o)[4]) {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint2 pack(const float (&o)[4]) { return make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])); }
+};
+template <> struct LnVec<bf16_t, 8> {
+    typedef uint4 raw_t;
+    static __device__ __forceinline__ void cvt(const uint4& v, float (&o)[8]) {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&o)[8]) {
+        return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    }
+};
+// keep-mask scales of the VEC elements of chunk `c` of a row of `nv` chunks: one Philox call per 4 elements, counters as in the 4-wide form
+template <int VEC>
+__device__ __forceinline__ void ln_dropout(uint64_t seed, uint64_t offset, long row, int nv, int c, float p, float inv_keep, float (&m)[VEC]) {
+#pragma unroll
+    for (int k = 0; k < VEC / 4; ++k) {
+        float s[4];
+        dropout_scale4(seed, offset, (uint64_t)((row * nv + c) * (VEC / 4) + k), p, inv_keep, s);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[4 * k + r] = s[r];
+    }
+}
+
+template <typename T, int IT, int VEC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ zout,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                      long rows, int cols, float eps, float drop_p, uint64_t seed,
                                                      uint64_t offset) {
+    typedef LnVec<T, VEC> V;
+    typedef typename V::raw_t raw_t;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const int nv = cols >> 2;
+    const int nv = cols / VEC;
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    float v[IT][4];
+    // every load of the row is issued before the first value is consumed
+    raw_t rx[IT], rr[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            rx[i] = *reinterpret_cast<const raw_t*>(x + row * cols + c * VEC);
+            if (res) rr[i] = *reinterpret_cast<const raw_t*>(res + row * cols + c * VEC);
+        }
+    }
+    float v[IT][VEC];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        int c = lane + 64 * i;
+        const int c = lane + 64 * i;
         if (c < nv) {
-            ld4<T>(x + row * cols + c * 4, v[i]);
+            V::cvt(rx[i], v[i]);
             if (drop_p > 0.f) {
-                float m[4];
-                dropout_scale4(seed, offset, (uint64_t)(row * nv + c), drop_p, inv_keep, m);
+                float m[VEC];
+                ln_dropout<VEC>(seed, offset, row, nv, c, drop_p, inv_keep, m);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] *= m[r];
+                for (int r = 0; r < VEC; ++r) v[i][r] *= m[r];
             }
             if (res) {
-                float q[4];
-                ld4<T>(res + row * cols + c * 4, q);
+                float q[VEC];
+                V::cvt(rr[i], q);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] += q[r];
+                for (int r = 0; r < VEC; ++r) v[i][r] += q[r];
             }
             if (zout) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] = rnd<T>(v[i][r]);
-                st4<T>(zout + row * cols + c * 4, v[i]);
+                for (int r = 0; r < VEC; ++r) v[i][r] = rnd<T>(v[i][r]);
+                *reinterpret_cast<raw_t*>(zout + row * cols + c * VEC) = V::pack(v[i]);
             }
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+            for (int r = 0; r < VEC; r += 4) s += (v[i][r] + v[i][r + 1]) + (v[i][r + 2] + v[i][r + 3]);
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i][r] = 0.f;
+            for (int r = 0; r < VEC; ++r) v[i][r] = 0.f;
         }
     }
     const float mu = wave_sum(s) / (float)cols;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        int c = lane + 64 * i;
+        const int c = lane + 64 * i;
         if (c < nv) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float d = v[i][r] - mu;
+            for (int r = 0; r < VEC; ++r) {
+                const float d = v[i][r] - mu;
                 q += d * d;
             }
         }
@@ -66,16 +120,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        int c = lane + 64 * i;
+        const int c = lane + 64 * i;
         if (c < nv) {
-            float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
-            float4 b = *reinterpret_cast<const float4*>(beta + c * 4);
-            float o[4];
-            o[0] = (v[i][0] - mu) * rs * g.x + b.x;
-            o[1] = (v[i][1] - mu) * rs * g.y + b.y;
-            o[2] = (v[i][2] - mu) * rs * g.z + b.z;
-            o[3] = (v[i][3] - mu) * rs * g.w + b.w;
-            st4<T>(y + row * cols + c * 4, o);
+            float o[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC / 4; ++k) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c * VEC + 4 * k);
+                const float4 b = *reinterpret_cast<const float4*>(beta + c * VEC + 4 * k);
+                o[4 * k + 0] = (v[i][4 * k + 0] - mu) * rs * g.x + b.x;
+                o[4 * k + 1] = (v[i][4 * k + 1] - mu) * rs * g.y + b.y;
+                o[4 * k + 2] = (v[i][4 * k + 2] - mu) * rs * g.z + b.z;
+                o[4 * k + 3] = (v[i][4 * k + 3] - mu) * rs * g.w + b.w;
+            }
+            *reinterpret_cast<raw_t*>(y + row * cols + c * VEC) = V::pack(o);
         }
     }
 }
@@ -85,50 +142,32 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy: per-lane column partials -> per-wave LDS slices (8 waves at a time) ->
 // one global f32 atomic per column per workgroup.  One 16-wave workgroup per CU: a 12800-row call issues 0.4 M global atomics on
 // the 48 cache lines of dgamma/dbeta instead of the 1.5 M of a 4-wave / 1024-block layout, whose per-line serialisation at L2
-// held the small shapes at 2 TB/s.
-// the 4-element vector of a row as it lies in memory (8 B of bf16 / 16 B of f32), converted when it is consumed
-template <typename T> struct LnRaw;
-template <> struct LnRaw<float> {
-    typedef float4 type;
-    static __device__ __forceinline__ void cvt(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-};
-template <> struct LnRaw<bf16_t> {
-    typedef uint2 type;
-    static __device__ __forceinline__ void cvt(const uint2& v, float (&o)[4]) {
-        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-    }
-};
-
-#define LN_BWD_WAVES 16
-template <typename T, int IT>
+// held the small shapes at 2 TB/s.  Sixteen waves per CU means 128 registers per wave: the row in flight is kept as it lies in
+// memory (raw 16-B registers, converted twice) and gamma is re-read from L1 per row instead of living in registers, so that the
+// 8-wide form of a 768- or 1024-column row (two chunks per lane: 16 + 16 column partials) stays clear of scratch.
+// (the 8-wide form of a 768- / 1024-column row needs ~150 registers: it runs twelve waves per CU -- 168 registers -- whose one-row
+// prefetch still keeps 12 x 3-4.5 KB per CU in flight)
+template <typename T, int IT, int VEC, int LN_BWD_WAVES>
 __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dz, T* __restrict__ dxdrop, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, long rows, int cols, float drop_p,
                                                      uint64_t seed, uint64_t offset) {
+    typedef LnVec<T, VEC> V;
+    typedef typename V::raw_t raw_t;
     extern __shared__ __attribute__((aligned(16))) float sh[];  // [8][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = cols >> 2;
+    const int nv = cols / VEC;
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    float ag[IT][4], ab[IT][4], gm[IT][4];
+    float ag[IT][VEC], ab[IT][VEC];
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        int c = lane + 64 * i;
+    for (int i = 0; i < IT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ag[i][r] = ab[i][r] = 0.f;
-        if (c < nv) {
-            float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
-            gm[i][0] = g.x; gm[i][1] = g.y; gm[i][2] = g.z; gm[i][3] = g.w;
-        } else {
-            gm[i][0] = gm[i][1] = gm[i][2] = gm[i][3] = 0.f;
-        }
-    }
+        for (int r = 0; r < VEC; ++r) ag[i][r] = ab[i][r] = 0.f;
     // rows are software-pipelined: the loads of a wave's NEXT row are in flight while the current row is reduced, normalised and
     // stored (a row is a dependent chain load -> two wave reductions -> store; without the prefetch a CU has no load outstanding
     // for about half of it)
-    typedef typename LnRaw<T>::type raw_t;
     raw_t rdy[IT], rz[IT], rq[IT];
     float nmu = 0.f, nrs = 0.f;
     const long stride = (long)gridDim.x * LN_BWD_WAVES;
@@ -139,9 +178,9 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
         for (int i = 0; i < IT; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
-                rdy[i] = *reinterpret_cast<const raw_t*>(dy + row * cols + c * 4);
-                rz[i] = *reinterpret_cast<const raw_t*>(z + row * cols + c * 4);
-                if (dres) rq[i] = *reinterpret_cast<const raw_t*>(dres + row * cols + c * 4);
+                rdy[i] = *reinterpret_cast<const raw_t*>(dy + row * cols + c * VEC);
+                rz[i] = *reinterpret_cast<const raw_t*>(z + row * cols + c * VEC);
+                if (dres) rq[i] = *reinterpret_cast<const raw_t*>(dres + row * cols + c * VEC);
             }
         }
     };
@@ -149,29 +188,29 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
     if (row < rows) fetch(row);
     for (; row < rows; row += stride) {
         const float mu = nmu, rs = nrs;
-        float xh[IT][4], g[IT][4];
-        raw_t cq[IT];
+        raw_t cdy[IT], cz[IT], cq[IT];   // the current row, as it lies in memory
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            int c = lane + 64 * i;
-            cq[i] = rq[i];
+            const int c = lane + 64 * i;
+            cdy[i] = rdy[i]; cz[i] = rz[i]; cq[i] = rq[i];
             if (c < nv) {
-                float d[4], zz[4];
-                LnRaw<T>::cvt(rdy[i], d);
-                LnRaw<T>::cvt(rz[i], zz);
+                float d[VEC], zz[VEC], gm[VEC];
+                V::cvt(cdy[i], d);
+                V::cvt(cz[i], zz);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    xh[i][r] = (zz[r] - mu) * rs;
-                    g[i][r] = d[r] * gm[i][r];
-                    s1 += g[i][r];
-                    s2 += g[i][r] * xh[i][r];
-                    ag[i][r] += d[r] * xh[i][r];
+                for (int k = 0; k < VEC / 4; ++k) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * VEC + 4 * k);
+                    gm[4 * k] = g4.x; gm[4 * k + 1] = g4.y; gm[4 * k + 2] = g4.z; gm[4 * k + 3] = g4.w;
+                }
+#pragma unroll
+                for (int r = 0; r < VEC; ++r) {
+                    const float xh = (zz[r] - mu) * rs, g = d[r] * gm[r];
+                    s1 += g;
+                    s2 += g * xh;
+                    ag[i][r] += d[r] * xh;
                     ab[i][r] += d[r];
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xh[i][r] = g[i][r] = 0.f;
             }
         }
         if (row + stride < rows) fetch(row + stride);
@@ -179,42 +218,57 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
         s2 = wave_sum(s2) / (float)cols;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            int c = lane + 64 * i;
+            const int c = lane + 64 * i;
             if (c < nv) {
-                float o[4];
+                float d[VEC], zz[VEC], o[VEC];
+                V::cvt(cdy[i], d);
+                V::cvt(cz[i], zz);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = rs * (g[i][r] - s1 - xh[i][r] * s2);
-                if (dres) {
-                    float q[4];
-                    LnRaw<T>::cvt(cq[i], q);
+                for (int k = 0; k < VEC / 4; ++k) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * VEC + 4 * k);
+                    const float gm[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] += q[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (zz[4 * k + r] - mu) * rs, g = d[4 * k + r] * gm[r];
+                        o[4 * k + r] = rs * (g - s1 - xh * s2);
+                    }
                 }
-                st4<T>(dz + row * cols + c * 4, o);
+                if (dres) {
+                    float q[VEC];
+                    V::cvt(cq[i], q);
+#pragma unroll
+                    for (int r = 0; r < VEC; ++r) o[r] += q[r];
+                }
+                *reinterpret_cast<raw_t*>(dz + row * cols + c * VEC) = V::pack(o);
                 if (dxdrop) {
                     if (drop_p > 0.f) {
-                        float m[4];
-                        dropout_scale4(seed, offset, (uint64_t)(row * nv + c), drop_p, inv_keep, m);
+                        float m[VEC];
+                        ln_dropout<VEC>(seed, offset, row, nv, c, drop_p, inv_keep, m);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = rnd<T>(o[r]) * m[r];
+                        for (int r = 0; r < VEC; ++r) o[r] = rnd<T>(o[r]) * m[r];
                     }
-                    st4<T>(dxdrop + row * cols + c * 4, o);
+                    *reinterpret_cast<raw_t*>(dxdrop + row * cols + c * VEC) = V::pack(o);
                 }
             }
         }
     }
     // workgroup reduction of the per-lane column partials, then one global atomic per column
     for (int pass = 0; pass < 2; ++pass) {
-        float tot[2] = {0.f, 0.f};   // columns threadIdx.x and threadIdx.x + 1024 (cols <= 2048)
-        for (int half = 0; half < 2; ++half) {
+        float tot[2] = {0.f, 0.f};   // columns threadIdx.x and threadIdx.x + blockDim.x (cols <= 2 * blockDim.x, host-checked)
+        for (int half = 0; half < (LN_BWD_WAVES + 7) / 8; ++half) {
+            const int nsl = LN_BWD_WAVES - 8 * half < 8 ? LN_BWD_WAVES - 8 * half : 8;   // wave slices written in this half
             __syncthreads();
             if ((wave >> 3) == half) {
 #pragma unroll
                 for (int i = 0; i < IT; ++i) {
-                    int c = lane + 64 * i;
-                    if (c < nv)
-                        *reinterpret_cast<float4*>(sh + (wave & 7) * cols + c * 4) =
-                            pass == 0 ? make_float4(ag[i][0], ag[i][1], ag[i][2], ag[i][3]) : make_float4(ab[i][0], ab[i][1], ab[i][2], ab[i][3]);
+                    const int c = lane + 64 * i;
+                    if (c < nv) {
+#pragma unroll
+                        for (int k = 0; k < VEC / 4; ++k)
+                            *reinterpret_cast<float4*>(sh + (wave & 7) * cols + c * VEC + 4 * k) =
+                                pass == 0 ? make_float4(ag[i][4 * k], ag[i][4 * k + 1], ag[i][4 * k + 2], ag[i][4 * k + 3])
+                                          : make_float4(ab[i][4 * k], ab[i][4 * k + 1], ab[i][4 * k + 2], ab[i][4 * k + 3]);
+                    }
                 }
             }
             __syncthreads();
@@ -223,7 +277,7 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
                 const int c = threadIdx.x + j * LN_BWD_WAVES * 64;
                 if (c < cols) {
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) tot[j] += sh[w * cols + c];
+                    for (int w = 0; w < 8; ++w) if (w < nsl) tot[j] += sh[w * cols + c];
                 }
             }
         }
@@ -240,9 +294,17 @@ template <typename T>
 static int ln_fwd_launch(const void* x, const void* res, void* z, const float* gamma, const float* beta, void* y, float* mean,
                          float* rstd, long rows, int cols, float eps, float p, uint64_t seed, uint64_t off, hipStream_t st) {
     dim3 grid(ceil_div(rows, 4)), block(256);
+    auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+#define L(IT_, V_) hipLaunchKernelGGL((ln_fwd_kernel<T, IT_, V_>), grid, block, 0, st, (const T*)x, (const T*)res, (T*)z, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, p, seed, off)
+    if constexpr (sizeof(T) == 2) {
+        if (cols % 8 == 0 && al16(x) && al16(res) && al16(z) && al16(y)) {   // 16-B lane accesses
+            const int it8 = ceil_div(cols / 8, 64);
+            if (it8 <= 1) L(1, 8); else if (it8 <= 2) L(2, 8); else L(4, 8);
+            return 0;
+        }
+    }
     const int it = ceil_div(cols / 4, 64);
-#define L(IT_) hipLaunchKernelGGL((ln_fwd_kernel<T, IT_>), grid, block, 0, st, (const T*)x, (const T*)res, (T*)z, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, p, seed, off)
-    if (it <= 1) L(1); else if (it <= 2) L(2); else if (it <= 3) L(3); else if (it <= 4) L(4); else L(8);
+    if (it <= 1) L(1, 4); else if (it <= 2) L(2, 4); else if (it <= 3) L(3, 4); else if (it <= 4) L(4, 4); else L(8, 4);
 #undef L
     return 0;
 }
@@ -264,13 +326,24 @@ template <typename T>
 static int ln_bwd_launch(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                          const void* dres, void* dz, void* dxdrop, float* dgamma, float* dbeta, long rows, int cols, float p,
                          uint64_t seed, uint64_t off, hipStream_t st) {
-    int nb = ceil_div(rows, LN_BWD_WAVES);
-    if (nb > 256) nb = 256;
-    dim3 grid(nb), block(LN_BWD_WAVES * 64);
     size_t shm = (size_t)8 * cols * sizeof(float);
+    auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+#define L(IT_, V_, W_)                                                                                                   \
+    do {                                                                                                                 \
+        int nb = ceil_div(rows, W_);                                                                                     \
+        if (nb > 256) nb = 256;                                                                                          \
+        hipLaunchKernelGGL((ln_bwd_kernel<T, IT_, V_, W_>), dim3(nb), dim3(W_ * 64), shm, st, (const T*)dy, (const T*)z, mean, rstd, gamma, \
+                           (const T*)dres, (T*)dz, (T*)dxdrop, dgamma, dbeta, rows, cols, p, seed, off);                 \
+    } while (0)
+    if constexpr (sizeof(T) == 2) {
+        if (cols % 8 == 0 && cols <= 1024 && al16(dy) && al16(z) && al16(dres) && al16(dz) && al16(dxdrop)) {   // 16-B lane accesses
+            const int it8 = ceil_div(cols / 8, 64);
+            if (it8 <= 1) L(1, 8, 16); else L(2, 8, 12);
+            return 0;
+        }
+    }
     const int it = ceil_div(cols / 4, 64);
-#define L(IT_) hipLaunchKernelGGL((ln_bwd_kernel<T, IT_>), grid, block, shm, st, (const T*)dy, (const T*)z, mean, rstd, gamma, (const T*)dres, (T*)dz, (T*)dxdrop, dgamma, dbeta, rows, cols, p, seed, off)
-    if (it <= 1) L(1); else if (it <= 2) L(2); else if (it <= 3) L(3); else if (it <= 4) L(4); else L(8);
+    if (it <= 1) L(1, 4, 16); else if (it <= 2) L(2, 4, 16); else if (it <= 3) L(3, 4, 16); else if (it <= 4) L(4, 4, 16); else L(8, 4, 16);
 #undef L
     return 0;
 }

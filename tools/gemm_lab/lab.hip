@@ -35,8 +35,20 @@ static void fill_bf16(unsigned short* d, size_t n, float scale) {
 
 typedef void (*q8_fn)(GemmArgs);
 // epi: 0 plain(+bias) 1 bias+pre+gelu 2 +residual 3 gmul 4 f32.  dbg variants only exist for the forward form.
+static int g_sch = 0;   // schedule variant of the launches that follow (gemm_q8.h SCH)
 static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
     (void)nslot;
+#define W(A, B, E, S) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, false, S>)
+    if (g_sch == 1 || g_sch == 2) {
+        if (dbg != 0) return nullptr;
+#define WS(A, B, E) (g_sch == 1 ? W(A, B, E, 1) : W(A, B, E, 2))
+        if (a_kc && b_kc) { if (epi == 0) return WS(true, true, 0); if (epi == 1) return WS(true, true, 1); if (epi == 2) return WS(true, true, 2); }
+        if (a_kc && !b_kc) { if (epi == 0) return WS(true, false, 0); if (epi == 3) return WS(true, false, 3); if (epi == 2) return WS(true, false, 2); }
+        if (!a_kc && !b_kc && epi == 4) return WS(false, false, 4);
+#undef WS
+        return nullptr;
+    }
+#undef W
 #define V(A, B, E, D) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, D>)
     if (a_kc && b_kc) {
         if (epi == 1) { if (dbg == 4) return V(true, true, 1, 4); if (dbg == 6) return V(true, true, 1, 6); return V(true, true, 1, 0); }
@@ -79,6 +91,7 @@ static void launch_q8(const Run& r, int nslot, int dbg, int grid_override, hipSt
     int ncu = grid_override > 0 ? grid_override : 256;
     dim3 grid((unsigned)(total < ncu ? total : ncu));
     const int epi = r.out_f32 ? 4 : r.gmul ? 3 : r.residual ? 2 : r.pre ? 1 : 0;
+    g_sch = nslot;
     q8_fn fn = pick(r.a_kc, r.b_kc, epi, nslot, dbg);
     if (!fn) { fprintf(stderr, "no Q8 instance for form %d%d epi %d dbg %d\n", r.a_kc, r.b_kc, epi, dbg); exit(1); }
     const size_t shm = (size_t)10 * Q8_HALF;
@@ -142,7 +155,7 @@ int main(int argc, char** argv) {
     int forms = 7;        // bit0 fwd, bit1 dgrad, bit2 wgrad
     bool quick = false;
     std::vector<int> dbgs = {0};
-    std::vector<int> nslots = {4};
+    std::vector<int> nslots = {0};   // the list of schedule variants to run (--sch=0,1,2); the name is historical
     int grid_override = 0, stress = 0, hog = 0;   // --hog: a small spinning kernel on a second stream beside every launch (uneven load)
     for (int i = 1; i < argc; ++i) {
         if (!strncmp(argv[i], "--stress=", 9)) { stress = atoi(argv[i] + 9); continue; }
@@ -151,6 +164,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--quick")) quick = true;
         else if (!strncmp(argv[i], "--grid=", 7)) grid_override = atoi(argv[i] + 7);
         else if (!strncmp(argv[i], "--dbg=", 6)) { dbgs.clear(); char* p = argv[i] + 6; while (*p) { dbgs.push_back((int)strtol(p, &p, 10)); if (*p == ',') ++p; } }
+        else if (!strncmp(argv[i], "--sch=", 6)) { nslots.clear(); char* p = argv[i] + 6; while (*p) { nslots.push_back((int)strtol(p, &p, 10)); if (*p == ',') ++p; } }
         else if (!strncmp(argv[i], "--nslot=", 8)) { nslots.clear(); char* p = argv[i] + 8; while (*p) { nslots.push_back((int)strtol(p, &p, 10)); if (*p == ',') ++p; } }
         else want.push_back(argv[i]);
     }
@@ -184,7 +198,7 @@ int main(int argc, char** argv) {
                 if (hog) ecamp_dev_spin(16 + 8 * (it % 13), 64, 20000 + 7000 * (it % 7), (ecampStream_t)s2);   // a different set of CUs held for 10-30 us each time
                 CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s)); CK(hipMemsetAsync(pre1, 0xff, (size_t)M * N * 2, s));
                 CK(hipMemsetAsync(dx1, 0xff, (size_t)M * K * 2, s)); CK(hipMemsetAsync(gw1, 0xff, (size_t)N * K * 4, s));
-                launch_q8(rf, 4, 0, grid_override, s); launch_q8(rd, 4, 0, grid_override, s); launch_q8(rw, 4, 0, grid_override, s);
+                launch_q8(rf, nslots[0], 0, grid_override, s); launch_q8(rd, nslots[0], 0, grid_override, s); launch_q8(rw, nslots[0], 0, grid_override, s);
                 const unsigned long long h[4] = {checksum(y1, (size_t)M * N * 2, s), checksum(pre1, (size_t)M * N * 2, s), checksum(dx1, (size_t)M * K * 2, s),
                                                  checksum(gw1, (size_t)N * K * 4, s)};
                 for (int j = 0; j < 4; ++j) { if (it == 0) h0[j] = h[j]; else if (h[j] != h0[j]) { ++bad; printf("  %s: repetition %d output %d differs\n", sh.name, it, j); } }
@@ -206,27 +220,28 @@ int main(int argc, char** argv) {
             printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f\n", sh.name, "fwd", M, N, K, "128^2 (r1)", t_ref, fl / t_ref / 1e6);
             for (int ns : nslots)
                 for (int dbg : dbgs) {
+                    if (ns != 0 && dbg != 0) continue;
                     CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s));
                     launch_q8(q, ns, dbg, grid_override, s);
                     CK(hipStreamSynchronize(s));
                     double rn, rn2; double d = compare(y1, y0, (size_t)M * N, false, &rn); double d2 = compare(pre1, pre0, (size_t)M * N, false, &rn2);
                     float t = time_us([&] { launch_q8(q, ns, dbg, grid_override, s); });
-                    char v[64]; snprintf(v, sizeof v, "Q8 nslot=%d dbg=%d", ns, dbg);
+                    char v[64]; snprintf(v, sizeof v, "Q8 sch=%d dbg=%d", ns, dbg);
                     printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f  maxdiff y %.3g (|y|max %.3g) pre %.3g\n", sh.name, "fwd", M, N, K, v, t, fl / t / 1e6, d, rn, d2);
                 }
             // plain (no bias / act / pre): the yardstick form
             Run r2 = {M, N, K, 1, 1, K, K, N, x, w, y0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 1, nullptr};
             Run q2 = r2; q2.C = y1;
             launch_ref(r2, 0, s);
+            for (int ns : nslots)
             for (int dbg : dbgs) {
-                
-                const int ns = 4;
+                if (ns != 0 && dbg != 0) continue;
                 CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s));
                 launch_q8(q2, ns, dbg, grid_override, s);
                 CK(hipStreamSynchronize(s));
                 double rn; double d = compare(y1, y0, (size_t)M * N, false, &rn);
                 float t = time_us([&] { launch_q8(q2, ns, dbg, grid_override, s); });
-                char v[64]; snprintf(v, sizeof v, "Q8 plain dbg=%d", dbg);
+                char v[64]; snprintf(v, sizeof v, "Q8 plain sch=%d dbg=%d", ns, dbg);
                 printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f  maxdiff %.3g\n", sh.name, "fwd", M, N, K, v, t, fl / t / 1e6, d);
             }
         }
@@ -244,7 +259,7 @@ int main(int argc, char** argv) {
                 CK(hipStreamSynchronize(s));
                 double rn; double d = compare(dx1, dx0, (size_t)M * K, false, &rn);
                 float t = time_us([&] { launch_q8(q, ns, 0, grid_override, s); });
-                char v[64]; snprintf(v, sizeof v, "Q8 nslot=%d", ns);
+                char v[64]; snprintf(v, sizeof v, "Q8 sch=%d", ns);
                 printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f  maxdiff %.3g (max %.3g)\n", sh.name, "dgrad", M, K, N, v, t, fl / t / 1e6, d, rn);
             }
         }
@@ -266,7 +281,7 @@ int main(int argc, char** argv) {
                 g_verbose = 0;
                 float t1 = time_us([&] { launch_q8(q1, ns, 0, grid_override, s); });
                 float t = time_us([&] { launch_q8(q, ns, 0, grid_override, s); });
-                char v[64]; snprintf(v, sizeof v, "Q8 nslot=%d", ns);
+                char v[64]; snprintf(v, sizeof v, "Q8 sch=%d", ns);
                 printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f  split %d slabs only; unsplit %.1f us maxdiff %.3g (max %.3g)\n", sh.name, "wgrad", N, K, M, v, t,
                        fl / t / 1e6, split, t1, d, rn);
             }
