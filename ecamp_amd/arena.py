@@ -24,7 +24,8 @@ class ParamArena:
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         name_of = {id(p): n for n, p in named}
         group_of = {}
-        for grp in (model.arena_fuse_groups() if hasattr(model, "arena_fuse_groups") else []):
+        self._fuse_groups = [list(g) for g in (model.arena_fuse_groups() if hasattr(model, "arena_fuse_groups") else [])]
+        for grp in self._fuse_groups:
             for p in grp:
                 group_of[id(p)] = grp
         params, seen = [], set()
@@ -72,6 +73,13 @@ class ParamArena:
         self._zero_flags = None      # uint8 per 64-element block: 1 = zero me in zero_grad(); rebuilt when _gemm_written grows
         self.version = 0      # bumped whenever the values the kernels read change (optimizer step, sync_shadow)
         self._w8 = {}         # slot -> (version, e4m3 copy, scale): the fp8-forward mode's weights, re-quantised once per step
+        # fp8 forward, delayed scaling (configs[4]): one GEMM-input SITE per weight slot -- scale (what this step's producers quantise
+        # with), 16 amax slots (what they have seen), and on the host whether the site has been calibrated (its first use runs the
+        # two-pass current scaling, which also seeds the scale).  Allocated on first use.
+        self.f8_scale = None
+        self.f8_amax = None
+        self.f8_cal = set()
+        self.f8_rolled = 0    # the `version` the scales were last rolled at
         self.sync_shadow()
 
     # -- views ---------------------------------------------------------------------------------
@@ -115,16 +123,58 @@ class ParamArena:
             ops.zero_(self.flat_g[o:o + n])
         self._fresh.difference_update(todo)
 
-    def w8(self, p):
-        """(uint8 e4m3 copy of parameter p, f32[1] scale) for the fp8 forward GEMMs (configs[4]); quantised from the bf16 shadow
-        the first time it is asked for after the values changed."""
-        i = self.index[id(p)]
-        hit = self._w8.get(i)
-        if hit is None or hit[0] != self.version:
-            q, s = ops.quantize_fp8(self.w(p).contiguous())
-            hit = (self.version, q, s)
-            self._w8[i] = hit
-        return hit[1], hit[2]
+    def w8(self, p, shape=None):
+        """(uint8 e4m3 copy, f32[1] scale) of parameter p -- or of a list of arena-adjacent parameters viewed as ONE [N, K] matrix of
+        `shape` (BERT's fused query/key/value block) -- for the fp8 forward GEMMs (configs[4]); quantised from the bf16 shadow the first
+        time it is asked for after the values changed (once per optimizer step)."""
+        plist = list(p) if isinstance(p, (list, tuple)) else [p]
+        i = self.index[id(plist[0])]
+        if self._w8.get("version") != self.version:
+            self._quantize_weights()
+        o, n = self._span(plist) if len(plist) > 1 else (self.offsets[i], self.sizes[i])
+        q = self.flat_p8[o:o + n]
+        return (q.view(shape) if shape is not None else q.view(plist[0].shape)), self.w8_scale[self._w8["sid"][i]:self._w8["sid"][i] + 1]
+
+    def _quantize_weights(self):
+        """All matrices of the bf16 shadow -> e4m3 arena `flat_p8`, each with its own per-matrix scale (the members of a fuse group
+        share one: they run as ONE GEMM), in three launches: maxima, roll, quantise (ecamp_fp8_weights)."""
+        if "items" not in self._w8:
+            sid = list(range(len(self.params)))
+            for grp in self._fuse_groups:
+                first = min(self.index[id(q)] for q in grp)
+                for q in grp:
+                    sid[self.index[id(q)]] = first
+            rows = []
+            for i, (p, o, n) in enumerate(zip(self.params, self.offsets, self.sizes)):
+                if p.dim() < 2 or n % 4:
+                    continue
+                for c in range(0, n, 65536):
+                    rows.append((o + c, min(65536, n - c), sid[i], 0))
+            self._w8["sid"] = sid
+            self._w8["items"] = torch.tensor(rows, dtype=torch.int32).to(self.device)
+            self.flat_p8 = torch.zeros((self.total,), device=self.device, dtype=torch.uint8)
+            self.w8_scale = torch.ones((len(self.params),), device=self.device, dtype=torch.float32)
+            self.w8_amax = ops.zeros((len(self.params) * 512,), self.device)
+        it = self._w8["items"]
+        ops.fp8_weights(self.flat_p16, self.flat_p8, it, self.w8_amax, self.w8_scale, 0)
+        ops.fp8_roll(self.w8_amax, self.w8_scale)
+        ops.fp8_weights(self.flat_p16, self.flat_p8, it, self.w8_amax, self.w8_scale, 1)
+        self._w8["version"] = self.version
+
+    def f8_site(self, p):
+        """-> (site index, scale f32[1] view, amax-slot f32[512] view, calibrated?) of the GEMM whose weight (first weight) is p.  Rolls
+        every site's amax into its next scale when an optimizer step has happened since the last roll (delayed scaling: this step
+        quantises with the maxima the previous step saw)."""
+        if self.f8_scale is None:
+            n = len(self.params)
+            self.f8_scale = torch.ones((n,), device=self.device, dtype=torch.float32)
+            self.f8_amax = ops.zeros((n * 512,), self.device)
+            self.f8_rolled = self.version
+        if self.f8_rolled != self.version:
+            ops.fp8_roll(self.f8_amax, self.f8_scale)
+            self.f8_rolled = self.version
+        i = self.index[id(p[0] if isinstance(p, (list, tuple)) else p)]
+        return i, self.f8_scale[i:i + 1], self.f8_amax[i * 512:(i + 1) * 512], i in self.f8_cal
 
     def _span(self, ps):
         idx = [self.index[id(p)] for p in ps]

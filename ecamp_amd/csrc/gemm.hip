@@ -451,6 +451,105 @@ __global__ void quant_fp8_kernel(const T* __restrict__ x, const float* __restric
     }
 }
 
+// ---- delayed scaling (round 4).  A GEMM input site owns one scale (f32, the one its producer quantises with and the GEMM dequantises
+// with during THIS optimizer step) and 16 amax slots 128 B apart (what the producers of this step have seen so far: their waves
+// atomicMax into slot (workgroup & 15), so that a 12800-wave LayerNorm does not serialise on one L2 line); ecamp_fp8_roll turns the
+// slots into the next step's scale and clears them.  One pass over the activation instead of amax + quantise.
+#define F8_SLOTS 16
+#define F8_SLOT_STRIDE 32   // floats
+template <typename T>
+__global__ __launch_bounds__(256) void quant_fp8_delayed_kernel(const T* __restrict__ x, const float* __restrict__ scale, unsigned int* __restrict__ q,
+                                                                float* __restrict__ amax_slots, long n4) {
+    const float inv = 1.0f / fmaxf(scale[0], 1e-30f);
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float v[4];
+        ld4<T>(x + i * 4, v);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * inv, -448.f), 448.f);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+        q[i] = (unsigned int)w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(amax_slots + (blockIdx.x & (F8_SLOTS - 1)) * F8_SLOT_STRIDE), __float_as_uint(m));
+}
+__global__ void fp8_roll_kernel(float* __restrict__ amax_slots, float* __restrict__ scale, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* s = amax_slots + (long)i * F8_SLOTS * F8_SLOT_STRIDE;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < F8_SLOTS; ++k) { a = fmaxf(a, s[k * F8_SLOT_STRIDE]); s[k * F8_SLOT_STRIDE] = 0.f; }
+    if (a > 0.f) scale[i] = a * (1.0f / 448.0f);   // a site nobody fed this step keeps its scale
+}
+extern "C" int ecamp_quant_fp8_delayed(const void* x, const float* scale, void* q, float* amax_slots, int64_t n, int32_t dtype, hipStream_t stream) {
+    ECAMP_CHECK_ARG(x && scale && q && amax_slots && n > 0 && n % 4 == 0, "quant_fp8_delayed: bad args");
+    ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "quant_fp8_delayed: bad dtype %d", dtype);
+    const long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    if (dtype == ECAMP_F32) hipLaunchKernelGGL(quant_fp8_delayed_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)x, scale, (unsigned int*)q, amax_slots, n4);
+    else hipLaunchKernelGGL(quant_fp8_delayed_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)x, scale, (unsigned int*)q, amax_slots, n4);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ecamp_fp8_roll(float* amax_slots, float* scale, int32_t n, hipStream_t stream) {
+    ECAMP_CHECK_ARG(amax_slots && scale && n > 0, "fp8_roll: bad args");
+    hipLaunchKernelGGL(fp8_roll_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax_slots, scale, (int)n);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+// ---- the fp8 copies of ALL weights in two launches per optimizer step (they were 92 amax + 92 quantise launches of 6-18 us each: 2.7 ms
+// of a 69 ms step).  One workgroup per table item {first element, count (multiple of 4, <= 65536), scale id, -}: pass 0 leaves the item's
+// |w| maximum in the slots of its scale id (several tensors may share one: BERT's fused query / key / value block), ecamp_fp8_roll turns
+// the slots into scales, pass 1 quantises with them.  Exact current scaling: a weight matrix is quantised with its own maximum.
+__global__ __launch_bounds__(256) void fp8_weights_kernel(const bf16_t* __restrict__ w, unsigned int* __restrict__ q, const int4* __restrict__ items,
+                                                          float* __restrict__ amax_slots, const float* __restrict__ scales, int pass) {
+    __shared__ float sh[4];
+    const int4 it = items[blockIdx.x];
+    const long first = (long)(unsigned)it.x;   // element offset (multiple of 4)
+    const int n4 = it.y >> 2;
+    if (pass == 0) {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float v[4];
+            ld4<bf16_t>(w + first + 4 * (long)i, v);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+            atomicMax(reinterpret_cast<unsigned int*>(amax_slots + (long)it.z * (F8_SLOTS * F8_SLOT_STRIDE) + (blockIdx.x & (F8_SLOTS - 1)) * F8_SLOT_STRIDE), __float_as_uint(m));
+        }
+    } else {
+        const float inv = 1.0f / fmaxf(scales[it.z], 1e-30f);
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float v[4];
+            ld4<bf16_t>(w + first + 4 * (long)i, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r] * inv, -448.f), 448.f);
+            int ww = 0;
+            ww = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], ww, false);
+            ww = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], ww, true);
+            q[(first >> 2) + i] = (unsigned int)ww;
+        }
+    }
+}
+extern "C" int ecamp_fp8_weights(const void* w_bf16, void* w8, const int32_t* items, int32_t nitems, float* amax_slots, const float* scales,
+                                 int32_t pass, hipStream_t stream) {
+    ECAMP_CHECK_ARG(w_bf16 && w8 && items && nitems > 0 && amax_slots && scales && (pass == 0 || pass == 1), "fp8_weights: bad args");
+    ECAMP_CHECK_ARG((reinterpret_cast<uintptr_t>(items) & 15) == 0, "fp8_weights: the item table must be 16-byte aligned");
+    hipLaunchKernelGGL(fp8_weights_kernel, dim3(nitems), dim3(256), 0, stream, (const bf16_t*)w_bf16, (unsigned int*)w8, (const int4*)items, amax_slots, scales, (int)pass);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int ecamp_amax(const void* x, float* out, int64_t n, int32_t dtype, hipStream_t stream) {
     ECAMP_CHECK_ARG(x && out && n > 0 && n % 4 == 0, "amax: bad args");
     ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "amax: bad dtype %d", dtype);
@@ -473,6 +572,11 @@ extern "C" int ecamp_quant_fp8(const void* x, const float* amax, void* q, float*
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
+static int p8_num_cu();
+static int q8_env();
+static long q8_min_items();
+static long g_f8_q8_launches = 0;
+extern "C" int64_t ecamp_gemm_f8_q8_launches(void) { return g_f8_q8_launches; }
 extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                               int64_t ldc, const float* scale_a, const float* scale_b, const float* bias, const void* residual,
                               int64_t ldr, void* pre_out, int64_t ldp, int act, hipStream_t stream) {
@@ -485,7 +589,7 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.pre_out = pre_out; g.ldp = ldp; g.gmul = nullptr; g.ldg = 0;
-    g.alpha = 1.0f; g.alpha_dev = nullptr; g.alpha_out = 1.0f; g.alpha_dev_out = nullptr;
+    g.alpha = 1.0f; g.alpha_dev = nullptr; g.alpha_dev2 = nullptr; g.alpha_out = 1.0f; g.alpha_dev_out = nullptr;
     g.rowsum = nullptr;
     g.act = act; g.out_f32 = 0; g.accumulate = 0;
     g.k_per_split = (int)K;
@@ -493,6 +597,35 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
     g.nbm = ceil_div(M, BM); g.nbn = ceil_div(N, BN);
     const bool prof = ecamp_prof_active();
     if (prof) ecamp_prof_begin(ECAMP_PROF_GEMM_FP8, 2.0 * (double)M * (double)N * (double)K, stream);
+    // the persistent 256 x 256 x 128 e4m3 form (gemm_q8.h, F8) from the same tile count up as the bf16 kernel, when its alignment /
+    // size conditions hold; otherwise the 128^2 kernel below.  ECAMP_F8_Q8=0 keeps everything on the 128^2 kernel (development A/B).
+    {
+        static const int f8q8 = getenv("ECAMP_F8_Q8") ? atoi(getenv("ECAMP_F8_Q8")) : 1;
+        const int q8m = q8_env();
+        const int epi = (pre_out || act) ? ((pre_out && act == 1 && !residual) ? 1 : -1) : residual ? 2 : 0;
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        const long lim = 0x7fffffffl;
+        const long items8 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+        const bool legal = f8q8 && q8m != 0 && epi >= 0 && K >= 256 && N % 8 == 0 && ldc % 8 == 0 && al16(A8) && al16(B8) && al16(C) &&
+                           M * lda <= lim && N * ldb <= lim && M * ldc * 2 <= lim && (!bias || al16(bias)) &&
+                           (!pre_out || (ldp % 8 == 0 && al16(pre_out) && M * ldp * 2 <= lim)) &&
+                           (!residual || (ldr % 8 == 0 && al16(residual) && M * ldr * 2 <= lim));
+        if (legal && (q8m == 2 || items8 >= q8_min_items())) {
+            typedef void (*f8_fn)(GemmArgs);
+            const f8_fn fn = epi == 0 ? (f8_fn)gemm_f8_q8_kernel<0> : epi == 1 ? (f8_fn)gemm_f8_q8_kernel<1> : (f8_fn)gemm_f8_q8_kernel<2>;
+            g.nbm = ceil_div(M, 256); g.nbn = ceil_div(N, 256); g.nsplit = 1; g.wide = 1;
+            g.alpha_dev = scale_a; g.alpha_dev2 = scale_b;
+            const size_t shm = 10 * Q8_HALF;
+            static bool attr[3] = {false, false, false};
+            if (!attr[epi]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr[epi] = true; }
+            const int ncu = p8_num_cu();
+            hipLaunchKernelGGL(fn, dim3((unsigned)(items8 < ncu ? items8 : ncu)), dim3(512), shm, stream, g);
+            ++g_f8_q8_launches;
+            if (prof) ecamp_prof_end(stream);
+            ECAMP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(gemm_fp8_kernel, dim3(g.nbm * g.nbn), dim3(256), 0, stream, g, scale_a, scale_b);
     if (prof) ecamp_prof_end(stream);
     ECAMP_LAUNCH_CHECK();
@@ -709,6 +842,7 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.pre_out = pre_out; g.ldp = ldp; g.gmul = gmul; g.ldg = ldg;
     g.alpha = alpha;
     g.alpha_dev = alpha_dev;
+    g.alpha_dev2 = nullptr;
     g.alpha_out = alpha;
     g.alpha_dev_out = alpha_dev;
     g.rowsum = rowsum;
@@ -881,20 +1015,23 @@ static const WgPlan* wg_plan(int n, const int64_t* n_out, const int64_t* k_in, c
             items.push_back({Tt.prob, Tt.m0, Tt.n0, (int)(k0 * 64), (int)kend, (int)(t * S + seg), (Tt.n0 == 0 && has_bias[Tt.prob]) ? 1 : 0, 0});
         }
     } else {
-    const long units = (long)tiles.size() * KT;
+    // the unit of the dealing is a PAIR of K tiles (a tile's last unit also takes its odd K tile, if it has one: 197 K tiles for the
+    // 12608 rows of ViT-L/448): every piece has >= 2 K tiles, whatever the row count
+    const long U = KT / 2;
+    const long units = (long)tiles.size() * U;
     long q = (units + ncu - 1) / ncu;
-    q += q & 1;                                   // even quota, even KT (rows % 128 == 0): every piece has >= 2 K tiles
-    if (q < 2) q = 2;
+    if (q < 1) q = 1;
     long u = 0;
     while (u < units) {
         first.push_back((int)items.size());
         long take = q < units - u ? q : units - u;
         while (take > 0) {
-            const long t = u / KT, k0 = u % KT, len = take < KT - k0 ? take : KT - k0;
+            const long t = u / U, j0 = u % U, len = take < U - j0 ? take : U - j0;
             WgTile& T = tiles[t];
             if (T.count == 0) T.first = (int)items.size();
             ++T.count;
-            const long kend = (k0 + len) * 64 < rows ? (k0 + len) * 64 : rows;
+            const long k0 = 2 * j0, k1 = j0 + len == U ? KT : 2 * (j0 + len);
+            const long kend = k1 * 64 < rows ? k1 * 64 : rows;
             items.push_back({T.prob, T.m0, T.n0, (int)(k0 * 64), (int)kend, (int)items.size(), (T.n0 == 0 && has_bias[T.prob]) ? 1 : 0, 0});
             u += len; take -= len;
         }
@@ -920,7 +1057,7 @@ static int wg_ncu() {
 }
 // 1 if the group can run as one launch (otherwise the caller issues per-layer ecamp_gemm calls)
 extern "C" int ecamp_wgrad_group_supported(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows) {
-    if (n < 1 || n > 4 || !n_out || !k_in || rows < 256 || rows % 128) return 0;
+    if (n < 1 || n > 4 || !n_out || !k_in || rows < 256) return 0;
     long tiles = 0;
     for (int p = 0; p < n; ++p) {
         if (n_out[p] % 8 || k_in[p] % 8 || n_out[p] <= 0 || k_in[p] <= 0) return 0;
@@ -973,7 +1110,7 @@ extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* c
                                  const void* table, int32_t workgroups, hipStream_t stream) {
     ECAMP_CHECK_ARG(dy && x && gw && gb && n_out && k_in && accumulate && ws && table, "wgrad_group: null pointer");
     ECAMP_CHECK_ARG(((uintptr_t)table & 31) == 0, "wgrad_group: the item table must be 32-byte aligned");
-    ECAMP_CHECK_ARG(ecamp_wgrad_group_supported(n, n_out, k_in, rows), "wgrad_group: unsupported group (1-4 layers, rows %% 128 == 0, dims %% 8 == 0, < 2 GB operands)");
+    ECAMP_CHECK_ARG(ecamp_wgrad_group_supported(n, n_out, k_in, rows), "wgrad_group: unsupported group (1-4 layers, rows >= 256, dims %% 8 == 0, < 2 GB operands)");
     unsigned hb[4] = {0, 0, 0, 0};
     bool any_bias = false;
     for (int p = 0; p < n; ++p) {

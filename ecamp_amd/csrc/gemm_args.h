@@ -26,6 +26,7 @@ struct GemmArgs {
     float alpha_out;        // the caller's alpha / alpha_dev, kept for the row-sum even when split-K resets the tile's own scale
     const float* alpha_dev_out;
     const float* alpha_dev; // optional device scalar multiplied into alpha (upstream loss gradient; avoids a host sync)
+    const float* alpha_dev2; // e4m3 form: the second operand's per-tensor scale (the first is alpha_dev)
     int dbg;                // development switches of the P8 kernel (ECAMP_P8_DBG); 0 in production
     int wide;               // every [M, ld] epilogue operand is 16-B aligned at 8-column granularity (P8's 16-B epilogue)
     int nsplit;             // P8: number of split-K slices (the persistent kernel walks tiles x slices itself)

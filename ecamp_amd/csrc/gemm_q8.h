@@ -37,6 +37,7 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 hw_bf16x8;
 typedef __attribute__((ext_vector_type(4))) short q8_v4s16;
+typedef unsigned int q8_u32x4_t __attribute__((ext_vector_type(4)));
 
 #define Q8_HALF 16384
 #define Q8_GLDS16(SRC, DST) \
@@ -48,6 +49,7 @@ static __device__ __attribute__((aligned(16))) unsigned int q8_zero16[4] = {0u, 
 struct Q8Item {
     int m0, n0, kbeg, kend, nt, z, ncol;
 };
+template <int KT_SHIFT = 6>   // log2 of the K tile's depth in elements: 64 bf16 or 128 e4m3 (a 128-byte row either way)
 __device__ __forceinline__ Q8Item q8_decode(const GemmArgs& g, int v, int total) {
     const unsigned f = (unsigned)xcd_remap(v, total), ntile = (unsigned)(g.nbm * g.nbn);
     // grouped order inside a split: 8 M-blocks are walked for one N-block before the next N-block, so the ~32 tiles an XCD works
@@ -60,7 +62,7 @@ __device__ __forceinline__ Q8Item q8_decode(const GemmArgs& g, int v, int total)
     it.m0 = (int)mb * 256; it.n0 = (int)nb * 256; it.z = (int)z; it.ncol = (int)nb;
     it.kbeg = (int)z * g.k_per_split;
     it.kend = min(g.K, it.kbeg + g.k_per_split);
-    it.nt = (it.kend - it.kbeg + 63) >> 6;
+    it.nt = (it.kend - it.kbeg + (1 << KT_SHIFT) - 1) >> KT_SHIFT;
     // the divisions above run on the VALU (v_rcp) and come back through v_readfirstlane; naming every result a scalar HERE keeps hipcc
     // from moving the whole chain behind them (pointers, record counts: the buffer descriptors) into VGPRs, which costs a waterfall
     // loop around every DMA instruction (cdna_hip_programming.md T20)
@@ -78,13 +80,13 @@ __device__ __forceinline__ Q8Item q8_decode(const GemmArgs& g, int v, int total)
 //   kc operand P[row*ld + k]: piece = 8 rows x 128 B; LDS position (row, j) holds global 16-B chunk j ^ ((row>>1)&7)
 //   oc operand P[k*ld + row]: half-tile kept as it lies in HBM, 64 k-rows x 256 B; piece = 4 k-rows; position (kr, j) holds
 //                             chunk j ^ ((kr&3)<<2), which puts the four k-rows of a transpose-read block on disjoint banks
-template <bool KC>
+template <bool KC, int ES = 2>   // ES: bytes per element (2 bf16, 1 e4m3)
 __device__ __forceinline__ unsigned q8_voff(int i, int wave, int lane, long ld) {
     const int pi = i * 8 + wave;
     if (KC) {
         const int row = pi * 8 + (lane >> 3);
         const int kc = (lane & 7) ^ ((row >> 1) & 7);
-        return (unsigned)(((long)row * ld + kc * 8) * 2);
+        return (unsigned)((long)row * ld * ES + kc * 16);
     } else {
         const int kr = pi * 4 + (lane >> 4);
         const int oc = (lane & 15) ^ ((kr & 3) << 2);
@@ -127,6 +129,16 @@ template <> struct Q8Frag<false> {
         return __builtin_bit_cast(hw_bf16x8, (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
     }
 };
+// e4m3 operand (contraction-contiguous only): the 32 bytes a lane feeds to one v_mfma_scale_f32_32x32x64_f8f6f4 = two 16-B chunks of its row
+typedef __attribute__((ext_vector_type(8))) int q8_v8i32;
+struct Q8Frag8 {
+    q8_u32x4_t lo, hi;
+    template <int OFF> __device__ __forceinline__ void read(const unsigned char* plo, const unsigned char* phi) {
+        lo = *reinterpret_cast<const q8_u32x4_t*>(plo + OFF);
+        hi = *reinterpret_cast<const q8_u32x4_t*>(phi + OFF);
+    }
+    __device__ __forceinline__ q8_v8i32 get() const { return (q8_v8i32){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}; }
+};
 // the explicit wait of a group whose fragments include asm reads: names every half so no consumer is scheduled above it
 __device__ __forceinline__ void q8_wait4(Q8Frag<false> (&f)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo), "+v"(f[3].hi));
@@ -160,8 +172,17 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
 // issue in the matrix interval as well (= sch 0), and wave-specialised producers -- 8 consumer + 4 producer waves, the whole operand
 // stream in waves of its own (tools/probes/gemm_producer_waves_fragment.hip.txt) -- which is within 3 % of this kernel on every shape:
 // the loop waits for the DATA (the L2 -> LDS path beside a power-limited MFMA stream), not for whoever issues the loads.
-template <bool A_KC, bool B_KC, int EPI, int DBG, bool ROWSUM, bool ITEMS, int SCH = 0>
+// F8: both operands are OCP e4m3 (one byte per element, contraction-contiguous; BASELINE.json configs[4]).  A K tile is still a
+// 128-byte row per operand row -- 128 elements instead of 64 -- so the LDS images, the rings, the DMA pieces and the counted waits
+// are the bf16 kernel's byte for byte; a phase is four v_mfma_scale_f32_32x32x64_f8f6f4 (64 matrix-pipe cycles each, block scales
+// 2^0: twice the bf16 rate per byte moved) on one k-step of 64 and one half of the wave's rows, the N-side fragments staying in
+// registers between the two halves.  The per-tensor scales are device scalars multiplied into alpha (alpha_dev, alpha_dev2).
+template <bool A_KC, bool B_KC, int EPI, int DBG, bool ROWSUM, bool ITEMS, int SCH = 0, bool F8 = false>
 __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
+    static_assert(!F8 || (A_KC && B_KC && SCH == 1 && !ROWSUM && !ITEMS && DBG == 0), "the e4m3 form is the forward form on the lean stream");
+    constexpr int ES = F8 ? 1 : 2;            // bytes per operand element
+    constexpr int KT = F8 ? 128 : 64;         // elements per K tile
+    constexpr int KT_SHIFT = F8 ? 7 : 6;
     static_assert(!ITEMS || (!A_KC && !B_KC && EPI == 4 && DBG == 0), "the item-table form is the weight-gradient form");
     static_assert(!ROWSUM || (!A_KC && !B_KC && EPI == 4), "rowsum is built for the weight-gradient form");
     constexpr int NSLOT = 5;                          // half-tile slots per operand ring
@@ -233,6 +254,14 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         offN[2] = offN[3] = 0;
     }
 
+    if (F8) {   // chunk pair (4 * ks8 + 2 * lh, + 1) of k-step ks8: offM / offN [2 * ks8 + j]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = 4 * (q >> 1) + 2 * lh + (q & 1);
+            offM[q] = (unsigned)(l31 * 128 + ((ch ^ ((l31 >> 1) & 7)) << 4));
+            offN[q] = (unsigned)(((wc & 1) * 64 + ncol) * 128 + ((ch ^ ((ncol >> 1) & 7)) << 4));
+        }
+    }
     f32x16 acc[4][2];
 
     // ---- DMA cursor over the flat K-tile stream; all of it wave-uniform (SGPRs): byte cursors of the A and B half-tile 0 of the
@@ -327,12 +356,12 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     auto q_cv = [&](bool tail) __attribute__((always_inline)) {   // (re)build the per-lane offsets for the current leading dimensions; tail: lanes past q_krem read as zero
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            cvA[i] = q8_voff<A_KC>(i, wave, lane, q_lda); cvA[2 + i] = cvA[i] + (unsigned)(A_KC ? q_lda * 256 : 256);
-            cvB[i] = q8_voff<B_KC>(i, wave, lane, q_ldb); cvB[2 + i] = cvB[i] + (unsigned)(B_KC ? q_ldb * 256 : 256);
+            cvA[i] = q8_voff<A_KC, ES>(i, wave, lane, q_lda); cvA[2 + i] = cvA[i] + (unsigned)(A_KC ? q_lda * 128 * ES : 256);
+            cvB[i] = q8_voff<B_KC, ES>(i, wave, lane, q_ldb); cvB[2 + i] = cvB[i] + (unsigned)(B_KC ? q_ldb * 128 * ES : 256);
         }
         if ((A_KC || B_KC) && tail) {
             const int kc0 = (lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7);   // same key for all four pieces (they lie 64 / 128 rows apart)
-            if (kc0 * 8 >= q_krem) {
+            if (kc0 * (16 / ES) >= q_krem) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { if (A_KC) cvA[i] = 0xFFFFFF00u; if (B_KC) cvB[i] = 0xFFFFFF00u; }
             }
@@ -353,12 +382,14 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
             a_step = (int)la_ * 128; b_step = (int)lb_ * 128;                                                            \
             if (la_ != q_lda || lb_ != q_ldb) { q_lda = la_; q_ldb = lb_; q_cv(false); }                                 \
         } else {                                                                                                         \
-            const Q8Item n_ = q8_decode(g, qv, total);                                                                   \
+            const Q8Item n_ = q8_decode<KT_SHIFT>(g, qv, total);                                                         \
+            const unsigned char* Ab_ = reinterpret_cast<const unsigned char*>(g.A);                                      \
+            const unsigned char* Bb_ = reinterpret_cast<const unsigned char*>(g.B);                                      \
             q_krem = n_.kend - n_.kbeg;                                                                                  \
-            if (A_KC) { qa = (const unsigned char*)(A + ((long)n_.m0 * g.lda + n_.kbeg)); qa_rec = (int)((((long)(g.M - n_.m0)) * g.lda - n_.kbeg) * 2); } \
-            else      { qa = (const unsigned char*)(A + ((long)n_.kbeg * g.lda + n_.m0)); qa_rec = (int)(((long)q_krem * g.lda - n_.m0) * 2); }             \
-            if (B_KC) { qb = (const unsigned char*)(B + ((long)n_.n0 * g.ldb + n_.kbeg)); qb_rec = (int)((((long)(g.N - n_.n0)) * g.ldb - n_.kbeg) * 2); } \
-            else      { qb = (const unsigned char*)(B + ((long)n_.kbeg * g.ldb + n_.n0)); qb_rec = (int)(((long)q_krem * g.ldb - n_.n0) * 2); }             \
+            if (A_KC) { qa = Ab_ + ((long)n_.m0 * g.lda + n_.kbeg) * ES; qa_rec = (int)((((long)(g.M - n_.m0)) * g.lda - n_.kbeg) * ES); } \
+            else      { qa = Ab_ + ((long)n_.kbeg * g.lda + n_.m0) * ES; qa_rec = (int)(((long)q_krem * g.lda - n_.m0) * ES); }             \
+            if (B_KC) { qb = Bb_ + ((long)n_.n0 * g.ldb + n_.kbeg) * ES; qb_rec = (int)((((long)(g.N - n_.n0)) * g.ldb - n_.kbeg) * ES); } \
+            else      { qb = Bb_ + ((long)n_.kbeg * g.ldb + n_.n0) * ES; qb_rec = (int)(((long)q_krem * g.ldb - n_.n0) * ES); }             \
         }                                                                                                                \
         qa_rec = max(qa_rec, 0); qb_rec = max(qb_rec, 0);                                                                \
     } while (0)
@@ -381,14 +412,14 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         if (((PART) & 1) == 0) { dA += Q8_HALF; if (dA >= NSLOT * Q8_HALF) dA -= NSLOT * Q8_HALF; }                      \
         else                   { dB += Q8_HALF; if (dB >= 2 * NSLOT * Q8_HALF) dB -= NSLOT * Q8_HALF; }                  \
         if ((PART) == 3) {                                                                                               \
-            q_krem -= 64;                                                                                                \
+            q_krem -= KT;                                                                                                \
             if (!(DBG & 64)) { qa += a_step; qb += b_step; qa_rec = max(qa_rec - a_step, 0); qb_rec = max(qb_rec - b_step, 0); } \
             if (q_krem <= 0) {                                                                                           \
                 qv += G;                                                                                                 \
                 if (qv < total) Q9_ITEM(); else { qa_rec = 0; qb_rec = 0; q_krem = 1 << 30; }                             \
             }                                                                                                            \
             if (A_KC || B_KC) {                                                                                          \
-                const bool tl_ = q_krem < 64;                                                                            \
+                const bool tl_ = q_krem < KT;                                                                            \
                 if (tl_ != q_tail) { q_tail = tl_; q_cv(tl_); }                                                          \
             }                                                                                                            \
         }                                                                                                                \
@@ -485,6 +516,11 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         float al = g.alpha;
         if (g.alpha_dev) {
             float ad = *(cfloat4*)g.alpha_dev;
+            asm volatile("" : "+s"(ad));
+            al *= ad;
+        }
+        if (F8 && g.alpha_dev2) {
+            float ad = *(cfloat4*)g.alpha_dev2;
             asm volatile("" : "+s"(ad));
             al *= ad;
         }
@@ -682,6 +718,56 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         if (!(DBG & 16)) __builtin_amdgcn_s_barrier();                                                                   \
         Q8_SB();                                                                                                         \
     } while (0)
+    // ---- the e4m3 phase: k-step KS8 (64 deep) x row half MH of the wave's tile.  MH = 0 also reads the two N-side fragments of the
+    // k-step, which stay in registers for MH = 1.  Four MFMAs of 64 matrix-pipe cycles = the bf16 phase's 256.
+    Q8Frag8 ym[2], yn[2];
+#define Q9F_MFMA(TMI, NH, ZERO)                                                                                          \
+    acc[2 * MH_ + (TMI)][NH] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(yn[NH].get(), ym[TMI].get(), (ZERO) ? zero16 : acc[2 * MH_ + (TMI)][NH], \
+                                                                               0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)
+#define Q9F_PHASE(KS8, MH, DPART, WAIT, ZERO, PRE_HOOK, MX_HOOK)                                                         \
+    do {                                                                                                                 \
+        constexpr int MH_ = (MH);                                                                                        \
+        if (PRE_HOOK) {                                                                                                  \
+            if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); } \
+            Q8_SB();                                                                                                     \
+        }                                                                                                                \
+        if ((MH) == 0) {                                                                                                 \
+            yn[0].template read<0>(sN + offN[2 * (KS8)], sN + offN[2 * (KS8) + 1]);                                       \
+        }                                                                                                                \
+        ym[0].template read<(2 * (MH)) * 4096>(sM + offM[2 * (KS8)], sM + offM[2 * (KS8) + 1]);                           \
+        ym[1].template read<(2 * (MH) + 1) * 4096>(sM + offM[2 * (KS8)], sM + offM[2 * (KS8) + 1]);                       \
+        if ((MH) == 0) {                                                                                                 \
+            yn[1].template read<4096>(sN + offN[2 * (KS8)], sN + offN[2 * (KS8) + 1]);                                    \
+        }                                                                                                                \
+        Q8_SB();                                                                                                         \
+        Q9_ISSUE(DPART); Q8_SB();                                                                                        \
+        if (WAIT) Q8_WAIT_DMA(4);                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); Q8_SB();                                                      \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+        Q8_SB();                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        Q9F_MFMA(0, 0, ZERO); Q9F_MFMA(0, 1, ZERO); Q8_SB();                                                             \
+        Q9_ADVANCE(DPART);                                                                                               \
+        if (MX_HOOK) { if (cv + G < total) Q9_CDECODE(cv + G); }                                                         \
+        Q8_SB();                                                                                                         \
+        Q9F_MFMA(1, 1, ZERO); Q9F_MFMA(1, 0, ZERO);                                                                      \
+        Q8_SB();                                                                                                         \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+        Q8_SB();                                                                                                         \
+    } while (0)
+#define Q9F_KTILE(FIRST)                                                                                              \
+    do {                                                                                                                 \
+        const int ra_ = rA + wr, rb_ = rB + (wc >> 1);                                                                   \
+        const unsigned char* sM = lds + (ra_ >= NSLOT ? ra_ - NSLOT : ra_) * Q8_HALF;                                    \
+        const unsigned char* sN = lds + (NSLOT + (rb_ >= NSLOT ? rb_ - NSLOT : rb_)) * Q8_HALF;                          \
+        Q9F_PHASE(0, 0, 2, false, FIRST, FIRST, false);                                                               \
+        Q9F_PHASE(0, 1, 3, false, FIRST, false, FIRST);                                                               \
+        Q9F_PHASE(1, 0, 0, false, false, false, false);                                                               \
+        Q9F_PHASE(1, 1, 1, true, false, false, false);                                                                \
+        rA = rA + 2 >= NSLOT ? rA + 2 - NSLOT : rA + 2;                                                                  \
+        rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
+    } while (0)
 #define Q9_KTILE(FIRST)                                                                                               \
     do {                                                                                                                 \
         const int ra_ = rA + wr, rb_ = rB + (wc >> 1);                                                                   \
@@ -733,7 +819,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
             nm0 = cr.m0; nn0 = cr.prob; nz = cr.slab; ncnt = (cr.kend - cr.kbeg + 63) >> 6;                              \
             if (ROWSUM) nrs = (cr.flags & 1) != 0 && wc == 0 && Q8_PROB(cr.prob, rowsum) != nullptr;                     \
         } else {                                                                                                         \
-            const Q8Item cit = q8_decode(g, V_, total);                                                                  \
+            const Q8Item cit = q8_decode<KT_SHIFT>(g, V_, total);                                                        \
             nm0 = cit.m0; nn0 = cit.n0; nz = cit.z; ncnt = cit.nt;                                                       \
             if (ROWSUM) nrs = g.rowsum != nullptr && wc == 0 && cit.ncol == 0;                                           \
         }                                                                                                                \
@@ -743,9 +829,15 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         for (int cv = it_beg; cv < total; cv += G) {
             const int cm0 = nm0, cn0 = nn0, cz = nz, cnt = ncnt;
             if (ROWSUM) { rs_on = nrs; rs_ones = rs_on ? 0x3f803f80u : 0u; }
-            Q9_KTILE(true);
+            if constexpr (F8) {
+                Q9F_KTILE(true);
 #pragma unroll 1
-            for (int t = 1; t < cnt; ++t) Q9_KTILE(false);
+                for (int t = 1; t < cnt; ++t) Q9F_KTILE(false);
+            } else {
+                Q9_KTILE(true);
+#pragma unroll 1
+                for (int t = 1; t < cnt; ++t) Q9_KTILE(false);
+            }
             have_pend = true; pm0 = cm0; pn0 = cn0; pz = cz;
             if (ROWSUM) {
                 rsp_on = rs_on; rsp_m0 = cm0; rsp_prob = cn0;
@@ -790,6 +882,9 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
 #undef Q8_KTILE
 #undef Q8_PHASE
 #undef Q9_KTILE
+#undef Q9F_KTILE
+#undef Q9F_PHASE
+#undef Q9F_MFMA
 #undef Q9_PHASE
 #undef Q9_ISSUE
 #undef Q9_ADVANCE
@@ -805,6 +900,12 @@ template <bool A_KC, bool B_KC, int EPI, int DBG = 0, bool ROWSUM = false, int S
 __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
     Q8Group none;   // never read in this form
     q8_body<A_KC, B_KC, EPI, DBG, ROWSUM, false, SCH>(g, none);
+}
+// e4m3 forward form (per-tensor scales in g.alpha_dev / g.alpha_dev2)
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f8_q8_kernel(GemmArgs g) {
+    Q8Group none;
+    q8_body<true, true, EPI, 0, false, false, 1, true>(g, none);
 }
 // grouped weight gradients: `g` only supplies the fields the item-table form does not take from the group (none of the operands)
 template <bool ROWSUM, int SCH = 0>

@@ -51,12 +51,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                      long rows, int cols, float eps, float drop_p, uint64_t seed,
-                                                     uint64_t offset) {
+                                                     uint64_t offset, unsigned char* __restrict__ q8, const float* __restrict__ q8_scale,
+                                                     float* __restrict__ q8_amax) {
     typedef LnVec<T, VEC> V;
     typedef typename V::raw_t raw_t;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    // q8 (fp8 forward, delayed scaling): an e4m3 copy of the (storage-rounded) output for the GEMM that consumes it, quantised with the
+    // site's current scale, and this step's |y| maximum into the site's amax slots -- no separate amax / quantise pass over y
+    const float q8_inv = q8 ? 1.0f / fmaxf(q8_scale[0], 1e-30f) : 0.f;
+    float q8_max = 0.f;
     const int nv = cols / VEC;
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     // every load of the row is issued before the first value is consumed
@@ -133,7 +138,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                 o[4 * k + 3] = (v[i][4 * k + 3] - mu) * rs * g.w + b.w;
             }
             *reinterpret_cast<raw_t*>(y + row * cols + c * VEC) = V::pack(o);
+            if (q8) {
+                unsigned int w[VEC / 4];
+#pragma unroll
+                for (int k = 0; k < VEC / 4; ++k) {
+                    float u[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float yr = rnd<T>(o[4 * k + r]);
+                        q8_max = fmaxf(q8_max, fabsf(yr));
+                        u[r] = fminf(fmaxf(yr * q8_inv, -448.f), 448.f);
+                    }
+                    int ww = 0;
+                    ww = __builtin_amdgcn_cvt_pk_fp8_f32(u[0], u[1], ww, false);
+                    ww = __builtin_amdgcn_cvt_pk_fp8_f32(u[2], u[3], ww, true);
+                    w[k] = (unsigned int)ww;
+                }
+                if constexpr (VEC == 8) *reinterpret_cast<uint2*>(q8 + row * cols + c * VEC) = make_uint2(w[0], w[1]);
+                else *reinterpret_cast<unsigned int*>(q8 + row * cols + c * VEC) = w[0];
+            }
         }
+    }
+    if (q8) {
+        q8_max = wave_max(q8_max);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(q8_amax + (blockIdx.x & 15) * 32), __float_as_uint(q8_max));
     }
 }
 
@@ -147,7 +175,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // 8-wide form of a 768- or 1024-column row (two chunks per lane: 16 + 16 column partials) stays clear of scratch.
 // (the 8-wide form of a 768- / 1024-column row needs ~150 registers: it runs twelve waves per CU -- 168 registers -- whose one-row
 // prefetch still keeps 12 x 3-4.5 KB per CU in flight)
-template <typename T, int IT, int VEC, int LN_BWD_WAVES>
+// GREG: gamma lives in registers (the 4-wide forms: 12 values per lane for a 768-column row); otherwise it is staged once into LDS
+// behind the reduction slices and read from there in both passes over a row (the 8-wide two-chunk form has no 16 registers to spare;
+// re-reading it from L1 put eight dependent vector loads into every row's chain: 42 instead of 32 us per call inside the step)
+template <typename T, int IT, int VEC, int LN_BWD_WAVES, bool GREG>
 __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
@@ -161,10 +192,29 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
     const int nv = cols / VEC;
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     float ag[IT][VEC], ab[IT][VEC];
+    float gmr[GREG ? IT : 1][VEC];
+    float* shg = sh + 8 * cols;   // [cols] gamma (only when !GREG)
 #pragma unroll
-    for (int i = 0; i < IT; ++i)
+    for (int i = 0; i < IT; ++i) {
+        const int c = lane + 64 * i;
 #pragma unroll
         for (int r = 0; r < VEC; ++r) ag[i][r] = ab[i][r] = 0.f;
+        if (GREG) {
+#pragma unroll
+            for (int k = 0; k < VEC / 4; ++k) {
+                const float4 g4 = c < nv ? *reinterpret_cast<const float4*>(gamma + c * VEC + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gmr[i][4 * k] = g4.x; gmr[i][4 * k + 1] = g4.y; gmr[i][4 * k + 2] = g4.z; gmr[i][4 * k + 3] = g4.w;
+            }
+        }
+    }
+    if (!GREG) {
+        for (int c = threadIdx.x; c < cols; c += LN_BWD_WAVES * 64) shg[c] = gamma[c];
+        __syncthreads();
+    }
+    auto gam = [&](int i, int c, int k, float (&o4)[4]) __attribute__((always_inline)) {   // gamma of columns c * VEC + 4 k .. + 3
+        if (GREG) { o4[0] = gmr[GREG ? i : 0][4 * k]; o4[1] = gmr[GREG ? i : 0][4 * k + 1]; o4[2] = gmr[GREG ? i : 0][4 * k + 2]; o4[3] = gmr[GREG ? i : 0][4 * k + 3]; }
+        else { const float4 g4 = *reinterpret_cast<const float4*>(shg + c * VEC + 4 * k); o4[0] = g4.x; o4[1] = g4.y; o4[2] = g4.z; o4[3] = g4.w; }
+    };
     // rows are software-pipelined: the loads of a wave's NEXT row are in flight while the current row is reduced, normalised and
     // stored (a row is a dependent chain load -> two wave reductions -> store; without the prefetch a CU has no load outstanding
     // for about half of it)
@@ -178,30 +228,38 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
         for (int i = 0; i < IT; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
-                rdy[i] = *reinterpret_cast<const raw_t*>(dy + row * cols + c * VEC);
-                rz[i] = *reinterpret_cast<const raw_t*>(z + row * cols + c * VEC);
-                if (dres) rq[i] = *reinterpret_cast<const raw_t*>(dres + row * cols + c * VEC);
+                rdy[i] = *reinterpret_cast<const raw_t*>(dy + ((unsigned)(row * cols) + (unsigned)(c * VEC)));
+                rz[i] = *reinterpret_cast<const raw_t*>(z + ((unsigned)(row * cols) + (unsigned)(c * VEC)));
             }
         }
     };
+    // the residual gradient is only consumed at the end of a row: its prefetch for the next row is issued there (no second copy)
+    auto fetch_q = [&](long row) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) rq[i] = *reinterpret_cast<const raw_t*>(dres + ((unsigned)(row * cols) + (unsigned)(c * VEC)));
+        }
+    };
     long row = (long)blockIdx.x * LN_BWD_WAVES + wave;
-    if (row < rows) fetch(row);
+    if (row < rows) { fetch(row); if (dres) fetch_q(row); }
     for (; row < rows; row += stride) {
         const float mu = nmu, rs = nrs;
-        raw_t cdy[IT], cz[IT], cq[IT];   // the current row, as it lies in memory
+        raw_t cdy[IT], cz[IT];   // the current row, as it lies in memory
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int c = lane + 64 * i;
-            cdy[i] = rdy[i]; cz[i] = rz[i]; cq[i] = rq[i];
+            cdy[i] = rdy[i]; cz[i] = rz[i];
             if (c < nv) {
                 float d[VEC], zz[VEC], gm[VEC];
                 V::cvt(cdy[i], d);
                 V::cvt(cz[i], zz);
 #pragma unroll
                 for (int k = 0; k < VEC / 4; ++k) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * VEC + 4 * k);
-                    gm[4 * k] = g4.x; gm[4 * k + 1] = g4.y; gm[4 * k + 2] = g4.z; gm[4 * k + 3] = g4.w;
+                    float g4[4];
+                    gam(i, c, k, g4);
+                    gm[4 * k] = g4[0]; gm[4 * k + 1] = g4[1]; gm[4 * k + 2] = g4[2]; gm[4 * k + 3] = g4[3];
                 }
 #pragma unroll
                 for (int r = 0; r < VEC; ++r) {
@@ -225,8 +283,8 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
                 V::cvt(cz[i], zz);
 #pragma unroll
                 for (int k = 0; k < VEC / 4; ++k) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * VEC + 4 * k);
-                    const float gm[4] = {g4.x, g4.y, g4.z, g4.w};
+                    float gm[4];
+                    gam(i, c, k, gm);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xh = (zz[4 * k + r] - mu) * rs, g = d[4 * k + r] * gm[r];
@@ -235,11 +293,11 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
                 }
                 if (dres) {
                     float q[VEC];
-                    V::cvt(cq[i], q);
+                    V::cvt(rq[i], q);
 #pragma unroll
                     for (int r = 0; r < VEC; ++r) o[r] += q[r];
                 }
-                *reinterpret_cast<raw_t*>(dz + row * cols + c * VEC) = V::pack(o);
+                *reinterpret_cast<raw_t*>(dz + ((unsigned)(row * cols) + (unsigned)(c * VEC))) = V::pack(o);
                 if (dxdrop) {
                     if (drop_p > 0.f) {
                         float m[VEC];
@@ -247,10 +305,11 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
 #pragma unroll
                         for (int r = 0; r < VEC; ++r) o[r] = rnd<T>(o[r]) * m[r];
                     }
-                    *reinterpret_cast<raw_t*>(dxdrop + row * cols + c * VEC) = V::pack(o);
+                    *reinterpret_cast<raw_t*>(dxdrop + ((unsigned)(row * cols) + (unsigned)(c * VEC))) = V::pack(o);
                 }
             }
         }
+        if (dres && row + stride < rows) fetch_q(row + stride);
     }
     // workgroup reduction of the per-lane column partials, then one global atomic per column
     for (int pass = 0; pass < 2; ++pass) {
@@ -292,10 +351,11 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
 
 template <typename T>
 static int ln_fwd_launch(const void* x, const void* res, void* z, const float* gamma, const float* beta, void* y, float* mean,
-                         float* rstd, long rows, int cols, float eps, float p, uint64_t seed, uint64_t off, hipStream_t st) {
+                         float* rstd, long rows, int cols, float eps, float p, uint64_t seed, uint64_t off, hipStream_t st,
+                         void* q8 = nullptr, const float* q8_scale = nullptr, float* q8_amax = nullptr) {
     dim3 grid(ceil_div(rows, 4)), block(256);
     auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-#define L(IT_, V_) hipLaunchKernelGGL((ln_fwd_kernel<T, IT_, V_>), grid, block, 0, st, (const T*)x, (const T*)res, (T*)z, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, p, seed, off)
+#define L(IT_, V_) hipLaunchKernelGGL((ln_fwd_kernel<T, IT_, V_>), grid, block, 0, st, (const T*)x, (const T*)res, (T*)z, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, p, seed, off, (unsigned char*)q8, q8_scale, q8_amax)
     if constexpr (sizeof(T) == 2) {
         if (cols % 8 == 0 && al16(x) && al16(res) && al16(z) && al16(y)) {   // 16-B lane accesses
             const int it8 = ceil_div(cols / 8, 64);
@@ -326,25 +386,44 @@ template <typename T>
 static int ln_bwd_launch(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                          const void* dres, void* dz, void* dxdrop, float* dgamma, float* dbeta, long rows, int cols, float p,
                          uint64_t seed, uint64_t off, hipStream_t st) {
-    size_t shm = (size_t)8 * cols * sizeof(float);
+    size_t shm = (size_t)9 * cols * sizeof(float);   // eight reduction slices + gamma
+    static const int variant = getenv("ECAMP_LN_BWD") ? atoi(getenv("ECAMP_LN_BWD")) : 0;   // development: 1 = 4-wide forms only
     auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-#define L(IT_, V_, W_)                                                                                                   \
+#define L(IT_, V_, W_, G_)                                                                                               \
     do {                                                                                                                 \
         int nb = ceil_div(rows, W_);                                                                                     \
         if (nb > 256) nb = 256;                                                                                          \
-        hipLaunchKernelGGL((ln_bwd_kernel<T, IT_, V_, W_>), dim3(nb), dim3(W_ * 64), shm, st, (const T*)dy, (const T*)z, mean, rstd, gamma, \
+        hipLaunchKernelGGL((ln_bwd_kernel<T, IT_, V_, W_, G_>), dim3(nb), dim3(W_ * 64), shm, st, (const T*)dy, (const T*)z, mean, rstd, gamma, \
                            (const T*)dres, (T*)dz, (T*)dxdrop, dgamma, dbeta, rows, cols, p, seed, off);                 \
     } while (0)
     if constexpr (sizeof(T) == 2) {
-        if (cols % 8 == 0 && cols <= 1024 && al16(dy) && al16(z) && al16(dres) && al16(dz) && al16(dxdrop)) {   // 16-B lane accesses
+        if (variant != 1 && cols % 8 == 0 && cols <= 1024 && al16(dy) && al16(z) && al16(dres) && al16(dz) && al16(dxdrop)) {   // 16-B lane accesses
             const int it8 = ceil_div(cols / 8, 64);
-            if (it8 <= 1) L(1, 8, 16); else L(2, 8, 12);
-            return 0;
+            // measured inside the step (profiles/r04_ln_variants.txt): one 16-B chunk per lane (<= 512 columns) beats two 8-B ones
+            // (37.2 vs 38.3 us), the 1024-column row needs the two-chunk 16-B form (27.6 vs 62 us: the 4-wide form spills), and the
+            // 768-column row is better off 4-wide with sixteen waves (32.4 vs 34.5 us)
+            if (it8 <= 1) { L(1, 8, 16, true); return 0; }
+            if (variant == 2 || cols > 768) { L(2, 8, 12, false); return 0; }
         }
     }
     const int it = ceil_div(cols / 4, 64);
-    if (it <= 1) L(1, 4, 16); else if (it <= 2) L(2, 4, 16); else if (it <= 3) L(3, 4, 16); else if (it <= 4) L(4, 4, 16); else L(8, 4, 16);
+    if (it <= 1) L(1, 4, 16, true); else if (it <= 2) L(2, 4, 16, true); else if (it <= 3) L(3, 4, 16, true); else if (it <= 4) L(4, 4, 16, true); else L(8, 4, 16, true);
 #undef L
+    return 0;
+}
+
+// ecamp_layernorm_fwd that also leaves q8 [rows, cols] = e4m3(clamp(y / q8_scale[0], +-448)) and max|y| in the site's 16 amax slots
+// (ecamp_quant_fp8_delayed's convention): the fp8 forward's quantisation folded into the producer of the GEMM input
+extern "C" int ecamp_layernorm_fwd_q8(const void* x, const void* residual, void* z_out, const float* gamma, const float* beta,
+                                      void* y, float* mean, float* rstd, int64_t rows, int32_t cols, float eps, float drop_p,
+                                      uint64_t seed, uint64_t offset, void* q8, const float* q8_scale, float* q8_amax_slots,
+                                      int32_t dtype, hipStream_t stream) {
+    ECAMP_CHECK_ARG(x && gamma && beta && y && mean && rstd && q8 && q8_scale && q8_amax_slots, "layernorm_fwd_q8: null pointer");
+    ECAMP_CHECK_ARG(cols % 4 == 0 && cols <= 2048 && rows > 0, "layernorm_fwd_q8: cols=%d must be a multiple of 4 and <= 2048", cols);
+    ECAMP_CHECK_ARG(!(residual || drop_p > 0.f) || z_out, "layernorm_fwd_q8: fused residual/dropout needs z_out");
+    ECAMP_CHECK_ARG(dtype == ECAMP_BF16 && (reinterpret_cast<uintptr_t>(q8) & 7) == 0, "layernorm_fwd_q8: bf16 rows, 8-byte aligned q8");
+    ln_fwd_launch<bf16_t>(x, residual, z_out, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p, seed, offset, stream, q8, q8_scale, q8_amax_slots);
+    ECAMP_LAUNCH_CHECK();
     return 0;
 }
 
@@ -354,6 +433,7 @@ extern "C" int ecamp_layernorm_bwd(const void* dy, const void* z, const float* m
                                    hipStream_t stream) {
     ECAMP_CHECK_ARG(dy && z && mean && rstd && gamma && dz && dgamma && dbeta, "layernorm_bwd: null pointer");
     ECAMP_CHECK_ARG(cols % 4 == 0 && cols <= 2048 && rows > 0, "layernorm_bwd: cols=%d must be a multiple of 4 and <= 2048", cols);
+    ECAMP_CHECK_ARG(rows * (int64_t)cols < (1ll << 30), "layernorm_bwd: rows * cols must stay below 2^30 (32-bit element offsets)");
     if (dtype == ECAMP_F32) ln_bwd_launch<float>(dy, z, mean, rstd, gamma, dres_in, dz, dx_drop, dgamma, dbeta, rows, cols, drop_p, seed, offset, stream);
     else if (dtype == ECAMP_BF16) ln_bwd_launch<bf16_t>(dy, z, mean, rstd, gamma, dres_in, dz, dx_drop, dgamma, dbeta, rows, cols, drop_p, seed, offset, stream);
     else return ecamp_set_error(-1, "layernorm_bwd: bad dtype %d", dtype);

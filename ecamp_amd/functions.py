@@ -84,14 +84,44 @@ def _wgrad(A, dy, x, w, gb=None, alpha_dev=None, shape=None):
     ops.linear_wgrad_async(dy, x, gw, alpha_dev=alpha_dev, gb=gb, accumulate=acc)
 
 
-def _vit_linear(m, x, lin, **kw):
-    """Forward of a timm Attention.qkv / proj or Mlp.fc1 / fc2 layer: bf16 GEMM, or -- model.fp8_forward, BASELINE configs[4] --
-    the e4m3 GEMM on per-tensor-quantised copies of x and the weight.  The backward is the bf16 one either way."""
+def _f8_site(m, x, weights):
+    """fp8 forward (configs[4]), delayed scaling: (scale, amax slots) to hand to `ops.layernorm_fwd(q8_site=...)` when the LayerNorm's
+    output `x`-to-be feeds the e4m3 GEMM of `weights` and that site has been calibrated (its first use runs the two-pass scaling)."""
+    if not (m.fp8_forward and x.dtype == torch.bfloat16):
+        return None
+    _, sc, am, cal = m.arena.f8_site(weights)
+    return (sc, am) if cal else None
+
+
+def _dense(m, x, weights, bias, shape=None, x8=None, **kw):
+    """Forward of a dense layer y = act(x W^T + b) (+ residual).  `weights`: one parameter or a list of arena-adjacent ones run as a
+    single [N, K] = `shape` GEMM (BERT's fused query/key/value).  bf16 GEMM, or -- model.fp8_forward, BASELINE configs[4]: the ViT
+    qkv / proj / fc1 / fc2 layers and the BERT / fusion dense layers -- the e4m3 GEMM on per-tensor-scaled copies: the weight's is
+    re-quantised once per optimizer step (ParamArena.w8), the activation's comes from its producer (`x8`: a LayerNorm that quantised
+    its own output) or from ONE pass over x with the site's delayed scale.  The backward is the bf16 one either way."""
     A = m.arena
+    plist = list(weights) if isinstance(weights, (list, tuple)) else [weights]
     if m.fp8_forward and x.dtype == torch.bfloat16:
-        w8, ws = A.w8(lin.weight)
-        return ops.linear_fwd_fp8(x, w8, ws, lin.bias.data, **kw)
-    return ops.linear_fwd(x, A.w(lin.weight), lin.bias.data, **kw)
+        i, sc, am, cal = A.f8_site(plist)
+        if x8 is None:
+            x8 = ops.quantize_fp8_site(x, sc, am, cal)
+            A.f8_cal.add(i)
+        w8, ws = A.w8(plist, shape)
+        return ops.gemm_fp8(x8, sc, w8, ws, bias, **kw)
+    w = A.fused_w(plist, shape) if len(plist) > 1 else A.w(plist[0])
+    return ops.linear_fwd(x, w, bias, **kw)
+
+
+def _vit_linear(m, x, lin, x8=None, **kw):
+    """Forward of a timm Attention.qkv / proj or Mlp.fc1 / fc2 layer (see _dense)."""
+    return _dense(m, x, lin.weight, lin.bias.data, x8=x8, **kw)
+
+
+def _ln_q8(m, x, ln, weights, eps=None, **kw):
+    """LayerNorm whose output feeds the dense layer of `weights`: -> (y, z, mean, rstd, y8 or None)."""
+    site = _f8_site(m, x, weights)
+    r = ops.layernorm_fwd(x, ln.weight.data, ln.bias.data, ln.eps if eps is None else eps, q8_site=site, **kw)
+    return r if site is not None else r + (None,)
 
 
 # =============================================================================================
@@ -136,15 +166,15 @@ class VitBlockFn(torch.autograd.Function):
         D = x.shape[1]
         hd = D // heads
         eps = blk.norm1.eps
-        h, _, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight.data, blk.norm1.bias.data, eps)
-        qkv = _vit_linear(m, h, blk.attn.qkv)
+        h, _, mean1, rstd1, h8 = _ln_q8(m, x, blk.norm1, blk.attn.qkv.weight)
+        qkv = _vit_linear(m, h, blk.attn.qkv, x8=h8)
         st = (T * 3 * D, 3 * D, hd)
         flat = qkv.view(-1)
         a, lse = ops.attn_fwd(flat, flat[D:], flat[2 * D:], B, heads, T, T, hd, st, st, st, hd ** -0.5)
         a = a.view(B * T, D)
         x1 = _vit_linear(m, a, blk.attn.proj, residual=x)
-        h2, _, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight.data, blk.norm2.bias.data, eps)
-        u, pre = _vit_linear(m, h2, blk.mlp.fc1, act=1, save_pre=True)
+        h2, _, mean2, rstd2, h28 = _ln_q8(m, x1, blk.norm2, blk.mlp.fc1.weight)
+        u, pre = _vit_linear(m, h2, blk.mlp.fc1, x8=h28, act=1, save_pre=True)
         x2 = _vit_linear(m, u, blk.mlp.fc2, residual=x1)
         ctx.s = (x, mean1, rstd1, h, qkv, a, lse, x1, mean2, rstd2, h2, pre, u)
         ctx.cfg = (blk, m, B, T, heads)
@@ -401,7 +431,7 @@ def _qkv_params(att):
     return [att.query, att.key, att.value]
 
 
-def _self_attn_fwd(m, att, out, h, B, S, key_mask, pa, ph, tape):
+def _self_attn_fwd(m, att, out, h, B, S, key_mask, pa, ph, tape, next_w=None):
     """BertAttention: LN(dropout(dense(SelfAttn(h))) + h).  q/k/v projections run as ONE GEMM over the
     arena-adjacent [3H,H] weight block."""
     A = m.arena
@@ -409,20 +439,21 @@ def _self_attn_fwd(m, att, out, h, B, S, key_mask, pa, ph, tape):
     heads = m.bert_config.num_attention_heads
     hd = H // heads
     qkvp = _qkv_params(att)
-    w3 = A.fused_w([l.weight for l in qkvp], (3 * H, H))
     b3 = A.fused_f32([l.bias for l in qkvp], (3 * H,))
-    qkv = ops.linear_fwd(h, w3, b3)
+    qkv = _dense(m, h, [l.weight for l in qkvp], b3, shape=(3 * H, H))
     st = (S * 3 * H, 3 * H, hd)
     f = qkv.view(-1)
     s1, o1 = m.next_rng()
     a, lse, bits = ops.attn_fwd(f, f[H:], f[2 * H:], B, heads, S, S, hd, st, st, st, 1.0 / math.sqrt(hd), key_mask, pa, s1, o1, want_mask=True)
     a = a.view(B * S, H)
-    y = ops.linear_fwd(a, A.w(out.dense.weight), out.dense.bias.data)
+    y = _dense(m, a, out.dense.weight, out.dense.bias.data)
     s2, o2 = m.next_rng()
     ln = out.LayerNorm
-    o, z, mean, rstd = ops.layernorm_fwd(y, ln.weight.data, ln.bias.data, ln.eps, residual=h, drop_p=ph, seed=s2, offset=o2)
+    # (`next_w`: the dense layer this LayerNorm's output feeds -- its e4m3 copy is made here when that site is calibrated)
+    o, z, mean, rstd, o8 = _ln_q8(m, y, ln, next_w, residual=h, drop_p=ph, seed=s2, offset=o2) if next_w is not None else \
+        ops.layernorm_fwd(y, ln.weight.data, ln.bias.data, ln.eps, residual=h, drop_p=ph, seed=s2, offset=o2) + (None,)
     tape.append((att, out, h, qkv, a, lse, z, mean, rstd, (s1, o1), (s2, o2), bits))
-    return o
+    return (o, o8) if next_w is not None else o
 
 
 def _self_attn_bwd(m, rec, dout, B, S, key_mask, pa, ph):
@@ -451,11 +482,11 @@ def _self_attn_bwd(m, rec, dout, B, S, key_mask, pa, ph):
     return dh
 
 
-def _ffn_fwd(m, inter, out, x, ph, tape):
+def _ffn_fwd(m, inter, out, x, ph, tape, x8=None):
     """BertIntermediate + BertOutput: LN(dropout(W2 gelu(W1 x)) + x)."""
     A = m.arena
-    u, pre = ops.linear_fwd(x, A.w(inter.dense.weight), inter.dense.bias.data, act=1, save_pre=True)
-    y = ops.linear_fwd(u, A.w(out.dense.weight), out.dense.bias.data)
+    u, pre = _dense(m, x, inter.dense.weight, inter.dense.bias.data, x8=x8, act=1, save_pre=True)
+    y = _dense(m, u, out.dense.weight, out.dense.bias.data)
     s, o = m.next_rng()
     ln = out.LayerNorm
     r, z, mean, rstd = ops.layernorm_fwd(y, ln.weight.data, ln.bias.data, ln.eps, residual=x, drop_p=ph, seed=s, offset=o)
@@ -484,8 +515,8 @@ class BertLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, layer, m, B, S, key_mask, pa, ph):
         tape = []
-        a = _self_attn_fwd(m, layer.attention.self, layer.attention.output, h, B, S, key_mask, pa, ph, tape)
-        o = _ffn_fwd(m, layer.intermediate, layer.output, a, ph, tape)
+        a, a8 = _self_attn_fwd(m, layer.attention.self, layer.attention.output, h, B, S, key_mask, pa, ph, tape, next_w=layer.intermediate.dense.weight)
+        o = _ffn_fwd(m, layer.intermediate, layer.output, a, ph, tape, x8=a8)
         ctx.s = (tape, m, B, S, key_mask, pa, ph)
         return o
 
@@ -512,10 +543,9 @@ class FusionFn(torch.autograd.Function):
         tape = []
         a1 = _self_attn_fwd(m, fl.attention.self, fl.attention.output, e, B, S, key_mask, pa, ph, tape)
         ca = fl.cross_self_attention
-        q = ops.linear_fwd(a1, A.w(ca.query.weight), ca.query.bias.data)
-        wkv = A.fused_w([ca.key.weight, ca.value.weight], (2 * H, H))
+        q = _dense(m, a1, ca.query.weight, ca.query.bias.data)
         bkv = A.fused_f32([ca.key.bias, ca.value.bias], (2 * H,))
-        kv = ops.linear_fwd(lat, wkv, bkv)  # [B*T, 2H]; token 0 (cls) is skipped by the attention via a pointer offset
+        kv = _dense(m, lat, [ca.key.weight, ca.value.weight], bkv, shape=(2 * H, H))  # [B*T, 2H]; token 0 (cls) is skipped by the attention via a pointer offset
         f = kv.view(-1)
         qs, ks = (S * H, H, hd), (T * 2 * H, 2 * H, hd)
         s1, o1 = m.next_rng()
@@ -523,11 +553,10 @@ class FusionFn(torch.autograd.Function):
         gp = ops.linear_fwd(gap, A.w(fl.gap_mlp.weight), fl.gap_mlp.bias.data)
         c2 = ops.bcast_add(c, gp).view(B * S, H)
         ol = fl.out_layer
-        y = ops.linear_fwd(c2, A.w(ol.dense.weight), ol.dense.bias.data)
+        y = _dense(m, c2, ol.dense.weight, ol.dense.bias.data)
         s2, o2 = m.next_rng()
-        a2, z, mean, rstd = ops.layernorm_fwd(y, ol.LayerNorm.weight.data, ol.LayerNorm.bias.data, ol.LayerNorm.eps, residual=a1,
-                                              drop_p=ph, seed=s2, offset=o2)
-        out = _ffn_fwd(m, fl.intermediate, fl.output, a2, ph, tape)
+        a2, z, mean, rstd, a28 = _ln_q8(m, y, ol.LayerNorm, fl.intermediate.dense.weight, residual=a1, drop_p=ph, seed=s2, offset=o2)
+        out = _ffn_fwd(m, fl.intermediate, fl.output, a2, ph, tape, x8=a28)
         ctx.s = (tape, e, lat, gap, fl, m, B, S, T, key_mask, pa, ph, a1, q, kv, c, lse, c2, z, mean, rstd, (s1, o1), (s2, o2), cbits)
         return out
 

@@ -74,6 +74,41 @@ def quantize_fp8(x):
     return q, scale
 
 
+def fp8_roll(amax_slots, scale):
+    """Delayed scaling, once per optimizer step: scale[i] = max(site i's 16 amax slots) / 448 where a producer fed the site; slots = 0."""
+    call("ecamp_fp8_roll", ptr(amax_slots), ptr(scale), scale.numel(), stream())
+
+
+def fp8_weights(w16, w8, items, amax_slots, scales, pass_):
+    """One pass of the whole-arena weight quantisation (ParamArena._quantize_weights): 0 = per-matrix maxima, 1 = quantise."""
+    call("ecamp_fp8_weights", ptr(w16), ptr(w8), ptr(items), items.shape[0], ptr(amax_slots), ptr(scales), int(pass_), stream())
+
+
+def quantize_fp8_site(x, scale, amax_slots, calibrated):
+    """e4m3 copy of x for a GEMM-input site (ParamArena.f8_site).  Calibrated: ONE pass -- quantise with the site's scale (the
+    previous step's maximum), record this step's maximum.  First use: the two-pass current scaling, which seeds scale and slots."""
+    assert x.is_contiguous() and x.numel() % 4 == 0
+    q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    if calibrated:
+        call("ecamp_quant_fp8_delayed", ptr(x), ptr(scale), ptr(q), ptr(amax_slots), x.numel(), code(x.dtype), stream())
+    else:
+        call("ecamp_amax", ptr(x), ptr(amax_slots), x.numel(), code(x.dtype), stream())
+        call("ecamp_quant_fp8", ptr(x), ptr(amax_slots), ptr(q), ptr(scale), x.numel(), code(x.dtype), stream())
+    return q
+
+
+def gemm_fp8(x8, x_scale, w8, w_scale, bias=None, act=0, residual=None, save_pre=False):
+    """y (bf16) = act(dequant(x8) @ dequant(w8).T + bias) (+ residual) on the e4m3 GEMM (ecamp_gemm_fp8): x8 [M,K], w8 [N,K] uint8."""
+    M, K = x8.shape
+    N = w8.shape[0]
+    assert w8.shape[1] == K and w8.dtype == torch.uint8 and x8.dtype == torch.uint8 and x8.is_contiguous() and w8.is_contiguous()
+    y = torch.empty((M, N), device=x8.device, dtype=torch.bfloat16)
+    pre = torch.empty((M, N), device=x8.device, dtype=torch.bfloat16) if save_pre else None
+    call("ecamp_gemm_fp8", ptr(x8), ptr(w8), ptr(y), M, N, K, K, K, N, ptr(x_scale), ptr(w_scale), ptr(bias), ptr(residual),
+         residual.stride(0) if residual is not None else 0, ptr(pre), N, int(act), stream())
+    return (y, pre) if save_pre else y
+
+
 def linear_fwd_fp8(x, w8, w_scale, bias=None, act=0, residual=None, save_pre=False):
     """y (bf16) = act(dequant(q(x)) @ dequant(w8).T + bias) (+ residual): x [M,K] bf16 is quantised here, w8 [N,K] uint8 + scale
     come from `quantize_fp8(weight)` (once per optimizer step).  The backward of the layer keeps using the bf16 x and w."""
@@ -190,8 +225,10 @@ def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):
 
 
 # --------------------------------------------------------------------------------------------- layernorm
-def layernorm_fwd(x, gamma, beta, eps, residual=None, drop_p=0.0, seed=0, offset=0):
-    """-> (y, z, mean, rstd);  z is x itself unless residual/dropout are fused (then the materialised LN input)."""
+def layernorm_fwd(x, gamma, beta, eps, residual=None, drop_p=0.0, seed=0, offset=0, q8_site=None):
+    """-> (y, z, mean, rstd);  z is x itself unless residual/dropout are fused (then the materialised LN input).
+    q8_site = (scale f32[1], amax slots f32[512]) of the GEMM that consumes y (fp8 forward, calibrated site): a fifth result, the e4m3
+    copy of y quantised inside this kernel (ecamp_layernorm_fwd_q8)."""
     _chk(x, gamma, beta)
     rows, cols = x.shape
     assert x.is_contiguous()
@@ -200,6 +237,11 @@ def layernorm_fwd(x, gamma, beta, eps, residual=None, drop_p=0.0, seed=0, offset
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
     fused = residual is not None or drop_p > 0.0
     z = torch.empty_like(x) if fused else None
+    if q8_site is not None:
+        y8 = torch.empty((rows, cols), device=x.device, dtype=torch.uint8)
+        call("ecamp_layernorm_fwd_q8", ptr(x), ptr(residual), ptr(z), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, cols,
+             float(eps), float(drop_p), seed, offset, ptr(y8), ptr(q8_site[0]), ptr(q8_site[1]), code(x.dtype), stream())
+        return y, (z if fused else x), mean, rstd, y8
     call("ecamp_layernorm_fwd", ptr(x), ptr(residual), ptr(z), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, cols,
          float(eps), float(drop_p), seed, offset, code(x.dtype), stream())
     return y, (z if fused else x), mean, rstd

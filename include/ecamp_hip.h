@@ -92,6 +92,22 @@ int ecamp_set_option(const char* name, int32_t value);
  *                   (call sites model_ecamp.py:233-234, 254-255).  K, lda, ldb multiples of 16 bytes.  f32 accumulation on
  *                   v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales. */
 int ecamp_amax(const void* x, float* out, int64_t n, int32_t dtype, ecampStream_t stream);
+/* Delayed per-tensor scaling (round 4): a GEMM input site owns scale[0] (f32: what its producer quantises with and ecamp_gemm_fp8
+ * dequantises with during this optimizer step) and 16 amax slots 32 floats apart (512 floats per site; what this step's producers saw).
+ *   ecamp_quant_fp8_delayed  q[i] = e4m3(clamp(x[i] / scale[0], +-448)); amax_slots[(workgroup & 15) * 32] = max(., |x|)  -- one pass
+ *   ecamp_fp8_roll           per site i < n: a = max over its slots; if a > 0: scale[i] = a / 448; slots = 0   (once per optimizer step)
+ *   ecamp_layernorm_fwd_q8   ecamp_layernorm_fwd that also writes the e4m3 copy of y (same conventions): the quantisation folded into
+ *                            the producer of the GEMM input (nn.LayerNorm sites model_ecamp.py:69,84,235,256; BertSelfOutput / BertOutput) */
+int ecamp_quant_fp8_delayed(const void* x, const float* scale, void* q, float* amax_slots, int64_t n, int32_t dtype, ecampStream_t stream);
+int ecamp_fp8_roll(float* amax_slots, float* scale, int32_t n, ecampStream_t stream);
+/* The e4m3 copies of all weights of a flat bf16 arena in two launches per optimizer step (exact per-matrix scaling): items = DEVICE table
+ * of int32[4] {first element (multiple of 4), count (multiple of 4, <= 65536), scale id, 0}, one workgroup each.  pass 0: the item's
+ * max|w| into the amax slots of its scale id; (ecamp_fp8_roll); pass 1: w8[i] = e4m3(clamp(w[i] / scales[id], +-448)). */
+int ecamp_fp8_weights(const void* w_bf16, void* w8, const int32_t* items, int32_t nitems, float* amax_slots, const float* scales,
+                      int32_t pass, ecampStream_t stream);
+int ecamp_layernorm_fwd_q8(const void* x, const void* residual, void* z_out, const float* gamma, const float* beta, void* y, float* mean,
+                           float* rstd, int64_t rows, int32_t cols, float eps, float drop_p, uint64_t seed, uint64_t offset, void* q8,
+                           const float* q8_scale, float* q8_amax_slots, int32_t dtype, ecampStream_t stream);
 int ecamp_quant_fp8(const void* x, const float* amax, void* q, float* scale_out, int64_t n, int32_t dtype, ecampStream_t stream);
 int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    const float* scale_a, const float* scale_b, const float* bias, const void* residual, int64_t ldr, void* pre_out,
@@ -228,11 +244,13 @@ int64_t ecamp_prof_live_events(void);
  *   ecamp_dev_spin              `blocks` workgroups spinning for `cycles` shader clocks on `stream` (tools/hog_probe.py: a stand-in
  *                               for a communication kernel sharing the GPU with the training step)
  *   ecamp_gemm_q8_launches      GEMM calls routed to the persistent 256x256x64 kernel so far (tests assert that it really ran)
- *   ecamp_wgrad_group_launches  grouped weight-gradient launches issued so far (tests assert that the grouped path really ran) */
+ *   ecamp_wgrad_group_launches  grouped weight-gradient launches issued so far (tests assert that the grouped path really ran)
+ *   ecamp_gemm_f8_q8_launches   ecamp_gemm_fp8 calls routed to the persistent 256 x 256 x 128 e4m3 kernel so far */
 #ifdef ECAMP_DEV_ABI
 int ecamp_dev_spin(int32_t blocks, int32_t threads, int64_t cycles, ecampStream_t stream);
 int64_t ecamp_gemm_q8_launches(void);
 int64_t ecamp_wgrad_group_launches(void);
+int64_t ecamp_gemm_f8_q8_launches(void);
 #endif
 
 #ifdef __cplusplus

@@ -92,7 +92,10 @@ def test_wgrad_group_item_table_covers_every_k_tile_once(lib):
     import numpy as np
     import torch
     cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
-    for rows, shapes in ((12800, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (32768, [(768, 1536), (1536, 768), (768, 768), (2304, 768)])):
+    # (the third group: a ViT-L/448 encoder block -- 12608 rows = 197 K tiles, an odd count with a partial-free last tile; the fourth: a
+    # row count that is no multiple of 64 either)
+    for rows, shapes in ((12800, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (32768, [(768, 1536), (1536, 768), (768, 768), (2304, 768)]),
+                         (12608, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 1024)]), (1000, [(768, 3072), (3072, 768), (768, 768), (2304, 768)])):
         for reserve in (0, 32):
             assert lib.ecamp_set_option(b"p8_wgrad_reserve_cus", reserve) == 0
             n = len(shapes)
@@ -113,7 +116,8 @@ def test_wgrad_group_item_table_covers_every_k_tile_once(lib):
             off_t = 32 * P + (4 * (P + 1) + 31) // 32 * 32
             tiles = raw[off_t:off_t + 20 * T].view(np.int32).reshape(T, 5)
             assert (first == np.arange(P + 1)).all()
-            KT = rows // 64
+            KT = (rows + 63) // 64
+            assert all(int(kend) <= rows for _, _, _, _, kend, _, _, _ in items)
             cover = {}
             for prob, m0, n0, kbeg, kend, slab, flags, _ in items:
                 assert 0 <= prob < n and m0 % 256 == 0 and n0 % 256 == 0 and kbeg % 64 == 0 and kend - kbeg >= 128

@@ -834,6 +834,71 @@ def test_gemm_fp8_forward_epilogues(dev, M, N, K):
     assert e < 6e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(394, 768, 256), (1000, 520, 400), (700, 2304, 768), (513, 136, 3072)])
+def test_gemm_fp8_persistent_kernel_forced_on_ragged_shapes(dev, M, N, K):
+    """The persistent 256 x 256 x 128 e4m3 kernel (gemm_q8.h, F8: the kernel configs[4] runs at its full size) forced on small ragged
+    shapes: edge tiles in M and N, a partial last K tile (K = 400 = 3 x 128 + 16), every forward epilogue, against the f32 product of the
+    DEQUANTISED operands; a launch counter proves which kernel ran."""
+    o = ops()
+    from ecamp_amd import _lib
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    x, w, b, r = rnd(gen(M, K, seed=1), dtype), rnd(gen(N, K, seed=2, scale=K ** -0.5), dtype), gen(N, seed=3), rnd(gen(M, N, seed=4), dtype)
+    xd, wd, bd, rd = x.to(dev, dtype), w.to(dev, dtype), b.to(dev), r.to(dev, dtype)
+    w8, ws = o.quantize_fp8(wd)
+    xq, xs = o.quantize_fp8(xd)
+    ref = (xq.cpu().view(torch.float8_e4m3fn).float() * xs.item()) @ (w8.cpu().view(torch.float8_e4m3fn).float() * ws.item()).T
+    tol = TOL[dtype]
+    o.set_option("q8_mode", 2)
+    try:
+        n0 = lib.ecamp_gemm_f8_q8_launches()
+        check("fp8 q8 linear", o.linear_fwd_fp8(xd, w8, ws, bd), ref + b, tol)
+        check("fp8 q8 linear (no bias)", o.linear_fwd_fp8(xd, w8, ws, None), ref, tol)
+        check("fp8 q8 linear+residual", o.linear_fwd_fp8(xd, w8, ws, None, residual=rd), ref + r, tol)
+        y, pre = o.linear_fwd_fp8(xd, w8, ws, bd, act=1, save_pre=True)
+        check("fp8 q8 linear pre", pre, ref + b, tol)
+        check("fp8 q8 linear gelu", y, F.gelu(rnd(ref + b, dtype)), tol)
+        assert lib.ecamp_gemm_f8_q8_launches() - n0 == 4
+    finally:
+        o.set_option("q8_mode", -1)
+
+
+def test_fp8_delayed_scaling_kernels(dev):
+    """Delayed per-tensor scaling (configs[4], round 4): ecamp_quant_fp8_delayed quantises with a GIVEN scale in one pass and leaves
+    max|x| in the site's amax slots; ecamp_fp8_roll turns the slots into the next scale and clears them (a site nobody fed keeps its
+    scale); ecamp_layernorm_fwd_q8's e4m3 copy is bit-identical to quantising its bf16 output afterwards, with and without the fused
+    residual + dropout, for 768- and 512-column rows (16-B lane accesses) and a 100-column row (the 4-wide form)."""
+    o = ops()
+    x = (gen(300, 512, seed=11, scale=3.0)).to(dev, torch.bfloat16)
+    scale = torch.tensor([0.0123], device=dev)
+    slots = torch.zeros(2 * 512, device=dev)
+    q = o.quantize_fp8_site(x, scale, slots[:512], True)
+    ref = (x.float().cpu() / 0.0123).clamp(-448, 448).to(torch.float8_e4m3fn)
+    same = (q.cpu().view(torch.uint8) == ref.view(torch.uint8)).float().mean().item()
+    assert same > 0.999   # x * (1 / scale) on the device against x / scale here: a tie may round the other way by one code
+    assert slots[:512].view(16, 32)[:, 0].max().item() == x.float().abs().max().item() and slots[:512].view(16, 32)[:, 1:].abs().max().item() == 0
+    scales = torch.tensor([7.0, 9.0], device=dev)
+    o.fp8_roll(slots, scales)
+    assert abs(scales[0].item() - x.float().abs().max().item() / 448.0) < 1e-7 and scales[1].item() == 9.0 and slots.abs().max().item() == 0
+    # first use of a site = the two-pass current scaling; it seeds scale and slot 0
+    sc2, sl2 = torch.ones(1, device=dev), torch.zeros(512, device=dev)
+    q2 = o.quantize_fp8_site(x, sc2, sl2, False)
+    q3, s3 = o.quantize_fp8(x)
+    assert torch.equal(q2, q3) and sc2.item() == s3.item() and sl2[0].item() == x.float().abs().max().item()
+    for rows, cols in ((260, 768), (130, 512), (50, 100)):
+        xx = gen(rows, cols, seed=3).to(dev, torch.bfloat16)
+        rr = gen(rows, cols, seed=4).to(dev, torch.bfloat16)
+        g, b = (1.0 + 0.1 * gen(cols, seed=5)).to(dev), (0.1 * gen(cols, seed=6)).to(dev)
+        for kw in ({}, dict(residual=rr, drop_p=0.1, seed=7, offset=9)):
+            sc, sl = torch.tensor([0.011], device=dev), torch.zeros(512, device=dev)
+            y, z, mean, rstd, y8 = o.layernorm_fwd(xx, g, b, 1e-6, q8_site=(sc, sl), **kw)
+            y0 = o.layernorm_fwd(xx, g, b, 1e-6, **kw)[0]
+            assert torch.equal(y, y0)
+            sl0 = torch.zeros(512, device=dev)
+            assert torch.equal(y8, o.quantize_fp8_site(y0, sc, sl0, True))
+            assert sl.view(16, 32)[:, 0].max().item() == y0.float().abs().max().item()
+
+
 def test_gemm_rows_past_2gb_are_split(dev):
     """An output of more than 2 GB (the vocabulary projection at B = 512) runs as two row halves on the persistent kernel; the rows on
     both sides of the seam match the same rows computed as a small GEMM."""
@@ -872,6 +937,8 @@ def test_gemm_wgrad_contraction_past_2gb_is_split(dev):
 
 @pytest.mark.parametrize("rows,shapes", [(1280, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
                                          (2560, [(1000, 520), (264, 264), (520, 1000)]),
+                                         (1000, [(1000, 520), (264, 264), (520, 1000)]),      # rows: no multiple of 64 (partial last K tile)
+                                         (12608, [(3072, 1024), (1024, 1024)]),               # ViT-L/448: 197 K tiles (odd)
                                          (12800, [(2304, 768), (768, 768), (3072, 768), (768, 3072)])])
 def test_wgrad_group_matches_per_layer_weight_gradients(dev, rows, shapes):
     """ecamp_wgrad_group (the weight and bias gradients of a block's linear layers as ONE item-table launch of the Q8 kernel + one

@@ -127,7 +127,7 @@ def _bf16_golden_case(dev, name, fp8=False, loss_tol=3e-2, med_tol=1e-2, max_tol
         nm, s = digest(t.float().cpu())
         e = max(rel(nm[0], g["act/%s/nm" % k][0]), rel(s, g["act/%s/s" % k]))
         print("  bf16 act %-10s rel err %.2e" % (k, e))
-        assert e < act_tol, (k, e)
+        assert e < (act_tol[k] if isinstance(act_tol, dict) else act_tol), (k, e)
     (mim + res + mlm).backward()
     names = list(g["grad/names"])
     params = dict(model.named_parameters())
@@ -140,10 +140,12 @@ def _bf16_golden_case(dev, name, fp8=False, loss_tol=3e-2, med_tol=1e-2, max_tol
 
 def test_fp8_forward_mode_matches_reference_golden(dev):
     """BASELINE.json configs[4] against the REFERENCE (not against this repo's own bf16 path): `fp8_forward=True` (e4m3 copies of the
-    activations and weights of the ViT-block linear layers, per-tensor scales, bf16 gradients) on the golden vectors of the base
-    model: losses within 5e-2 (measured 2e-3), activation digests within 1e-1 (the encoder output after twelve e4m3 blocks: 6.6e-2 of its
-    largest sampled element), per-tensor gradient norms median 3e-2 / worst 1.5e-1."""
-    _bf16_golden_case(dev, "base_b2_s128", fp8=True, loss_tol=5e-2, med_tol=3e-2, max_tol=1.5e-1, act_tol=1e-1)
+    activations and weights of the ViT-block linear layers AND, since round 4, of the BERT / fusion dense layers; per-tensor scales,
+    bf16 gradients) on the golden vectors of the base model.  Bounds = what is measured x ~1.3: losses 1e-2 (measured 6e-4 / 2e-3 /
+    6e-4), activation digests per tensor (encoder output after twelve e4m3 blocks 6.6e-2 of its largest sampled element, decoder
+    prediction 9.6e-2, report-side output after seven e4m3 layers 1.03e-1), per-tensor gradient norms median / worst below."""
+    _bf16_golden_case(dev, "base_b2_s128", fp8=True, loss_tol=1e-2, med_tol=3e-2, max_tol=1.5e-1,
+                      act_tol={"latent": 9e-2, "pred": 1.25e-1, "pred_img": 1.1e-1, "fused": 7.5e-2, "seq_out": 1.35e-1, "logits": 1.35e-1})
 
 
 def test_engine_step_matches_reference(dev):
@@ -571,6 +573,54 @@ def test_fp8_forward_mode_tracks_bf16(dev):
     assert d0.max() < 2e-2 and d1.max() < 3e-2 and cos > 0.98
     with pytest.raises(ValueError):
         me.ecamp(compute_dtype=torch.float32, fp8_forward=True)
+
+
+def test_fp8_delayed_scaling_takes_over_after_the_calibrating_forward(dev):
+    """configs[4], delayed scaling: the FIRST forward of a model quantises every GEMM input with the two-pass current scaling (and so
+    calibrates the site); the second forward quantises in one pass with the site's stored scale -- inside the producing LayerNorm for
+    the sites a LayerNorm feeds (ViT qkv / fc1, BERT intermediate) -- and, the scale being the same number while no optimizer step
+    has rolled it, reproduces the first forward's losses (to the summation order of the loss kernels' atomics).  After an optimizer step the scales roll to the maxima the
+    producers saw; the BERT and fusion dense layers run on the e4m3 kernel too (launch counter)."""
+    from ecamp_amd import _lib, hip_ops, optim
+    from ecamp_amd.module import model_ecamp as me
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    lib = _lib.load()
+    cfg = orc.cfg_base()
+    B, S = 4, 128
+    state = recipe.recipe_state(cfg, seed=0)
+    batch = recipe.recipe_batch(cfg, B, S, seed=0)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=0)
+    model = me.ecamp(compute_dtype=torch.bfloat16, fp8_forward=True)
+    model.load_state_dict(state, strict=True)
+    model.to(dev).eval()
+    opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-4, betas=(0.9, 0.95))
+    calls = []
+    orig = hip_ops.quantize_fp8_site
+    hip_ops.quantize_fp8_site = lambda x, sc, am, cal: (calls.append(bool(cal)), orig(x, sc, am, cal))[1]
+    try:
+        out1 = [t.item() for t in model(batch, mask_ratio=0.75, noise=noise)]
+        n1 = len(calls)
+        assert n1 > 0 and not any(calls)                       # every site: first use = calibration
+        A = model.arena
+        assert len(A.f8_cal) == n1
+        # 16 ViT blocks x 4 + 6 BERT layers x 4 + fusion layer 7 dense layers
+        assert n1 == 16 * 4 + 6 * 4 + 7, n1
+        del calls[:]
+        out2 = [t.item() for t in model(batch, mask_ratio=0.75, noise=noise)]
+        assert all(calls) and len(calls) == n1 - (16 * 2 + 6 + 1)   # the LayerNorm-fed sites no longer need a pass of their own
+        # (equal up to the summation order of the loss kernels' atomics, as for any two forwards of this model)
+        assert all(abs(a - b) <= 2e-6 * abs(a) for a, b in zip(out1, out2)), (out1, out2)
+        scale_before = A.f8_scale.clone()
+        loss = model(batch, mask_ratio=0.75, noise=noise)
+        (loss[0] + loss[1] + loss[2]).backward()
+        opt.step(); opt.zero_grad()
+        out3 = [t.item() for t in model(batch, mask_ratio=0.75, noise=noise)]   # first use after the step: the roll
+        changed = (A.f8_scale != scale_before).sum().item()
+        assert changed >= n1 - 2, changed                      # (a site whose maximum did not move keeps its bits)
+        assert all(abs(a - b) < 2e-2 * abs(a) for a, b in zip(out1, out3))
+    finally:
+        hip_ops.quantize_fp8_site = orig
 
 
 def test_grouped_and_per_layer_weight_gradients_agree_at_model_level_bf16(dev):
