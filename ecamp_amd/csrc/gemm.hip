@@ -579,7 +579,10 @@ static long g_f8_q8_launches = 0;
 extern "C" int64_t ecamp_gemm_f8_q8_launches(void) { return g_f8_q8_launches; }
 extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                               int64_t ldc, const float* scale_a, const float* scale_b, const float* bias, const void* residual,
-                              int64_t ldr, void* pre_out, int64_t ldp, int act, hipStream_t stream) {
+                              int64_t ldr, void* pre_out, int64_t ldp, int act, void* q8_out, const float* q8_scale, float* q8_amax_slots,
+                              hipStream_t stream) {
+    ECAMP_CHECK_ARG(!q8_out || (q8_scale && q8_amax_slots && act == 1 && pre_out && !residual && ldc == N),
+                    "ecamp_gemm_fp8: the e4m3 copy of the output needs its scale and amax slots, the GELU epilogue and a dense C");
     ECAMP_CHECK_ARG(A8 && B8 && C && scale_a && scale_b, "ecamp_gemm_fp8: null operand");
     ECAMP_CHECK_ARG(M > 0 && N > 0 && K > 0, "ecamp_gemm_fp8: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
     ECAMP_CHECK_ARG(K % 16 == 0 && lda % 16 == 0 && ldb % 16 == 0 && N % 4 == 0, "ecamp_gemm_fp8: K, lda, ldb must be multiples of 16 and N of 4");
@@ -590,6 +593,7 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.pre_out = pre_out; g.ldp = ldp; g.gmul = nullptr; g.ldg = 0;
     g.alpha = 1.0f; g.alpha_dev = nullptr; g.alpha_dev2 = nullptr; g.alpha_out = 1.0f; g.alpha_dev_out = nullptr;
+    g.q8_out = nullptr; g.q8_scale = nullptr; g.q8_amax = nullptr;
     g.rowsum = nullptr;
     g.act = act; g.out_f32 = 0; g.accumulate = 0;
     g.k_per_split = (int)K;
@@ -615,6 +619,7 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
             const f8_fn fn = epi == 0 ? (f8_fn)gemm_f8_q8_kernel<0> : epi == 1 ? (f8_fn)gemm_f8_q8_kernel<1> : (f8_fn)gemm_f8_q8_kernel<2>;
             g.nbm = ceil_div(M, 256); g.nbn = ceil_div(N, 256); g.nsplit = 1; g.wide = 1;
             g.alpha_dev = scale_a; g.alpha_dev2 = scale_b;
+            g.q8_out = q8_out; g.q8_scale = q8_scale; g.q8_amax = q8_amax_slots;
             const size_t shm = 10 * Q8_HALF;
             static bool attr[3] = {false, false, false};
             if (!attr[epi]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr[epi] = true; }
@@ -628,6 +633,12 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
     }
     hipLaunchKernelGGL(gemm_fp8_kernel, dim3(g.nbm * g.nbn), dim3(256), 0, stream, g, scale_a, scale_b);
     if (prof) ecamp_prof_end(stream);
+    if (q8_out) {   // the 128^2 kernel has no third output: one pass over C afterwards gives the same bytes
+        const long n4 = M * N / 4;
+        int nb = (int)((n4 + 255) / 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(quant_fp8_delayed_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)C, q8_scale, (unsigned int*)q8_out, q8_amax_slots, n4);
+    }
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
@@ -843,6 +854,7 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     g.alpha = alpha;
     g.alpha_dev = alpha_dev;
     g.alpha_dev2 = nullptr;
+    g.q8_out = nullptr; g.q8_scale = nullptr; g.q8_amax = nullptr;
     g.alpha_out = alpha;
     g.alpha_dev_out = alpha_dev;
     g.rowsum = rowsum;

@@ -27,6 +27,9 @@ struct GemmArgs {
     const float* alpha_dev_out;
     const float* alpha_dev; // optional device scalar multiplied into alpha (upstream loss gradient; avoids a host sync)
     const float* alpha_dev2; // e4m3 form: the second operand's per-tensor scale (the first is alpha_dev)
+    void* q8_out;            // e4m3 form, GELU epilogue: a third output, the e4m3 copy of C [M, ldc bytes per row] for the NEXT GEMM ...
+    const float* q8_scale;   // ... quantised with that GEMM's input scale (delayed scaling) ...
+    float* q8_amax;          // ... and max|C| of this launch into its 16 amax slots
     int dbg;                // development switches of the P8 kernel (ECAMP_P8_DBG); 0 in production
     int wide;               // every [M, ld] epilogue operand is 16-B aligned at 8-column granularity (P8's 16-B epilogue)
     int nsplit;             // P8: number of split-K slices (the persistent kernel walks tiles x slices itself)

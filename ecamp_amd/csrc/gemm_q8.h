@@ -477,6 +477,8 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         (EPI == 4 && g.partial) ? (void*)g.partial : g.C, 0,
         (int)(unsigned)(((EPI == 4 && g.partial) ? (long)g.nsplit * g.M : (long)g.M) * ldo * esz), 0x00020000);
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? g.pre_out : g.C, 0, (int)(unsigned)((long)g.M * g.ldp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((F8 && EPI == 1 && g.q8_out) ? g.q8_out : g.C, 0, (int)(unsigned)((long)g.M * g.ldc), 0x00020000);
+    float q8_max = 0.f;   // e4m3 form, GELU epilogue: this wave's running max|C| (one atomic per wave at the end of the kernel)
     const unsigned lane_o = (unsigned)((l31 * ldo + 8 * lh) * esz);          // lane part of an output offset
     const unsigned lane_p = (unsigned)((l31 * g.ldp + 8 * lh) * 2);
     const unsigned lane_g = (unsigned)((l31 * g.ldg + 8 * lh) * 2);
@@ -557,6 +559,13 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                 if (EPI == 3) ug[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldg + col) * 2) + lane_g;
                 if (EPI == 2 || EPI == 3) ur[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldr + col) * 2) + lane_r;
             }
+        // e4m3 form with the GELU epilogue: the e4m3 copy of the output for the next GEMM (8 bytes per lane and group)
+        float q8_inv = 0.f;
+        if (F8 && EPI == 1 && g.q8_out) {
+            float qs = *(cfloat4*)g.q8_scale;
+            asm volatile("" : "+s"(qs));
+            q8_inv = 1.0f / fmaxf(qs, 1e-30f);
+        }
         // all loads of the quadrant ahead of its first store
         q8_u32x4 qg[2][2], qr[2][2], qo[2][2][2];
 #pragma unroll
@@ -585,6 +594,21 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                     __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rP, up[tm][gq], 0, ST_AUX);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16_t>(rnd<bf16_t>(v[r]));
+                    if (F8 && g.q8_out) {
+                        float u[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float yr = rnd<bf16_t>(v[r]);   // what the bf16 output holds: fused == quantising C afterwards, bit for bit
+                            q8_max = fmaxf(q8_max, fabsf(yr));
+                            u[r] = fminf(fmaxf(yr * q8_inv, -448.f), 448.f);
+                        }
+                        int w0 = 0, w1 = 0;
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(u[0], u[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(u[2], u[3], w0, true);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(u[4], u[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(u[6], u[7], w1, true);
+                        typedef unsigned int q8_u32x2_ __attribute__((ext_vector_type(2)));
+                        // (same element offsets as C, one byte per element instead of two)
+                        __builtin_amdgcn_raw_buffer_store_b64((q8_u32x2_){(unsigned)w0, (unsigned)w1}, rQ, uo[tm][gq] == 0x80000000u ? 0x80000000u : (uo[tm][gq] >> 1), 0, 0);
+                    }
                 }
                 if (EPI == 3) {
 #pragma unroll
@@ -871,6 +895,11 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     if (wr == 0) __builtin_amdgcn_s_barrier();   // wave row 0's share of the row lag
     if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); }
     if (ROWSUM) { if (rsp_on) rowsum_flush(); }
+    if (F8 && EPI == 1 && g.q8_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q8_max = fmaxf(q8_max, __shfl_xor(q8_max, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(g.q8_amax + ((blockIdx.x + wave) & 15) * 32), __float_as_uint(q8_max));
+    }
 #undef Q8_STORE_Q
 #undef Q8_SB
 #undef Q8_READ_GROUP

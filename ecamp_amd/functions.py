@@ -93,12 +93,13 @@ def _f8_site(m, x, weights):
     return (sc, am) if cal else None
 
 
-def _dense(m, x, weights, bias, shape=None, x8=None, **kw):
+def _dense(m, x, weights, bias, shape=None, x8=None, next_w=None, **kw):
     """Forward of a dense layer y = act(x W^T + b) (+ residual).  `weights`: one parameter or a list of arena-adjacent ones run as a
     single [N, K] = `shape` GEMM (BERT's fused query/key/value).  bf16 GEMM, or -- model.fp8_forward, BASELINE configs[4]: the ViT
     qkv / proj / fc1 / fc2 layers and the BERT / fusion dense layers -- the e4m3 GEMM on per-tensor-scaled copies: the weight's is
     re-quantised once per optimizer step (ParamArena.w8), the activation's comes from its producer (`x8`: a LayerNorm that quantised
-    its own output) or from ONE pass over x with the site's delayed scale.  The backward is the bf16 one either way."""
+    its own output, a GELU epilogue that did the same: `next_w` asks this layer for it) or from ONE pass over x with the site's
+    delayed scale.  The backward is the bf16 one either way."""
     A = m.arena
     plist = list(weights) if isinstance(weights, (list, tuple)) else [weights]
     if m.fp8_forward and x.dtype == torch.bfloat16:
@@ -107,14 +108,20 @@ def _dense(m, x, weights, bias, shape=None, x8=None, **kw):
             x8 = ops.quantize_fp8_site(x, sc, am, cal)
             A.f8_cal.add(i)
         w8, ws = A.w8(plist, shape)
+        if next_w is not None:   # GELU layer whose output feeds the dense layer of `next_w`: -> (y, pre, y8 or None)
+            _, nsc, nam, ncal = A.f8_site(next_w)
+            if ncal:
+                return ops.gemm_fp8(x8, sc, w8, ws, bias, q8_site=(nsc, nam), **kw)
+            return ops.gemm_fp8(x8, sc, w8, ws, bias, **kw) + (None,)
         return ops.gemm_fp8(x8, sc, w8, ws, bias, **kw)
     w = A.fused_w(plist, shape) if len(plist) > 1 else A.w(plist[0])
-    return ops.linear_fwd(x, w, bias, **kw)
+    r = ops.linear_fwd(x, w, bias, **kw)
+    return r + (None,) if next_w is not None else r
 
 
-def _vit_linear(m, x, lin, x8=None, **kw):
+def _vit_linear(m, x, lin, x8=None, next_w=None, **kw):
     """Forward of a timm Attention.qkv / proj or Mlp.fc1 / fc2 layer (see _dense)."""
-    return _dense(m, x, lin.weight, lin.bias.data, x8=x8, **kw)
+    return _dense(m, x, lin.weight, lin.bias.data, x8=x8, next_w=next_w, **kw)
 
 
 def _ln_q8(m, x, ln, weights, eps=None, **kw):
@@ -174,8 +181,8 @@ class VitBlockFn(torch.autograd.Function):
         a = a.view(B * T, D)
         x1 = _vit_linear(m, a, blk.attn.proj, residual=x)
         h2, _, mean2, rstd2, h28 = _ln_q8(m, x1, blk.norm2, blk.mlp.fc1.weight)
-        u, pre = _vit_linear(m, h2, blk.mlp.fc1, x8=h28, act=1, save_pre=True)
-        x2 = _vit_linear(m, u, blk.mlp.fc2, residual=x1)
+        u, pre, u8 = _vit_linear(m, h2, blk.mlp.fc1, x8=h28, next_w=blk.mlp.fc2.weight, act=1, save_pre=True)
+        x2 = _vit_linear(m, u, blk.mlp.fc2, x8=u8, residual=x1)
         ctx.s = (x, mean1, rstd1, h, qkv, a, lse, x1, mean2, rstd2, h2, pre, u)
         ctx.cfg = (blk, m, B, T, heads)
         return x2
@@ -485,8 +492,8 @@ def _self_attn_bwd(m, rec, dout, B, S, key_mask, pa, ph):
 def _ffn_fwd(m, inter, out, x, ph, tape, x8=None):
     """BertIntermediate + BertOutput: LN(dropout(W2 gelu(W1 x)) + x)."""
     A = m.arena
-    u, pre = _dense(m, x, inter.dense.weight, inter.dense.bias.data, x8=x8, act=1, save_pre=True)
-    y = _dense(m, u, out.dense.weight, out.dense.bias.data)
+    u, pre, u8 = _dense(m, x, inter.dense.weight, inter.dense.bias.data, x8=x8, next_w=out.dense.weight, act=1, save_pre=True)
+    y = _dense(m, u, out.dense.weight, out.dense.bias.data, x8=u8)
     s, o = m.next_rng()
     ln = out.LayerNorm
     r, z, mean, rstd = ops.layernorm_fwd(y, ln.weight.data, ln.bias.data, ln.eps, residual=x, drop_p=ph, seed=s, offset=o)

@@ -97,15 +97,20 @@ def quantize_fp8_site(x, scale, amax_slots, calibrated):
     return q
 
 
-def gemm_fp8(x8, x_scale, w8, w_scale, bias=None, act=0, residual=None, save_pre=False):
-    """y (bf16) = act(dequant(x8) @ dequant(w8).T + bias) (+ residual) on the e4m3 GEMM (ecamp_gemm_fp8): x8 [M,K], w8 [N,K] uint8."""
+def gemm_fp8(x8, x_scale, w8, w_scale, bias=None, act=0, residual=None, save_pre=False, q8_site=None):
+    """y (bf16) = act(dequant(x8) @ dequant(w8).T + bias) (+ residual) on the e4m3 GEMM (ecamp_gemm_fp8): x8 [M,K], w8 [N,K] uint8.
+    q8_site = (scale, amax slots) of the NEXT dense layer (GELU epilogue only): a third result, the e4m3 copy of y made in the epilogue."""
     M, K = x8.shape
     N = w8.shape[0]
     assert w8.shape[1] == K and w8.dtype == torch.uint8 and x8.dtype == torch.uint8 and x8.is_contiguous() and w8.is_contiguous()
     y = torch.empty((M, N), device=x8.device, dtype=torch.bfloat16)
     pre = torch.empty((M, N), device=x8.device, dtype=torch.bfloat16) if save_pre else None
+    y8 = torch.empty((M, N), device=x8.device, dtype=torch.uint8) if q8_site is not None else None
     call("ecamp_gemm_fp8", ptr(x8), ptr(w8), ptr(y), M, N, K, K, K, N, ptr(x_scale), ptr(w_scale), ptr(bias), ptr(residual),
-         residual.stride(0) if residual is not None else 0, ptr(pre), N, int(act), stream())
+         residual.stride(0) if residual is not None else 0, ptr(pre), N, int(act), ptr(y8), ptr(q8_site[0] if q8_site else None),
+         ptr(q8_site[1] if q8_site else None), stream())
+    if q8_site is not None:
+        return y, pre, y8
     return (y, pre) if save_pre else y
 
 
@@ -119,7 +124,7 @@ def linear_fwd_fp8(x, w8, w_scale, bias=None, act=0, residual=None, save_pre=Fal
     y = torch.empty((M, N), device=x.device, dtype=torch.bfloat16)
     pre = torch.empty((M, N), device=x.device, dtype=torch.bfloat16) if save_pre else None
     call("ecamp_gemm_fp8", ptr(x8), ptr(w8), ptr(y), M, N, K, K, K, N, ptr(xs), ptr(w_scale), ptr(bias), ptr(residual),
-         residual.stride(0) if residual is not None else 0, ptr(pre), N, int(act), stream())
+         residual.stride(0) if residual is not None else 0, ptr(pre), N, int(act), ptr(None), ptr(None), ptr(None), stream())
     return (y, pre) if save_pre else y
 
 

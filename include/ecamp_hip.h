@@ -111,7 +111,10 @@ int ecamp_layernorm_fwd_q8(const void* x, const void* residual, void* z_out, con
 int ecamp_quant_fp8(const void* x, const float* amax, void* q, float* scale_out, int64_t n, int32_t dtype, ecampStream_t stream);
 int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    const float* scale_a, const float* scale_b, const float* bias, const void* residual, int64_t ldr, void* pre_out,
-                   int64_t ldp, int act, ecampStream_t stream);
+                   int64_t ldp, int act, void* q8_out, const float* q8_scale, float* q8_amax_slots, ecampStream_t stream);
+/* q8_out (nullable; needs act = 1, pre_out, no residual, ldc = N): also leave the e4m3 copy of C for the NEXT dense layer (timm Mlp.fc2 /
+ * BertOutput.dense behind the GELU), quantised with that layer's input scale q8_scale[0], and max|C| in its amax slots -- the fp8
+ * forward's quantisation folded into the epilogue that produces the activation (ecamp_quant_fp8_delayed's conventions). */
 
 /* ---- LayerNorm (nn.LayerNorm eps 1e-6: model_ecamp.py:69,84,235,256 + timm Block norms; HF LN eps 1e-12:
  * BertSelfOutput/BertOutput/BertEmbeddings/transform).  y = LN(z), z = dropout(x) + residual (both optional). */

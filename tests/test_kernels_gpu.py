@@ -828,6 +828,10 @@ def test_gemm_fp8_forward_epilogues(dev, M, N, K):
     y, pre = o.linear_fwd_fp8(xd, w8, ws, bd, act=1, save_pre=True)
     check("fp8 linear pre", pre, ref + b, tol)
     check("fp8 linear gelu", y, F.gelu(rnd(ref + b, dtype)), tol)
+    # (the 128^2 kernel has no third output: ecamp_gemm_fp8 quantises C in a pass of its own -- same bytes as the persistent kernel's epilogue)
+    sc, sl, sl0 = torch.tensor([0.02], device=dev), torch.zeros(512, device=dev), torch.zeros(512, device=dev)
+    y2, pre2, y8 = o.gemm_fp8(xq, xs, w8, ws, bd, act=1, save_pre=True, q8_site=(sc, sl))
+    assert torch.equal(y2, y) and torch.equal(y8, o.quantize_fp8_site(y, sc, sl0, True)) and sl.max().item() == y.float().abs().max().item()
     exact = x @ w.T + b
     e = ((o.linear_fwd_fp8(xd, w8, ws, bd).float().cpu() - exact).norm() / exact.norm()).item()
     print("  fp8 vs unquantised product: relative Frobenius error %.3e" % e)
@@ -859,6 +863,13 @@ def test_gemm_fp8_persistent_kernel_forced_on_ragged_shapes(dev, M, N, K):
         check("fp8 q8 linear pre", pre, ref + b, tol)
         check("fp8 q8 linear gelu", y, F.gelu(rnd(ref + b, dtype)), tol)
         assert lib.ecamp_gemm_f8_q8_launches() - n0 == 4
+        # the GELU epilogue's third output: the e4m3 copy of y for the next dense layer, quantised in the epilogue with that layer's scale
+        sc, sl, sl0 = torch.tensor([0.02], device=dev), torch.zeros(512, device=dev), torch.zeros(512, device=dev)
+        y2, pre2, y8 = o.gemm_fp8(xq, xs, w8, ws, bd, act=1, save_pre=True, q8_site=(sc, sl))
+        assert torch.equal(y2, y) and torch.equal(pre2, pre)
+        assert torch.equal(y8, o.quantize_fp8_site(y, sc, sl0, True))
+        assert sl.view(16, 32)[:, 0].max().item() == y.float().abs().max().item()
+        assert lib.ecamp_gemm_f8_q8_launches() - n0 == 5
     finally:
         o.set_option("q8_mode", -1)
 

@@ -20,6 +20,6 @@ for name, M, N, K in SHAPES:
     w8, ws = o.quantize_fp8(w); x8, xs = o.quantize_fp8(x); y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     fl = 2.0 * M * N * K
     t0 = timeit(lambda: o.linear_fwd(x, w, b))
-    t1 = timeit(lambda: o.call("ecamp_gemm_fp8", o.ptr(x8), o.ptr(w8), o.ptr(y), M, N, K, K, K, N, o.ptr(xs), o.ptr(ws), o.ptr(b), o.ptr(None), 0, o.ptr(None), N, 0, o.stream()))
+    t1 = timeit(lambda: o.call("ecamp_gemm_fp8", o.ptr(x8), o.ptr(w8), o.ptr(y), M, N, K, K, K, N, o.ptr(xs), o.ptr(ws), o.ptr(b), o.ptr(None), 0, o.ptr(None), N, 0, o.ptr(None), o.ptr(None), o.ptr(None), o.stream()))
     t2 = timeit(lambda: o.linear_fwd_fp8(x, w8, ws, b))
     print("%-10s %7d %5d %5d | %5.0f TF %4.0fus %5.0f TF %4.0fus %5.0f TF %4.0fus" % (name, M, N, K, fl / t0 / 1e9, t0 * 1e3, fl / t1 / 1e9, t1 * 1e3, fl / t2 / 1e9, t2 * 1e3))
