@@ -32,7 +32,7 @@ def main():
     if rank == 0:
         model.load_state_dict(state)   # rank 1 keeps its random init: the wrapper's broadcast must overwrite it
     model.to(dev).eval()               # dropout off (its streams differ per rank); gradients still flow
-    net = DistributedDataParallel(model)
+    net = DistributedDataParallel(model, grad_dtype=torch.bfloat16 if os.environ.get("ECAMP_DDP_GRAD_DTYPE") == "bf16" else None)
     opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-3, betas=(0.9, 0.95))
     scaler = NativeScalerWithGradNormCount()
     per = B // world

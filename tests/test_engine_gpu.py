@@ -225,15 +225,16 @@ def test_lazy_zero_grad_matches_memset_and_flushes_unwritten_weights(dev):
                 assert (g - b[k]).abs().max().item() <= 5e-3 * b[k].abs().max().item() + 1e-9, k
 
 
-@pytest.mark.parametrize("accum,branches", [(1, 0), (2, 0), (1, 1)])
-def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum, branches):
+@pytest.mark.parametrize("accum,branches,gdt", [(1, 0, "f32"), (2, 0, "f32"), (1, 1, "f32"), (1, 0, "bf16")])
+def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum, branches, gdt):
     """SURVEY.md section 4, "distributed without a cluster" (main_pretrain.py:247-250): two data-parallel ranks of B=4 (accum 1) or
     2 x B=2 with no_sync on the first micro-step (accum 2) must leave, after the bucketed all-reduce, the SAME gradient arena and
     the same parameters after one AdamW step as ONE process on the concatenated B=8 batch.  Both ranks share cuda:0 (this pool
     has one GPU per box), so the process group is gloo on device tensors; rank 1 starts from a different initialisation, which the
     wrapper's parameter broadcast must overwrite.  fp32 parity mode, tiny config, recipe inputs.  branches=1: the ranks run with
     ECAMP_OVERLAP_BRANCHES=1 (image decoder and report side on two streams, forward and backward): a bucket reported from a
-    branch-stream node must still wait for the main stream's share of its gradients."""
+    branch-stream node must still wait for the main stream's share of its gradients.  gdt = "bf16": the optional bf16
+    gradient exchange (round 4: half the bytes on the links) -- the arena then agrees to bf16 rounding (contract 1e-2, measured ~3e-3)."""
     import socket
     import subprocess
     import sys
@@ -268,7 +269,7 @@ def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum, branches):
     sock.close()
     out = os.path.join(tmp_path, "ddp_rank0.pt")
     worker = os.path.join(root, "tests", "_ddp_worker.py")
-    env = dict(os.environ, ECAMP_OVERLAP_BRANCHES=str(branches))
+    env = dict(os.environ, ECAMP_OVERLAP_BRANCHES=str(branches), ECAMP_DDP_GRAD_DTYPE=gdt)
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(accum), out], cwd=root, env=env) for r in range(2)]
     rcs = [p.wait(timeout=600) for p in procs]
     assert rcs == [0, 0], rcs
@@ -277,6 +278,10 @@ def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum, branches):
     ep = float((got["flat_p"] - ref_p).abs().max() / ref_p.abs().max())
     print("  DDP 2 ranks (accum %d) vs single process: grad arena rel %.2e, params after AdamW rel %.2e, norm %.6f vs %.6f"
           % (accum, eg, ep, got["norm"], ref_norm))
+    if gdt == "bf16":
+        assert 1e-6 < eg <= 1e-2, eg      # really went through bf16, and no further than its rounding
+        assert abs(got["norm"] - ref_norm) <= 5e-3 * ref_norm
+        return
     assert eg <= 1e-5, eg
     # the first AdamW step is lr * g / (|g| + eps): where a gradient element is ~0 a 1e-7 difference moves the update by O(lr), so the
     # parameters are compared at lr-scale resolution (lr = 1e-3, |p|max ~ 1); the gradient arena above is the contract
