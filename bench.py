@@ -401,13 +401,13 @@ def main():
             ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
             # HBM-side traffic per GEMM launch: not measurable from inside this process -- taken from the committed PMC passes of this
-            # very command (profiles/r03_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); null if absent
+            # very command (profiles/r04_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); null if absent
             traffic, traffic_src = None, None
-            tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+            tj = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
             if args.dtype == "bf16" and args.batch == 256 and args.seq == 128 and os.path.exists(tj):
                 try:
                     traffic = round(json.load(open(tj))["gemm_traffic_bytes_per_launch"])
-                    traffic_src = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per GEMM launch)"
+                    traffic_src = "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per GEMM launch)"
                 except Exception:
                     traffic = None
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
