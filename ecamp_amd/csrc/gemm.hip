@@ -1119,7 +1119,7 @@ extern "C" int64_t ecamp_wgrad_group_table(int32_t n, const int64_t* n_out, cons
 // dy[p] [rows, n_out[p]], x[p] [rows, k_in[p]] bf16, row-contiguous.  accumulate[p] = 0 overwrites gw[p].
 extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* const* x, float* const* gw, float* const* gb, const int64_t* n_out,
                                  const int64_t* k_in, int64_t rows, float alpha, const float* alpha_dev, const int32_t* accumulate, float* ws,
-                                 const void* table, int32_t workgroups, hipStream_t stream) {
+                                 const void* table, int64_t table_bytes, int32_t workgroups, hipStream_t stream) {
     ECAMP_CHECK_ARG(dy && x && gw && gb && n_out && k_in && accumulate && ws && table, "wgrad_group: null pointer");
     ECAMP_CHECK_ARG(((uintptr_t)table & 31) == 0, "wgrad_group: the item table must be 32-byte aligned");
     ECAMP_CHECK_ARG(ecamp_wgrad_group_supported(n, n_out, k_in, rows), "wgrad_group: unsupported group (1-4 layers, rows >= 256, dims %% 8 == 0, < 2 GB operands)");
@@ -1133,6 +1133,10 @@ extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* c
     }
     const int nwg = ecamp_wgrad_group_workgroups(workgroups);   // caller's choice (how much of the chip to leave to what runs beside it) or the default
     const WgPlan* pl = wg_plan(n, n_out, k_in, hb, rows, nwg);   // host arithmetic (cached): counts and offsets of the caller's device image
+    // the device image must be the one ecamp_wgrad_group_table wrote for THIS plan: a process-wide switch flipped through the raw C
+    // ecamp_set_option between building the table and this call changes the piece count, and with it every offset below
+    ECAMP_CHECK_ARG(table_bytes == (int64_t)pl->bytes, "wgrad_group: the item table (%ld bytes) was not built for the current plan (%ld bytes: CU reserve "
+                    "or workgroup count changed since ecamp_wgrad_group_table) -- rebuild it", (long)table_bytes, (long)pl->bytes);
     const char* tb = (const char*)table;
     Q8Group G;
     memset(&G, 0, sizeof(G));

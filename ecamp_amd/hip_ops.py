@@ -219,7 +219,7 @@ def wgrad_group(items, alpha=1.0, alpha_dev=None, workgroups=0):
     nws = int(_lib.load().ecamp_wgrad_group_workspace_bytes(n, cv(no), cv(ki), rows)) // 4
     ws = torch.empty((nws,), device=dev, dtype=torch.float32)
     call("ecamp_wgrad_group", n, cv(dyp), cv(xp), cv(gwp), cv(gbp), cv(no), cv(ki), rows, float(alpha), ptr(alpha_dev), cv(acc), ptr(ws), ptr(table),
-         int(workgroups), stream())
+         table.numel(), int(workgroups), stream())
 
 
 def colsum(x, out, alpha=1.0, period=0, lo=0, hi=0, alpha_dev=None):

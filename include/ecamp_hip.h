@@ -53,7 +53,9 @@ int ecamp_gemm_suggest_split(int64_t M, int64_t N, int64_t K, int a_kc, int b_kc
  * table: DEVICE copy (32-byte aligned) of the group's item table -- pure host arithmetic on (shapes, has_bias, rows, workgroup count)
  * that ecamp_wgrad_group_table writes into HOST memory of ecamp_wgrad_group_table_bytes(...) bytes; the caller uploads it once per
  * shape set and keeps it (the library never allocates and never synchronises: the call is two kernel launches, capturable into a
- * HIP graph).  ecamp_wgrad_group_workgroups(w) = the workgroup count the launch uses for argument w (part of the table's identity). */
+ * HIP graph).  ecamp_wgrad_group_workgroups(w) = the workgroup count the launch uses for argument w (part of the table's identity).
+ * table_bytes = what ecamp_wgrad_group_table returned for that image: a table built for another plan (the CU reserve or the workgroup
+ * count changed in between) is refused instead of read at the wrong offsets. */
 int ecamp_wgrad_group_supported(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows);
 int64_t ecamp_wgrad_group_workspace_bytes(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows);
 int64_t ecamp_wgrad_group_table_bytes(int32_t n, const int64_t* n_out, const int64_t* k_in, int64_t rows);
@@ -62,7 +64,7 @@ int64_t ecamp_wgrad_group_table(int32_t n, const int64_t* n_out, const int64_t* 
 int ecamp_wgrad_group_workgroups(int32_t workgroups);
 int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* const* x, float* const* gw, float* const* gb, const int64_t* n_out,
                       const int64_t* k_in, int64_t rows, float alpha, const float* alpha_dev, const int32_t* accumulate, float* ws,
-                      const void* table, int32_t workgroups, ecampStream_t stream);
+                      const void* table, int64_t table_bytes, int32_t workgroups, ecampStream_t stream);
 /* Workspace sizes (bytes) the caller allocates and passes in -- the library never allocates:
  *   ecamp_gemm_workspace_bytes      `splitk_ws` of ecamp_gemm for this split count (0 when split_k <= 1)
  *   ecamp_attn_bwd_workspace_bytes  `delta_ws` of ecamp_attn_bwd (one f32 per query row)

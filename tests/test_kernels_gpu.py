@@ -984,6 +984,27 @@ def test_wgrad_group_matches_per_layer_weight_gradients(dev, rows, shapes):
         assert (gw - gw_ref).abs().max() < 1e-4 * gw_ref.abs().max() + 1e-3
 
 
+def test_wgrad_group_refuses_a_table_built_for_another_plan(dev):
+    """the grouped launch reads counts and offsets from the host-side plan and the items from the caller's device table; a
+    process-wide switch flipped through the RAW C ecamp_set_option (which does not clear the Python table cache) changes the plan.
+    The call must fail loudly instead of reading the old image at the new offsets."""
+    from ecamp_amd import _lib
+    o = ops()
+    lib = _lib.load()
+    rows, shapes = 12800, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+    items = [((torch.randn(rows, a) * 0.5).to(dev, torch.bfloat16), torch.randn(rows, b).to(dev, torch.bfloat16), torch.zeros(a, b, device=dev),
+              torch.zeros(a, device=dev), False) for a, b in shapes]
+    o.wgrad_group(items)
+    try:
+        assert lib.ecamp_set_option(b"p8_wgrad_reserve_cus", 48) == 0     # raw C: same workgroup count (192), fewer pieces allowed (208 < 216): hip_ops._WG_TABLES still holds the old plan's image
+        with pytest.raises(_lib.EcampHipError, match="not built for the current plan"):
+            o.wgrad_group(items)
+    finally:
+        o.set_option("p8_wgrad_reserve_cus", 0)                            # (the wrapper clears the cache)
+    o.wgrad_group(items)
+    torch.cuda.synchronize()
+
+
 def test_profiling_events_are_bounded(dev):
     """csrc/profile.hip: `main_pretrain.py --profile` brackets every GEMM / attention launch of a whole epoch with HIP events; the pool
     holds at most 4096 pairs however many launches are recorded (finished records are folded into running totals), and the totals
