@@ -5,7 +5,8 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libecamp_hip.so")
+# ECAMP_LIB (development A/B of two builds on one box, tools/ab_lib.sh): another build of the SAME library; the default is the in-tree one
+LIB_PATH = os.environ.get("ECAMP_LIB") or os.path.join(HERE, "libecamp_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "ecamp_hip.h")
 
 F32, BF16 = 0, 1

@@ -1,9 +1,7 @@
 #!/bin/bash
-# A/B of two builds of the library on the same box: tools/ab_lib.sh <old.so> <python script> [args]   (the in-tree build is "new")
-R=${GRAFT_REPO_ROOT:-/root/repo}
-OLD=$1; shift
+# A/B of two builds of the library on the same box: tools/ab_lib.sh <old.so> <python script> [args]   (the in-tree build is "new").
+# The old build is selected through ECAMP_LIB; the product file is never touched.
+OLD=$(readlink -f $1); shift
 echo "== new"; python3 "$@"
-cp $R/ecamp_amd/libecamp_hip.so /tmp/lib_new_keep.so; cp $OLD $R/ecamp_amd/libecamp_hip.so
-echo "== old"; python3 "$@"
-cp /tmp/lib_new_keep.so $R/ecamp_amd/libecamp_hip.so
+echo "== old"; ECAMP_LIB=$OLD python3 "$@"
 echo "== new again"; python3 "$@"
