@@ -701,9 +701,7 @@ static q8_fn q8_pick(int a_kc, int b_kc, int epi, bool rowsum) {
     const int sch = q8_sch();
 #define Q8S(A, B, E, R) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, R, 1>)
     if (a_kc && b_kc && (sch & 1)) return epi == 0 ? Q8S(true, true, 0, false) : epi == 1 ? Q8S(true, true, 1, false) : epi == 2 ? Q8S(true, true, 2, false) : (q8_fn) nullptr;
-#define Q8D(E) ((q8_fn)gemm_bf16_q8_kernel<true, false, E, 0, false, 2>)
-    if (a_kc && !b_kc && (sch & 2)) return epi == 0 ? Q8D(0) : epi == 2 ? Q8D(2) : epi == 3 ? Q8D(3) : (q8_fn) nullptr;
-#undef Q8D
+    if (a_kc && !b_kc && (sch & 2)) return epi == 0 ? Q8S(true, false, 0, false) : epi == 2 ? Q8S(true, false, 2, false) : epi == 3 ? Q8S(true, false, 3, false) : (q8_fn) nullptr;
     if (!a_kc && !b_kc && epi == 4 && (sch & 4)) return rowsum ? Q8S(false, false, 4, true) : Q8S(false, false, 4, false);
 #undef Q8S
     if (a_kc && b_kc) return epi == 0 ? gemm_bf16_q8_kernel<true, true, 0> : epi == 1 ? gemm_bf16_q8_kernel<true, true, 1> : epi == 2 ? gemm_bf16_q8_kernel<true, true, 2> : (q8_fn) nullptr;
@@ -1157,8 +1155,8 @@ extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* c
     const size_t shm = 10 * Q8_HALF;
     typedef void (*q8i_fn)(GemmArgs, Q8Group);
     const bool lean = (q8_sch() & 8) != 0;
-    const q8i_fn fn = any_bias ? (lean ? (q8i_fn)gemm_bf16_q8_items_kernel<true, 2> : (q8i_fn)gemm_bf16_q8_items_kernel<true, 0>)
-                               : (lean ? (q8i_fn)gemm_bf16_q8_items_kernel<false, 2> : (q8i_fn)gemm_bf16_q8_items_kernel<false, 0>);
+    const q8i_fn fn = any_bias ? (lean ? (q8i_fn)gemm_bf16_q8_items_kernel<true, 1> : (q8i_fn)gemm_bf16_q8_items_kernel<true, 0>)
+                               : (lean ? (q8i_fn)gemm_bf16_q8_items_kernel<false, 1> : (q8i_fn)gemm_bf16_q8_items_kernel<false, 0>);
     static bool attr[4] = {false, false, false, false};
     if (!attr[any_bias + 2 * lean]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

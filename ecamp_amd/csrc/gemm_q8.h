@@ -167,11 +167,13 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
 // fragments by the first wave column of the tiles in the first N-tile column, added with 4 buffer atomics per wave and tile.
 // ITEMS (weight-gradient form only): the work items come from a table (Q8Group, gemm_args.h) instead of the tile x split arithmetic;
 // operands and leading dimensions change with the item's problem, every piece stores a dense f32 slab.
-// SCH: 0 = the round-3 stream (descriptors rebuilt per half-tile, bookkeeping in the load interval; the data-gradient and item-table
-// forms), 1 = lean stream (the forward and weight-gradient forms).  Measured and removed again (profiles/r04_gemm_lab_sch.txt): the DMA
-// issue in the matrix interval as well (= sch 0), and wave-specialised producers -- 8 consumer + 4 producer waves, the whole operand
-// stream in waves of its own (tools/probes/gemm_producer_waves_fragment.hip.txt) -- which is within 3 % of this kernel on every shape:
-// the loop waits for the DATA (the L2 -> LDS path beside a power-limited MFMA stream), not for whoever issues the loads.
+// SCH: 0 = the round-3 stream (descriptors rebuilt per half-tile, bookkeeping spread over the load interval; the item-table form),
+// 1 = lean stream (every other form).  Measured and removed again (profiles/r04_gemm_lab_sch.txt): the lean stream's bookkeeping in the
+// matrix interval (-1..3 %), the DMA issue in the matrix interval as well (= sch 0), two k-steps per phase = four barriers per K tile
+// instead of eight (+-1 %), and wave-specialised producers -- 8 consumer + 4 producer waves, the whole operand stream in waves of its own
+// (tools/probes/gemm_producer_waves_fragment.hip.txt) -- within 3 % of this kernel on every shape.  Every schedule lands on the same
+// ~1.75 us per 256 x 256 x 64 step: the loop waits for the DATA (the L2 -> LDS path beside a power-limited MFMA stream), not for whoever
+// issues the loads, for bookkeeping, or for barriers.
 // F8: both operands are OCP e4m3 (one byte per element, contraction-contiguous; BASELINE.json configs[4]).  A K tile is still a
 // 128-byte row per operand row -- 128 elements instead of 64 -- so the LDS images, the rings, the DMA pieces and the counted waits
 // are the bf16 kernel's byte for byte; a phase is four v_mfma_scale_f32_32x32x64_f8f6f4 (64 matrix-pipe cycles each, block scales
@@ -342,11 +344,9 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     //    zero-fills have been consumed (same ring discipline), every counted wait keeps its count, and the kernel drains them before it ends;
     //  * the partial-K lane mask is folded into the per-lane offsets when the stream enters / leaves a tail K tile (twice per item at
     //    most), not evaluated in every part;
-    //  * every piece of bookkeeping -- ring advance, descriptor advance, item decodes (a division chain) -- runs in the MATRIX interval,
-    //    between the MFMAs, where 7 of 8 issue slots are free; the load interval is six fragment reads, two DMA instructions, the waits.
-    // (the data-gradient form -- one strided operand, twelve transpose reads per phase: its matrix interval is the longer one -- keeps
-    // the bookkeeping in the load interval, behind the DMA issue: SCH = 2)
-    constexpr bool ADV_MX = SCH != 2;
+    //  * the decode of the NEXT output tile (a division chain) runs one tile ahead in a matrix interval, between the MFMAs; the stream's own
+    //    bookkeeping -- ring advance, descriptor advance, the stream's item decode -- sits behind the DMA issue of the load interval (in the
+    //    matrix interval it measured 1-3 % slower on every form: profiles/r04_gemm_lab_sch.txt).
     const unsigned char *qa = reinterpret_cast<const unsigned char*>(A), *qb = reinterpret_cast<const unsigned char*>(B);
     int qa_rec = 0, qb_rec = 0, q_krem = 1 << 30, qv = it_beg;
     bool q_tail = false;
@@ -711,9 +711,9 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
     } while (0)
 
-    // ---- the lean-stream phase: [load interval: six fragment reads, the part's two DMA instructions, the waits] barrier [matrix
-    // interval: MFMA 0-3, the bookkeeping behind the part (and MX_HOOK: the decode of the next output tile), MFMA 4-7] barrier.  The
-    // counted wait of phase 3 covers K tile t+1: in flight behind it are A_0 / B_0 of K tile t+2 (4 instructions).
+    // ---- the lean-stream phase: [load interval: six fragment reads, the part's two DMA instructions, the bookkeeping behind the part,
+    // the waits] barrier [matrix interval: MFMA 0-3, (MX_HOOK: the decode of the next output tile), MFMA 4-7] barrier.  The counted wait
+    // of phase 3 covers K tile t+1: in flight behind it are A_0 / B_0 of K tile t+2 (4 instructions).
 #define Q9_PHASE(KS, DPART, WAIT, ZERO, PRE_HOOK, MX_HOOK)                                                              \
     do {                                                                                                                 \
         if (PRE_HOOK) {                                                                                                  \
@@ -723,7 +723,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         }                                                                                                                \
         Q8_READ_GROUP(xm, xn, sM, sN, KS); Q8_SB();                                                                      \
         Q9_ISSUE(DPART); Q8_SB();                                                                                        \
-        if (!ADV_MX) { Q9_ADVANCE(DPART); Q8_SB(); }                                                                     \
+        Q9_ADVANCE(DPART); Q8_SB();                                                                                      \
         if (WAIT) Q8_WAIT_DMA(4);                                                                                        \
         if (!A_KC || !B_KC) { q8_wait4(xm); q8_wait2(xn); }                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); Q8_SB();                                                      \
@@ -732,7 +732,6 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                                                   \
         Q8_MFMA1(xm, xn, 0, ZERO); Q8_MFMA1(xm, xn, 1, ZERO); Q8_SB();                                                   \
         Q8_MFMA1(xm, xn, 2, ZERO); Q8_MFMA1(xm, xn, 3, ZERO); Q8_SB();                                                   \
-        if (ADV_MX) Q9_ADVANCE(DPART);                                                                                   \
         if (MX_HOOK) { if (cv + G < total) Q9_CDECODE(cv + G); }                                                           \
         Q8_SB();                                                                                                         \
         if (ROWSUM) { Q8_RS_ACC(xm); }   /* no scheduling fence behind it: the compiler spreads these between the MFMAs */ \

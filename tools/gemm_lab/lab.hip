@@ -39,9 +39,9 @@ static int g_sch = 0;   // schedule variant of the launches that follow (gemm_q8
 static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
     (void)nslot;
 #define W(A, B, E, S) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, false, S>)
-    if (g_sch == 1 || g_sch == 2) {
+    if (g_sch == 1) {
         if (dbg != 0) return nullptr;
-#define WS(A, B, E) (g_sch == 1 ? W(A, B, E, 1) : W(A, B, E, 2))
+#define WS(A, B, E) W(A, B, E, 1)
         if (a_kc && b_kc) { if (epi == 0) return WS(true, true, 0); if (epi == 1) return WS(true, true, 1); if (epi == 2) return WS(true, true, 2); }
         if (a_kc && !b_kc) { if (epi == 0) return WS(true, false, 0); if (epi == 3) return WS(true, false, 3); if (epi == 2) return WS(true, false, 2); }
         if (!a_kc && !b_kc && epi == 4) return WS(false, false, 4);

@@ -1,3 +1,2 @@
 cd tools/gemm_lab
-./lab --sch=0,1,2 --quick --forms=2 enc_fc1 enc_qkv enc_fc2 bert_inter dec_fc1 dec_fc2 sq4k vocab 2>&1 | grep -v "128^2" | cut -c1-150
-./lab --sch=0,1,2 --quick --forms=2 enc_fc1 enc_qkv enc_fc2 bert_inter dec_fc1 dec_fc2 sq4k vocab 2>&1 | grep -v "128^2" | cut -c1-150
+for i in 1 2; do ./lab --sch=1,2,3 --quick --forms=5 enc_fc1 enc_qkv bert_inter dec_fc1 dec_fc2 bert_dense enc_fc2 2>&1 | grep -v "128^2" | cut -c1-150; done
