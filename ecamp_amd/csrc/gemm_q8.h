@@ -770,7 +770,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         Q8_SB();                                                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
         Q9F_MFMA(0, 0, ZERO); Q9F_MFMA(0, 1, ZERO); Q8_SB();                                                             \
-        Q9_ADVANCE(DPART);                                                                                               \
+        Q9_ADVANCE(DPART);   /* (load-interval placement measured equal on this form: tools/fp8_bench.py) */                   \
         if (MX_HOOK) { if (cv + G < total) Q9_CDECODE(cv + G); }                                                         \
         Q8_SB();                                                                                                         \
         Q9F_MFMA(1, 1, ZERO); Q9F_MFMA(1, 0, ZERO);                                                                      \
