@@ -586,6 +586,17 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
     ECAMP_CHECK_ARG(A8 && B8 && C && scale_a && scale_b, "ecamp_gemm_fp8: null operand");
     ECAMP_CHECK_ARG(M > 0 && N > 0 && K > 0, "ecamp_gemm_fp8: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
     ECAMP_CHECK_ARG(K % 16 == 0 && lda % 16 == 0 && ldb % 16 == 0 && N % 4 == 0, "ecamp_gemm_fp8: K, lda, ldb must be multiples of 16 and N of 4");
+    {   // outputs past 2 GB (the vocabulary projection at B = 512: 65536 x 30000 bf16): two calls over row halves, as ecamp_gemm does
+        const long lim = 0x7fffffffl;
+        if (M >= 512 && !q8_out && (M * ldc * 2 > lim || (residual && M * ldr * 2 > lim) || (pre_out && M * ldp * 2 > lim))) {
+            const int64_t m1 = (M / 2 + 255) / 256 * 256;
+            auto rows = [](const void* p, int64_t r, int64_t ld, int64_t es) { return p ? (const void*)((const char*)p + r * ld * es) : nullptr; };
+            int rc = ecamp_gemm_fp8(A8, B8, C, m1, N, K, lda, ldb, ldc, scale_a, scale_b, bias, residual, ldr, pre_out, ldp, act, nullptr, nullptr, nullptr, stream);
+            if (rc) return rc;
+            return ecamp_gemm_fp8(rows(A8, m1, lda, 1), B8, (void*)rows(C, m1, ldc, 2), M - m1, N, K, lda, ldb, ldc, scale_a, scale_b, bias, rows(residual, m1, ldr, 2),
+                                  ldr, (void*)rows(pre_out, m1, ldp, 2), ldp, act, nullptr, nullptr, nullptr, stream);
+        }
+    }
     GemmArgs g;
     g.dbg = 0; g.wide = 0; g.nsplit = 1;
     g.A = A8; g.B = B8; g.C = C;

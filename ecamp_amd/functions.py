@@ -615,10 +615,18 @@ class MlmHeadFn(torch.autograd.Function):
     def forward(ctx, h, labels, weights, cls, m):
         A = m.arena
         pr = cls.predictions
-        t1, pre = ops.linear_fwd(h, A.w(pr.transform.dense.weight), pr.transform.dense.bias.data, act=1, save_pre=True)
-        ln = pr.transform.LayerNorm
-        t, _, mean, rstd = ops.layernorm_fwd(t1, ln.weight.data, ln.bias.data, ln.eps)
-        logits = ops.linear_fwd(t, A.w(pr.decoder.weight), pr.bias.data)
+        # (fp8 forward, model.fp8_head: the transform dense layer and the 30000-way decoder on the e4m3 kernel as well; the decoder's input
+        # is quantised inside the transform LayerNorm)
+        if m.fp8_forward and m.fp8_head:
+            t1, pre = _dense(m, h, pr.transform.dense.weight, pr.transform.dense.bias.data, act=1, save_pre=True)
+            ln = pr.transform.LayerNorm
+            t, _, mean, rstd, t8 = _ln_q8(m, t1, ln, pr.decoder.weight)
+            logits = _dense(m, t, pr.decoder.weight, pr.bias.data, x8=t8)
+        else:
+            t1, pre = ops.linear_fwd(h, A.w(pr.transform.dense.weight), pr.transform.dense.bias.data, act=1, save_pre=True)
+            ln = pr.transform.LayerNorm
+            t, _, mean, rstd = ops.layernorm_fwd(t1, ln.weight.data, ln.bias.data, ln.eps)
+            logits = ops.linear_fwd(t, A.w(pr.decoder.weight), pr.bias.data)
         if m.keep_aux:
             m._aux_logits = logits.clone()
         s = ops.zeros((1,), h.device)

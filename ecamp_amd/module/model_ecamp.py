@@ -12,6 +12,8 @@ Lifted hard-coded constants of the reference (defaults unchanged): `.cuda()` -> 
 """
 from functools import partial
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -91,6 +93,8 @@ class ECAMP(nn.Module):
         if fp8_forward and compute_dtype != torch.bfloat16:
             raise ValueError("fp8_forward needs compute_dtype=torch.bfloat16")
         self.fp8_forward = bool(fp8_forward)
+        # fp8_forward also covers the MLM head (transform dense + vocabulary decoder) when set; ECAMP_FP8_HEAD=0/1 overrides the default
+        self.fp8_head = os.environ.get("ECAMP_FP8_HEAD", "0") != "0"
         self.bert_config = bert_config if bert_config is not None else BertConfig()
         # image encoder (model_ecamp.py:58-69)
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
