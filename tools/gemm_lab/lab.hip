@@ -1,7 +1,7 @@
 // Development lab for the persistent 8-phase GEMM (ecamp_amd/csrc/gemm_q8.h): a torch-free binary that compiles the SAME kernel
 // header as the product, checks it against the product's 128^2 kernel (ecamp_gemm with q8_mode = 0) and times variants.
 //   make -C tools/gemm_lab        (cross-compiles here)          gpurun -- tools/gemm_lab/lab [shape-substr ...]
-#include "../../ecamp_amd/csrc/gemm_q8.h"
+#include "../../ecamp_amd/csrc/gemm_q4.h"
 #include "../../include/ecamp_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +19,8 @@ static const Shape SHAPES[] = {
     {"dec_qkv", 50432, 1536, 512}, {"dec_fc1", 50432, 2048, 512}, {"dec_fc2", 50432, 512, 2048},
     {"bert_qkv", 32768, 2304, 768}, {"bert_dense", 32768, 768, 768}, {"bert_inter", 32768, 1536, 768}, {"bert_out", 32768, 768, 1536},
     {"vocab", 32768, 30000, 768}, {"sq4k", 4096, 4096, 4096}, {"sq8k", 8192, 8192, 8192}, {"ragged", 1000, 520, 200},
+    // K sweep on one exact round of 256 tiles (per-tile overhead = intercept), and three exact rounds at the model's K
+    {"ks256", 4096, 4096, 256}, {"ks512", 4096, 4096, 512}, {"ks1024", 4096, 4096, 1024}, {"ks2048", 4096, 4096, 2048}, {"r3k768", 12288, 4096, 768},
 };
 
 static unsigned short f2bf_h(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
@@ -39,6 +41,19 @@ static int g_sch = 0;   // schedule variant of the launches that follow (gemm_q8
 static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
     (void)nslot;
 #define W(A, B, E, S) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, false, S>)
+    if (g_sch == 4 || g_sch == 5) {   // four waves of 128 x 128 (gemm_q4.h): forward form only; 5 = with the store-aware tile boundary
+        if (dbg != 0 || !(a_kc && b_kc)) return nullptr;
+        if (g_sch == 4) {
+            if (epi == 0) return (q8_fn)gemm_bf16_q4_kernel<0, false>;
+            if (epi == 1) return (q8_fn)gemm_bf16_q4_kernel<1, false>;
+            if (epi == 2) return (q8_fn)gemm_bf16_q4_kernel<2, false>;
+        } else {
+            if (epi == 0) return (q8_fn)gemm_bf16_q4_kernel<0, true>;
+            if (epi == 1) return (q8_fn)gemm_bf16_q4_kernel<1, true>;
+            if (epi == 2) return (q8_fn)gemm_bf16_q4_kernel<2, true>;
+        }
+        return nullptr;
+    }
     if (g_sch == 1) {
         if (dbg != 0) return nullptr;
 #define WS(A, B, E) W(A, B, E, 1)
@@ -93,10 +108,10 @@ static void launch_q8(const Run& r, int nslot, int dbg, int grid_override, hipSt
     const int epi = r.out_f32 ? 4 : r.gmul ? 3 : r.residual ? 2 : r.pre ? 1 : 0;
     g_sch = nslot;
     q8_fn fn = pick(r.a_kc, r.b_kc, epi, nslot, dbg);
-    if (!fn) { fprintf(stderr, "no Q8 instance for form %d%d epi %d dbg %d\n", r.a_kc, r.b_kc, epi, dbg); exit(1); }
+    if (!fn) { fprintf(stderr, "no Q8 instance for form %d%d epi %d dbg %d sch %d\n", r.a_kc, r.b_kc, epi, dbg, nslot); return; }
     const size_t shm = (size_t)10 * Q8_HALF;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(fn, grid, dim3(512), shm, s, g);
+    hipLaunchKernelGGL(fn, grid, dim3(nslot == 4 || nslot == 5 ? 256 : 512), shm, s, g);
 }
 
 static int launch_ref(const Run& r, int /*unused*/, hipStream_t s) {   // the product's 128^2 kernel
