@@ -1,20 +1,25 @@
-// "Q4": the persistent 256x256x64 bf16 GEMM as FOUR waves of 128x128, one per SIMD (round 4, experiment).
+// "Q4": the persistent 256x256x64 bf16 GEMM as FOUR waves of 128x128, one per SIMD (round 4).  LAB ONLY -- not part of the product
+// library: it ties the eight-wave kernel (profiles/r04_q4_and_power.txt) and the measurements it made possible say why.
 //
-// Why: the counter comparison with the vendor library's kernel (profiles/r04_vendor_vs_q8_pmc.txt) says that its lead on the forward
-// form -- 11 % fewer cycles per tile step at a 5 % higher clock -- comes with one wave per SIMD: a third less LDS traffic (a 128 x 128 wave
-// tile reads 32 fragments per K tile where two 128 x 64 tiles read 48), no phase barriers (one barrier per K tile instead of eight), and
-// every schedule variant of the eight-wave kernel lands on the same ~1.75 us per step (profiles/r04_gemm_lab_sch.txt).  The round-1
-// attempt at this shape (tools/probes/gemm_p4_fragment.hip.txt) was 35-50 % slower; it predates the lean operand stream and the
-// discovery that hipcc drains the DMA queue (vmcnt(0)) in front of LDS reads it does not understand.
+// Why it was built: the counter comparison with the vendor library's kernel (profiles/r04_vendor_vs_q8_pmc.txt) says that kernel runs
+// one wave per SIMD: a third less LDS traffic (a 128 x 128 wave tile reads 32 fragments per K tile where two 128 x 64 tiles read 48),
+// few barriers, few scalar instructions -- and every schedule variant of the eight-wave kernel lands on the same time per K tile.
 //
 // Structure.  Same LDS images, rings (5 half-tile slots per operand), DMA pieces, descriptors and tile order as gemm_q8.h: half-tile A_r
 // holds the 128 rows of wave row r, B_c the 128 columns of wave column c.  A K tile is ONE instruction stream per wave: for each of its
-// four k-steps of 16, sixteen MFMAs (4 x 4 tiles of 32 x 32) with the eight fragment reads of the NEXT k-step and this wave's four DMA
-// pieces of one half-tile part slotted between them in fixed positions (scheduling fences pin the order); the fragments are double
-// buffered in registers (there are 512 per lane).  One counted DMA wait and ONE barrier per K tile publish K tile t+1; the first k-step's
-// fragments of a K tile are read behind that barrier.
+// four k-steps of 16, sixteen MFMAs (4 x 4 tiles of 32 x 32) with ONE other instruction in the shadow of each: the eight fragment reads
+// of the NEXT k-step (across the K tile boundary too: k-step 3 reads k-step 0 of the next K tile), this wave's four DMA pieces of one
+// half-tile part, the stream bookkeeping (scheduling fences pin the order); the fragments are double buffered in registers.  One
+// counted DMA wait and ONE barrier per K tile (between k-steps 2 and 3) publish K tile t+1.  0 scratch, 117-125 VGPRs + 256 AGPRs.
+//
+// What it showed (profiles/r04_q4_and_power.txt): bit-exact at the first run; the plain forward form within -3 .. +3 % of the eight-wave
+// kernel on every shape, the same time per K tile (slope of a K sweep) to 1 %; the GELU epilogue 8-15 % slower (one wave per SIMD has
+// nobody to overlap its 256 accumulators' arithmetic with).  Issuing all DMA parts right behind the barrier (three k-steps of lead
+// instead of two, EARLY) is 5-9 % SLOWER: the loop does not wait for DMA latency.  With all-zero operands the same instruction
+// stream needs 1.12 us per K tile instead of 1.64 (eight-wave kernel: 1.12 / 1.64): the loop is bound by the socket's power limit
+// on the matrix pipes + operand movement, not by its structure.
 #pragma once
-#include "gemm_q8.h"
+#include "../../ecamp_amd/csrc/gemm_q8.h"
 
 template <bool KC>
 __device__ __forceinline__ unsigned q4_voff(int pi, int lane, long ld) {   // per-lane source offset of piece `pi` (0..15) of a half-tile
@@ -30,11 +35,12 @@ __device__ __forceinline__ unsigned q4_voff(int pi, int lane, long ld) {   // pe
 }
 
 // EPI: 0 bf16 C = alpha*acc (+bias)   1 ... + save pre-activation + exact GELU   2 ... + residual
-// BND: the tile boundary.  gfx9 counts loads and stores in ONE in-order counter, so a counted DMA wait behind the epilogue waits for the
-// epilogue's stores to be acknowledged as well.  With BND the last part the next K tile needs (B_1 of K tile t+2) is issued in FRONT of
-// the stores and that K tile's wait lets the stores (and the two parts behind them) stay in flight: the first wait that covers the
-// stores comes one K tile later.
-template <int EPI, bool BND>
+// EARLY: the DMA lead.  false: one half-tile part per k-step (B_1(t+1), A_0(t+2), B_0(t+2) | barrier | A_1(t+2)): the youngest part the
+// barrier waits for was issued two k-steps earlier.  true: all four parts that fit the ring are issued in k-step 3, right behind the
+// barrier that freed their slots (A_1, B_1 of t+2 and A_0, B_0 of t+3): the youngest part a barrier waits for is three k-steps old.
+// (A variant that issued B_1(t+2) in front of the epilogue's stores and let the stores stay in flight across the next K tile's
+// counted wait -- gfx9 counts loads and stores in one in-order counter -- measured 1-3 % slower: removed.)
+template <int EPI, bool EARLY, int DBG = 0>   // DBG (lab only): 1 no MFMA, 2 no DMA, 4 no fragment reads
 __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
     constexpr int NSLOT = 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // A ring (5 x 16 KB) | B ring (5 x 16 KB); the ONLY LDS object
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
     typedef void __attribute__((address_space(3))) lds_void_;
     // piece J (0..3) of part PART (0: A half 0, 1: B half 0, 2: A half 1, 3: B half 1)
 #define Q4_ISSUE1(PART, J)                                                                                               \
-    if ((PART) >= 0) do {                                                                                                \
+    if ((PART) >= 0 && !(DBG & 2)) do {                                                                                                \
         constexpr bool isA_ = (((PART) & 1) == 0);                                                                       \
         constexpr int h_ = (PART) >> 1;                                                                                  \
         const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(isA_ ? qa : qb), 0, isA_ ? qa_rec : qb_rec, 0x00020000); \
@@ -170,9 +176,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
     // boundary too: k-step 3 reads k-step 0 of the next K tile, which the barrier in front of it has published
     hw_bf16x8 fa[2][4], fb[2][4];
 #define Q4_SB() __builtin_amdgcn_sched_barrier(0)
-#define Q4_RDA(S, KS, I, SM_) fa[S][I] = *reinterpret_cast<const hw_bf16x8*>((SM_) + offM[KS] + (I) * 4096)
-#define Q4_RDB(S, KS, I, SN_) fb[S][I] = *reinterpret_cast<const hw_bf16x8*>((SN_) + offN[KS] + (I) * 4096)
-#define Q4_MFMA(S, I, ZERO) acc[(I) & 3][(I) >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][(I) >> 2], fa[S][(I) & 3], (ZERO) ? zero16 : acc[(I) & 3][(I) >> 2], 0, 0, 0)
+#define Q4_RDA(S, KS, I, SM_) if (!(DBG & 4)) fa[S][I] = *reinterpret_cast<const hw_bf16x8*>((SM_) + offM[KS] + (I) * 4096)
+#define Q4_RDB(S, KS, I, SN_) if (!(DBG & 4)) fb[S][I] = *reinterpret_cast<const hw_bf16x8*>((SN_) + offN[KS] + (I) * 4096)
+#define Q4_MFMA(S, I, ZERO) if (!(DBG & 1)) acc[(I) & 3][(I) >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][(I) >> 2], fa[S][(I) & 3], (ZERO) ? zero16 : acc[(I) & 3][(I) >> 2], 0, 0, 0)
     // one k-step: sixteen MFMAs, ONE other action in the shadow of each (a wave issues in order: a clump of reads and DMA behind four MFMAs
     // outlasts the fourth one's 32 cycles and idles the matrix pipe).  The eight fragment reads of the next k-step (set NS, k-step NKS of
     // the K tile at SM_ / SN_) come in the order its MFMAs consume them; four DMA pieces of part DPART; the stream bookkeeping last.
@@ -196,6 +202,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
         Q4_MFMA(S, 14, ZERO); Q4_SB(); Q4_ISSUE1(DPART, 3); Q4_SB();                                                     \
         Q4_MFMA(S, 15, ZERO); Q4_SB(); Q4_ADVANCE(DPART); Q4_SB();                                                       \
     } while (0)
+    // k-step 3 with EARLY: the next K tile's first fragments and sixteen DMA pieces (parts 2, 3, 0, 1 in stream order), one per MFMA
+#define Q4_KSTEP3E(S, NS, SM_, SN_)                                                                                      \
+    do {                                                                                                                 \
+        Q4_SB();                                                                                                         \
+        Q4_MFMA(S, 0, false);  Q4_SB(); Q4_RDB(NS, 0, 0, SN_); Q4_ISSUE1(2, 0); Q4_SB();                                 \
+        Q4_MFMA(S, 1, false);  Q4_SB(); Q4_RDA(NS, 0, 0, SM_); Q4_ISSUE1(2, 1); Q4_SB();                                 \
+        Q4_MFMA(S, 2, false);  Q4_SB(); Q4_RDA(NS, 0, 1, SM_); Q4_ISSUE1(2, 2); Q4_SB();                                 \
+        Q4_MFMA(S, 3, false);  Q4_SB(); Q4_RDA(NS, 0, 2, SM_); Q4_ISSUE1(2, 3); Q4_ADVANCE(2); Q4_SB();                  \
+        Q4_MFMA(S, 4, false);  Q4_SB(); Q4_RDA(NS, 0, 3, SM_); Q4_ISSUE1(3, 0); Q4_SB();                                 \
+        Q4_MFMA(S, 5, false);  Q4_SB(); Q4_RDB(NS, 0, 1, SN_); Q4_ISSUE1(3, 1); Q4_SB();                                 \
+        Q4_MFMA(S, 6, false);  Q4_SB(); Q4_RDB(NS, 0, 2, SN_); Q4_ISSUE1(3, 2); Q4_SB();                                 \
+        Q4_MFMA(S, 7, false);  Q4_SB(); Q4_RDB(NS, 0, 3, SN_); Q4_ISSUE1(3, 3); Q4_ADVANCE(3); Q4_SB();                  \
+        Q4_MFMA(S, 8, false);  Q4_SB(); Q4_ISSUE1(0, 0); Q4_SB();                                                        \
+        Q4_MFMA(S, 9, false);  Q4_SB(); Q4_ISSUE1(0, 1); Q4_SB();                                                        \
+        Q4_MFMA(S, 10, false); Q4_SB(); Q4_ISSUE1(0, 2); Q4_SB();                                                        \
+        Q4_MFMA(S, 11, false); Q4_SB(); Q4_ISSUE1(0, 3); Q4_ADVANCE(0); Q4_SB();                                         \
+        Q4_MFMA(S, 12, false); Q4_SB(); Q4_ISSUE1(1, 0); Q4_SB();                                                        \
+        Q4_MFMA(S, 13, false); Q4_SB(); Q4_ISSUE1(1, 1); Q4_SB();                                                        \
+        Q4_MFMA(S, 14, false); Q4_SB(); Q4_ISSUE1(1, 2); Q4_SB();                                                        \
+        Q4_MFMA(S, 15, false); Q4_SB(); Q4_ISSUE1(1, 3); Q4_ADVANCE(1); Q4_SB();                                         \
+    } while (0)
     int rA = 0, rB = 0;   // ring slots of A_0 / B_0 of the K tile being multiplied
     // a K tile t.  Staged during its k-steps 0..3: B_1(t+1), A_0(t+2), B_0(t+2), A_1(t+2) -- the last one into the slot of A_0(t), which is
     // free once every wave is past the barrier between k-steps 2 and 3 (all of tile t's fragments have been read by then).  That barrier,
@@ -207,13 +234,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
         const unsigned char* sN = lds + (NSLOT + Q4_SLOT(rB, wc)) * Q8_HALF;                                             \
         const unsigned char* sMn = lds + Q4_SLOT(rA, 2 + wr) * Q8_HALF;                                                  \
         const unsigned char* sNn = lds + (NSLOT + Q4_SLOT(rB, 2 + wc)) * Q8_HALF;                                        \
-        if (BND && (FIRST)) Q4_KSTEP(0, FIRST, 1, 1, sM, sN, -1); else Q4_KSTEP(0, FIRST, 1, 1, sM, sN, 3);                \
-        Q4_KSTEP(1, false, 0, 2, sM, sN, 0);                                                                             \
-        Q4_KSTEP(0, false, 1, 3, sM, sN, 1);                                                                             \
-        if (BND && (FIRST)) { if (EPI == 0) asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); } \
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                            \
+        Q4_KSTEP(0, FIRST, 1, 1, sM, sN, (EARLY ? -1 : 3));                                                              \
+        Q4_KSTEP(1, false, 0, 2, sM, sN, (EARLY ? -1 : 0));                                                              \
+        Q4_KSTEP(0, false, 1, 3, sM, sN, (EARLY ? -1 : 1));                                                              \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                 \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); Q4_SB();                                                      \
         __builtin_amdgcn_s_barrier(); Q4_SB();                                                                           \
+        if (EARLY) Q4_KSTEP3E(1, 0, sMn, sNn); else                                                                      \
         Q4_KSTEP(1, false, 0, 0, sMn, sNn, 2);                                                                           \
         rA = Q4_SLOT(rA, 2); rB = Q4_SLOT(rB, 2);                                                                        \
     } while (0)
@@ -223,8 +250,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
     if (qv < total) Q4_ITEM();
     Q4_ISSUE_ALL(0); Q4_ADVANCE(0); Q4_ISSUE_ALL(1); Q4_ADVANCE(1); Q4_ISSUE_ALL(2); Q4_ADVANCE(2); Q4_ISSUE_ALL(3); Q4_ADVANCE(3);
     Q4_ISSUE_ALL(0); Q4_ADVANCE(0); Q4_ISSUE_ALL(1); Q4_ADVANCE(1); Q4_ISSUE_ALL(2); Q4_ADVANCE(2);
-    if (BND) { Q4_ISSUE_ALL(3); Q4_ADVANCE(3); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // (K tile 1 too: the first tile's relaxed wait has no stores to allow for)
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (EARLY) {   // ... and B_1 of K tile 1, A_0 / B_0 of K tile 2: the whole ring
+        Q4_ISSUE_ALL(3); Q4_ADVANCE(3); Q4_ISSUE_ALL(0); Q4_ADVANCE(0); Q4_ISSUE_ALL(1); Q4_ADVANCE(1);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
         const unsigned char* sM = lds + wr * Q8_HALF;
@@ -241,7 +270,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
         Q4_KTILE(true);
 #pragma unroll 1
         for (int t = 1; t < cit.nt; ++t) Q4_KTILE(false);
-        if (BND) { Q4_ISSUE_ALL(3); Q4_ADVANCE(3); Q4_SB(); }
         Q4_STORE_ROW(cit.m0, cit.n0, 0); Q4_STORE_ROW(cit.m0, cit.n0, 1); Q4_STORE_ROW(cit.m0, cit.n0, 2); Q4_STORE_ROW(cit.m0, cit.n0, 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the exhausted stream's zero-length loads still write their (zero) pieces into this workgroup's LDS
@@ -256,5 +284,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
 #undef Q4_RDB
 #undef Q4_MFMA
 #undef Q4_KSTEP
+#undef Q4_KSTEP3E
 #undef Q4_KTILE
 }

@@ -1,7 +1,7 @@
 // Development lab for the persistent 8-phase GEMM (ecamp_amd/csrc/gemm_q8.h): a torch-free binary that compiles the SAME kernel
 // header as the product, checks it against the product's 128^2 kernel (ecamp_gemm with q8_mode = 0) and times variants.
 //   make -C tools/gemm_lab        (cross-compiles here)          gpurun -- tools/gemm_lab/lab [shape-substr ...]
-#include "../../ecamp_amd/csrc/gemm_q4.h"
+#include "gemm_q4.h"
 #include "../../include/ecamp_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,12 +37,22 @@ static void fill_bf16(unsigned short* d, size_t n, float scale) {
 
 typedef void (*q8_fn)(GemmArgs);
 // epi: 0 plain(+bias) 1 bias+pre+gelu 2 +residual 3 gmul 4 f32.  dbg variants only exist for the forward form.
+static int g_zero = 0;
 static int g_sch = 0;   // schedule variant of the launches that follow (gemm_q8.h SCH)
 static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
     (void)nslot;
 #define W(A, B, E, S) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, false, S>)
-    if (g_sch == 4 || g_sch == 5) {   // four waves of 128 x 128 (gemm_q4.h): forward form only; 5 = with the store-aware tile boundary
-        if (dbg != 0 || !(a_kc && b_kc)) return nullptr;
+    if (g_sch == 4 || g_sch == 5) {   // four waves of 128 x 128 (gemm_q4.h): forward form only; 5 = all DMA parts right behind the barrier (EARLY)
+        if (!(a_kc && b_kc)) return nullptr;
+        if (dbg != 0) {   // timing decomposition of the plain kernel: 1 no MFMA, 2 no DMA, 4 no fragment reads (results are garbage)
+            if (g_sch != 4 || epi != 0) return nullptr;
+            if (dbg == 1) return (q8_fn)gemm_bf16_q4_kernel<0, false, 1>;
+            if (dbg == 2) return (q8_fn)gemm_bf16_q4_kernel<0, false, 2>;
+            if (dbg == 4) return (q8_fn)gemm_bf16_q4_kernel<0, false, 4>;
+            if (dbg == 6) return (q8_fn)gemm_bf16_q4_kernel<0, false, 6>;
+            if (dbg == 5) return (q8_fn)gemm_bf16_q4_kernel<0, false, 5>;
+            return nullptr;
+        }
         if (g_sch == 4) {
             if (epi == 0) return (q8_fn)gemm_bf16_q4_kernel<0, false>;
             if (epi == 1) return (q8_fn)gemm_bf16_q4_kernel<1, false>;
@@ -175,6 +185,7 @@ int main(int argc, char** argv) {
     for (int i = 1; i < argc; ++i) {
         if (!strncmp(argv[i], "--stress=", 9)) { stress = atoi(argv[i] + 9); continue; }
         if (!strcmp(argv[i], "--hog")) { hog = 1; continue; }
+        if (!strcmp(argv[i], "--zero")) { g_zero = 1; continue; }   // all-zero operands: the matrix pipes draw far less power (is a gap power or structure?)
         if (!strncmp(argv[i], "--forms=", 8)) forms = atoi(argv[i] + 8);
         else if (!strcmp(argv[i], "--quick")) quick = true;
         else if (!strncmp(argv[i], "--grid=", 7)) grid_override = atoi(argv[i] + 7);
@@ -197,7 +208,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&pre0, (size_t)M * N * 2)); CK(hipMalloc(&pre1, (size_t)M * N * 2));
         CK(hipMalloc(&dx0, (size_t)M * K * 2)); CK(hipMalloc(&dx1, (size_t)M * K * 2));
         CK(hipMalloc(&bias, (size_t)N * 4)); CK(hipMalloc(&gw0, (size_t)N * K * 4)); CK(hipMalloc(&gw1, (size_t)N * K * 4));
-        fill_bf16(x, (size_t)M * K, 1.0f); fill_bf16(w, (size_t)N * K, 1.0f / sqrtf((float)K)); fill_bf16(dy, (size_t)M * N, 1.0f);
+        fill_bf16(x, (size_t)M * K, g_zero ? 0.f : 1.0f); fill_bf16(w, (size_t)N * K, g_zero ? 0.f : 1.0f / sqrtf((float)K)); fill_bf16(dy, (size_t)M * N, 1.0f);
         { std::vector<float> hb(N); for (auto& v : hb) v = frand(); CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice)); }
         const double fl = 2.0 * M * N * K;
         if (stress > 0) {
@@ -235,7 +246,7 @@ int main(int argc, char** argv) {
             printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f\n", sh.name, "fwd", M, N, K, "128^2 (r1)", t_ref, fl / t_ref / 1e6);
             for (int ns : nslots)
                 for (int dbg : dbgs) {
-                    if (ns != 0 && dbg != 0) continue;
+                    if (ns != 0 && ns != 4 && dbg != 0) continue;
                     CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s));
                     launch_q8(q, ns, dbg, grid_override, s);
                     CK(hipStreamSynchronize(s));
@@ -250,7 +261,7 @@ int main(int argc, char** argv) {
             launch_ref(r2, 0, s);
             for (int ns : nslots)
             for (int dbg : dbgs) {
-                if (ns != 0 && dbg != 0) continue;
+                if (ns != 0 && ns != 4 && dbg != 0) continue;
                 CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s));
                 launch_q8(q2, ns, dbg, grid_override, s);
                 CK(hipStreamSynchronize(s));
