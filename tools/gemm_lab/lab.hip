@@ -147,7 +147,9 @@ static unsigned long long checksum(const void* p, size_t bytes, hipStream_t s) {
     return h;
 }
 
-template <typename F> static float time_us(F f, int n = 20) {
+static int g_n = 20;   // launches per timing (--n=; a long run lets tools/power_probe-style sampling see the loop)
+template <typename F> static float time_us(F f, int n = 0) {
+    if (n == 0) n = g_n;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); f(); CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
@@ -185,6 +187,7 @@ int main(int argc, char** argv) {
     for (int i = 1; i < argc; ++i) {
         if (!strncmp(argv[i], "--stress=", 9)) { stress = atoi(argv[i] + 9); continue; }
         if (!strcmp(argv[i], "--hog")) { hog = 1; continue; }
+        if (!strncmp(argv[i], "--n=", 4)) { g_n = atoi(argv[i] + 4); continue; }
         if (!strcmp(argv[i], "--zero")) { g_zero = 1; continue; }   // all-zero operands: the matrix pipes draw far less power (is a gap power or structure?)
         if (!strncmp(argv[i], "--forms=", 8)) forms = atoi(argv[i] + 8);
         else if (!strcmp(argv[i], "--quick")) quick = true;
