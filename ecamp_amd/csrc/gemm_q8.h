@@ -160,7 +160,7 @@ __device__ __forceinline__ q8_u32x4 q8_pack8(const float (&v)[8]) {
     return (q8_u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
 }
 
-// DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 8 = no s_setprio, 16 = no barriers in the
+// DBG bits (development, template parameter): 1 = no MFMA, 2 = no DMA, 4 = no epilogue, 1024 = the epilogue runs but every store / load is out of range (dropped), 8 = no s_setprio, 16 = no barriers in the
 // loop, 32 = no fragment reads, 64 = every DMA re-reads the tile's first K tile (timing decomposition only: 16, 32, 64 give wrong results),
 // 128 / 256 = nt / sc1 output stores, 512 = workgroups start in four phases 9 us apart (lock-step epilogue bursts: the stagger costs what it saves)
 // ROWSUM (weight-gradient form only): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient -- summed on the VALU from the M-side
@@ -553,7 +553,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
             for (int gq = 0; gq < 2; ++gq) {
                 const long row = mb + tm * 32, col = nb + 16 * gq;
                 // (rows past M fall outside the descriptors by themselves -- except inside the stack of split-K slabs)
-                const bool oob = (edge && (nb + 16 * gq + 8 * lh >= g.N)) || (EPI == 4 && g.partial && mb + tm * 32 + l31 >= g.M);
+                const bool oob = (DBG & 1024) || (edge && (nb + 16 * gq + 8 * lh >= g.N)) || (EPI == 4 && g.partial && mb + tm * 32 + l31 >= g.M);   // (DBG 1024: every store dropped by its descriptor)
                 uo[tm][gq] = oob ? 0x80000000u : (unsigned)(((EPI == 4 && g.partial ? (long)tz * g.M : 0) + row) * ldo + col) * esz + lane_o;
                 if (EPI == 1) up[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldp + col) * 2) + lane_p;
                 if (EPI == 3) ug[tm][gq] = oob ? 0x80000000u : (unsigned)((row * g.ldg + col) * 2) + lane_g;

@@ -1,5 +1,2 @@
 cd tools/gemm_lab
-for i in 1 2; do
-./lab --sch=1,4 --quick --forms=1 ks2048 sq4k 2>&1 | grep "plain" | cut -c1-110
-./lab --zero --sch=1,4 --quick --forms=1 ks2048 sq4k 2>&1 | grep "plain" | sed 's/^/ZERO /' | cut -c1-110
-done
+for i in 1 2; do ./lab --sch=1 --dbg=0,4,1024 --quick --forms=1 enc_fc1 bert_inter dec_fc1 r3k768 2>&1 | grep "Q8" | cut -c1-110; done
