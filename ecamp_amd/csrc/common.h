@@ -149,14 +149,62 @@ __device__ __forceinline__ float erf_as_f(float z, float& e) {   // -> erf(z);  
     e = __builtin_amdgcn_exp2f(-1.4426950408889634f * a * a);
     return copysignf(fmaf(-p, e, 1.0f), z);
 }
-__device__ __forceinline__ float gelu_fast_f(float x) {
-    float e;
-    return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f, e));
+// Forward only needs erf, and Abramowitz-Stegun 7.1.28 gives erfc(z) = (1 + a1 z + ... + a6 z^6)^-16 (|error| <= 3e-7) with ONE
+// quarter-rate instruction (v_rcp_f32) instead of two (7.1.26 needs v_rcp_f32 and v_exp_f32): the GELU epilogue of the fc1 GEMMs is VALU
+// time with the matrix pipes idle (profiles/r04_q4_and_power.txt section 8), and the two transcendentals were 44 % of it.  The
+// polynomial is in a = |x| with the 1/sqrt(2) folded into the coefficients, split into even and odd parts, and
+// x * Phi(x) = x/2 + |x| * (1 - erfc(|x|/sqrt 2)) / 2 needs no sign select: everything but the two multiply-adds by |x| packs
+// (v_pk_fma_f32 / v_pk_mul_f32 have no |x| modifier) -- ~12 issue slots per element instead of ~18.  The pair form exists because
+// hipcc stops packing the scalar form on its own once the constants are fma literals.
+// Over all 65 280 finite bf16 inputs: max |error| 7.0e-7 (7.1.26: 4.4e-7); 9 results with |y| > 1e-4 round to the other bf16
+// neighbour than the exact function (7.1.26: 2).  Huge |x|: x*x = inf -> s = inf -> erfc = 0 -> x or 0, no NaN.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_fast_f2(f32x2_t x) {
+    const f32x2_t x2 = x * x;
+    f32x2_t E = __builtin_elementwise_fma((f32x2_t)(5.3829750000e-06f), x2, (f32x2_t)(3.8003575000e-05f));
+    E = __builtin_elementwise_fma(E, x2, (f32x2_t)(2.1141006150e-02f));
+    E = __builtin_elementwise_fma(E, x2, (f32x2_t)(1.0f));
+    f32x2_t O = __builtin_elementwise_fma((f32x2_t)(4.8890635643e-05f), x2, (f32x2_t)(3.2776263241e-03f));
+    O = __builtin_elementwise_fma(O, x2, (f32x2_t)(4.9867346967e-02f));
+    f32x2_t s = {fmaf(fabsf(x[0]), O[0], E[0]), fmaf(fabsf(x[1]), O[1], E[1])};
+    s *= s; s *= s; s *= s; s *= s;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(s[0]), __builtin_amdgcn_rcpf(s[1])};   // erfc(|x| / sqrt 2)
+    const f32x2_t q = __builtin_elementwise_fma((f32x2_t)(-0.5f), r, (f32x2_t)(0.5f));
+    const f32x2_t hx = x * 0.5f;
+    return (f32x2_t){fmaf(fabsf(x[0]), q[0], hx[0]), fmaf(fabsf(x[1]), q[1], hx[1])};
+}
+__device__ __forceinline__ float gelu_fast_f(float x) {   // the same operations on one value (bit-identical to a lane of the pair form)
+    const float x2 = x * x;
+    const float E = fmaf(fmaf(fmaf(5.3829750000e-06f, x2, 3.8003575000e-05f), x2, 2.1141006150e-02f), x2, 1.0f);
+    const float O = fmaf(fmaf(4.8890635643e-05f, x2, 3.2776263241e-03f), x2, 4.9867346967e-02f);
+    float s = fmaf(fabsf(x), O, E);
+    s *= s; s *= s; s *= s; s *= s;
+    const float q = fmaf(-0.5f, __builtin_amdgcn_rcpf(s), 0.5f);
+    return fmaf(fabsf(x), q, x * 0.5f);
 }
 __device__ __forceinline__ float gelu_grad_fast_f(float x) {
     float e;
     const float cdf = 0.5f * (1.0f + erf_as_f(x * 0.70710678118654752440f, e));
     return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+// The same operations in the same order on two values (bit-identical to the scalar form), written out so that everything except
+// |z|, the sign transfer and the two quarter-rate instructions is a packed instruction (the gelu' epilogue of the fc2 data gradient).
+__device__ __forceinline__ f32x2_t gelu_grad_fast_f2(f32x2_t x) {
+    const f32x2_t z = x * 0.70710678118654752440f;
+    const f32x2_t a = {fabsf(z[0]), fabsf(z[1])};
+    const f32x2_t d = __builtin_elementwise_fma((f32x2_t)(0.3275911f), a, (f32x2_t)(1.0f));
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2_t p = __builtin_elementwise_fma((f32x2_t)(1.061405429f), t, (f32x2_t)(-1.453152027f));
+    p = __builtin_elementwise_fma(p, t, (f32x2_t)(1.421413741f));
+    p = __builtin_elementwise_fma(p, t, (f32x2_t)(-0.284496736f));
+    p = __builtin_elementwise_fma(p, t, (f32x2_t)(0.254829592f));
+    p *= t;
+    const f32x2_t m = (a * -1.4426950408889634f) * a;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
+    const f32x2_t er = __builtin_elementwise_fma(-p, e, (f32x2_t)(1.0f));                    // erf(|z|)
+    const f32x2_t ers = {copysignf(er[0], z[0]), copysignf(er[1], z[1])};
+    const f32x2_t cdf = (ers + 1.0f) * 0.5f;
+    return __builtin_elementwise_fma(x * 0.39894228040143267794f, e, cdf);
 }
 template <typename T> __device__ __forceinline__ float gelu_t(float x);
 template <> __device__ __forceinline__ float gelu_t<float>(float x) { return gelu_f(x); }

@@ -593,7 +593,10 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                 if (EPI == 1) {
                     __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rP, up[tm][gq], 0, ST_AUX);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16_t>(rnd<bf16_t>(v[r]));
+                    for (int r = 0; r < 8; r += 2) {   // pair form: packed math (common.h)
+                        const f32x2_t y_ = gelu_fast_f2((f32x2_t){rnd<bf16_t>(v[r]), rnd<bf16_t>(v[r + 1])});
+                        v[r] = y_[0]; v[r + 1] = y_[1];
+                    }
                     if (F8 && g.q8_out) {
                         float u[8];
 #pragma unroll
@@ -613,8 +616,9 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                 if (EPI == 3) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[2 * r] *= gelu_grad_t<bf16_t>(__uint_as_float(qg[tm][gq][r] << 16));
-                        v[2 * r + 1] *= gelu_grad_t<bf16_t>(__uint_as_float(qg[tm][gq][r] & 0xffff0000u));
+                        const f32x2_t gp_ = gelu_grad_fast_f2((f32x2_t){__uint_as_float(qg[tm][gq][r] << 16), __uint_as_float(qg[tm][gq][r] & 0xffff0000u)});
+                        v[2 * r] *= gp_[0];
+                        v[2 * r + 1] *= gp_[1];
                     }
                 }
                 if (EPI == 2 || (EPI == 3 && g.residual)) {
