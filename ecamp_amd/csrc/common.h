@@ -182,6 +182,33 @@ __device__ __forceinline__ float gelu_fast_f(float x) {   // the same operations
     const float q = fmaf(-0.5f, __builtin_amdgcn_rcpf(s), 0.5f);
     return fmaf(fabsf(x), q, x * 0.5f);
 }
+// GELU and its derivative together (act == 2, "saved derivative": the forward epilogue stores gelu'(x) in place of the pre-activation x,
+// and the data-gradient epilogue of the following layer multiplies by it -- no erf / exp at all in the backward pass).  y is
+// bit-identical to gelu_fast_f2; Phi = 1/2 + sign(x) (1 - erfc(|x|/sqrt 2))/2 reuses its q; the density costs the one v_exp_f32.
+__device__ __forceinline__ f32x2_t gelu_both_fast_f2(f32x2_t x, f32x2_t& g) {
+    const f32x2_t x2 = x * x;
+    f32x2_t E = __builtin_elementwise_fma((f32x2_t)(5.3829750000e-06f), x2, (f32x2_t)(3.8003575000e-05f));
+    E = __builtin_elementwise_fma(E, x2, (f32x2_t)(2.1141006150e-02f));
+    E = __builtin_elementwise_fma(E, x2, (f32x2_t)(1.0f));
+    f32x2_t O = __builtin_elementwise_fma((f32x2_t)(4.8890635643e-05f), x2, (f32x2_t)(3.2776263241e-03f));
+    O = __builtin_elementwise_fma(O, x2, (f32x2_t)(4.9867346967e-02f));
+    f32x2_t s = {fmaf(fabsf(x[0]), O[0], E[0]), fmaf(fabsf(x[1]), O[1], E[1])};
+    s *= s; s *= s; s *= s; s *= s;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(s[0]), __builtin_amdgcn_rcpf(s[1])};
+    const f32x2_t q = __builtin_elementwise_fma((f32x2_t)(-0.5f), r, (f32x2_t)(0.5f));
+    const f32x2_t hx = x * 0.5f;
+    const f32x2_t m = x2 * -0.72134752044448170368f;                                 // -x^2/2 * log2(e)
+    const f32x2_t e = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
+    const f32x2_t phi = {0.5f + copysignf(q[0], x[0]), 0.5f + copysignf(q[1], x[1])};
+    g = __builtin_elementwise_fma(x * 0.39894228040143267794f, e, phi);
+    return (f32x2_t){fmaf(fabsf(x[0]), q[0], hx[0]), fmaf(fabsf(x[1]), q[1], hx[1])};
+}
+__device__ __forceinline__ float gelu_both_fast_f(float x, float& g) {   // the same operations on one value
+    f32x2_t g2;
+    const f32x2_t y = gelu_both_fast_f2((f32x2_t){x, x}, g2);
+    g = g2[0];
+    return y[0];
+}
 __device__ __forceinline__ float gelu_grad_fast_f(float x) {
     float e;
     const float cdf = 0.5f * (1.0f + erf_as_f(x * 0.70710678118654752440f, e));

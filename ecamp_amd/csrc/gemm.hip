@@ -581,9 +581,10 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
                               int64_t ldc, const float* scale_a, const float* scale_b, const float* bias, const void* residual,
                               int64_t ldr, void* pre_out, int64_t ldp, int act, void* q8_out, const float* q8_scale, float* q8_amax_slots,
                               hipStream_t stream) {
-    ECAMP_CHECK_ARG(!q8_out || (q8_scale && q8_amax_slots && act == 1 && pre_out && !residual && ldc == N),
+    ECAMP_CHECK_ARG(!q8_out || (q8_scale && q8_amax_slots && (act == 1 || act == 2) && pre_out && !residual && ldc == N),
                     "ecamp_gemm_fp8: the e4m3 copy of the output needs its scale and amax slots, the GELU epilogue and a dense C");
     ECAMP_CHECK_ARG(A8 && B8 && C && scale_a && scale_b, "ecamp_gemm_fp8: null operand");
+    ECAMP_CHECK_ARG(act >= 0 && act <= 2 && (act != 2 || pre_out), "ecamp_gemm_fp8: act=%d (0 none, 1 GELU, 2 GELU with the saved derivative in pre_out)", act);
     ECAMP_CHECK_ARG(M > 0 && N > 0 && K > 0, "ecamp_gemm_fp8: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
     ECAMP_CHECK_ARG(K % 16 == 0 && lda % 16 == 0 && ldb % 16 == 0 && N % 4 == 0, "ecamp_gemm_fp8: K, lda, ldb must be multiples of 16 and N of 4");
     {   // outputs past 2 GB (the vocabulary projection at B = 512: 65536 x 30000 bf16): two calls over row halves, as ecamp_gemm does
@@ -617,7 +618,7 @@ extern "C" int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M
     {
         static const int f8q8 = getenv("ECAMP_F8_Q8") ? atoi(getenv("ECAMP_F8_Q8")) : 1;
         const int q8m = q8_env();
-        const int epi = (pre_out || act) ? ((pre_out && act == 1 && !residual) ? 1 : -1) : residual ? 2 : 0;
+        const int epi = (pre_out || act) ? ((pre_out && (act == 1 || act == 2) && !residual) ? 1 : -1) : residual ? 2 : 0;
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         const long lim = 0x7fffffffl;
         const long items8 = (long)ceil_div(M, 256) * ceil_div(N, 256);
@@ -693,8 +694,8 @@ static int q8_env() {
 // epilogue variant of a call (-1: none fits)
 static int q8_epi(const float* bias, const void* residual, const void* pre_out, const void* gmul, int act, int out_f32) {
     if (out_f32) return (!bias && !residual && !pre_out && !gmul && !act) ? 4 : -1;
-    if (gmul) return (!bias && !pre_out && !act) ? 3 : -1;
-    if (pre_out || act) return (pre_out && act == 1 && !residual) ? 1 : -1;
+    if (gmul) return (!bias && !pre_out && (act == 0 || act == 2)) ? 3 : -1;
+    if (pre_out || act) return (pre_out && (act == 1 || act == 2) && !residual) ? 1 : -1;
     if (residual) return 2;
     return 0;
 }
@@ -811,6 +812,9 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     ECAMP_CHECK_ARG(A && B && C, "ecamp_gemm: null operand");
     ECAMP_CHECK_ARG(M > 0 && N > 0 && K > 0, "ecamp_gemm: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
     ECAMP_CHECK_ARG(dtype == ECAMP_F32 || dtype == ECAMP_BF16, "ecamp_gemm: bad dtype %d", dtype);
+    ECAMP_CHECK_ARG(act >= 0 && act <= 2, "ecamp_gemm: act=%d (0 none, 1 GELU, 2 GELU with the saved derivative)", act);
+    ECAMP_CHECK_ARG(act != 2 || (dtype == ECAMP_BF16 && !out_f32 && ((pre_out != nullptr) != (gmul != nullptr))),
+                    "ecamp_gemm: act=2 (saved derivative) is the bf16 forward form with pre_out or the data-gradient form with gmul");
     const int vec = dtype == ECAMP_BF16 ? 8 : 4;   // elements per 16-B global access
     const int ovec = dtype == ECAMP_BF16 ? 8 : 4;  // output-contiguous operands are read 16 B at a time
     ECAMP_CHECK_ARG(N % 4 == 0, "ecamp_gemm: N=%ld must be a multiple of 4", (long)N);

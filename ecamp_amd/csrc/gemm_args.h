@@ -15,7 +15,7 @@ struct GemmArgs {
     long ldp;
     const void* gmul;       // T [M, ldg]: multiply result by gelu'(gmul[m,n]) (dgrad through GELU) or null
     long ldg;
-    int act;                // 0 none, 1 exact GELU
+    int act;                // 0 none, 1 exact GELU, 2 exact GELU with the SAVED DERIVATIVE: pre_out receives gelu'(pre) (forward), gmul holds gelu' itself (data gradient)
     int out_f32;            // C is f32 regardless of operand type
     int accumulate;         // C += result (requires an f32 output); exclusive ownership -> plain read-modify-write
     float* rowsum;          // optional f32 [M]: rowsum[m] += alpha * sum_k opA[m,k]  (bias gradient inside the wgrad GEMM)
@@ -76,16 +76,23 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n0, f32x
         float4 b = *reinterpret_cast<const float4*>(g.bias + n0);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if (g.pre_out) st4<T>(reinterpret_cast<T*>(g.pre_out) + (long)m * g.ldp + n0, v);
-    if (g.act == 1) {
+    if (g.act == 2 && g.pre_out) {   // "saved derivative" (bf16 only, host-checked): pre_out receives gelu'(x) of the rounded pre-activation x
+        float d[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_t<T>(g.pre_out ? rnd<T>(v[r]) : v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_both_fast_f(rnd<T>(v[r]), d[r]);
+        st4<T>(reinterpret_cast<T*>(g.pre_out) + (long)m * g.ldp + n0, d);
+    } else {
+        if (g.pre_out) st4<T>(reinterpret_cast<T*>(g.pre_out) + (long)m * g.ldp + n0, v);
+        if (g.act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_t<T>(g.pre_out ? rnd<T>(v[r]) : v[r]);
+        }
     }
     if (g.gmul) {
         float p[4];
         ld4<T>(reinterpret_cast<const T*>(g.gmul) + (long)m * g.ldg + n0, p);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_t<T>(p[r]);
+        for (int r = 0; r < 4; ++r) v[r] *= (g.act == 2 ? p[r] : gelu_grad_t<T>(p[r]));   // act == 2: gmul already holds gelu'
     }
     if (g.residual) {
         float p[4];

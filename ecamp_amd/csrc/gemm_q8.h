@@ -591,11 +591,23 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                     for (int r = 0; r < 8; ++r) v[r] += bias[gq][r];
                 }
                 if (EPI == 1) {
+                    if (g.act == 2) {   // saved derivative: the second output is gelu'(x), not x (uniform branch)
+                        float d_[8];
+#pragma unroll
+                        for (int r = 0; r < 8; r += 2) {
+                            f32x2_t g_;
+                            const f32x2_t y_ = gelu_both_fast_f2((f32x2_t){rnd<bf16_t>(v[r]), rnd<bf16_t>(v[r + 1])}, g_);
+                            v[r] = y_[0]; v[r + 1] = y_[1];
+                            d_[r] = g_[0]; d_[r + 1] = g_[1];
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(d_), rP, up[tm][gq], 0, ST_AUX);
+                    } else {
                     __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rP, up[tm][gq], 0, ST_AUX);
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) {   // pair form: packed math (common.h)
                         const f32x2_t y_ = gelu_fast_f2((f32x2_t){rnd<bf16_t>(v[r]), rnd<bf16_t>(v[r + 1])});
                         v[r] = y_[0]; v[r + 1] = y_[1];
+                    }
                     }
                     if (F8 && g.q8_out) {
                         float u[8];
@@ -616,7 +628,8 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                 if (EPI == 3) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const f32x2_t gp_ = gelu_grad_fast_f2((f32x2_t){__uint_as_float(qg[tm][gq][r] << 16), __uint_as_float(qg[tm][gq][r] & 0xffff0000u)});
+                        const f32x2_t lg_ = {__uint_as_float(qg[tm][gq][r] << 16), __uint_as_float(qg[tm][gq][r] & 0xffff0000u)};
+                        const f32x2_t gp_ = g.act == 2 ? lg_ : gelu_grad_fast_f2(lg_);   // act == 2: the forward pass saved gelu' itself (uniform branch)
                         v[2 * r] *= gp_[0];
                         v[2 * r + 1] *= gp_[1];
                     }

@@ -181,7 +181,7 @@ class VitBlockFn(torch.autograd.Function):
         a = a.view(B * T, D)
         x1 = _vit_linear(m, a, blk.attn.proj, residual=x)
         h2, _, mean2, rstd2, h28 = _ln_q8(m, x1, blk.norm2, blk.mlp.fc1.weight)
-        u, pre, u8 = _vit_linear(m, h2, blk.mlp.fc1, x8=h28, next_w=blk.mlp.fc2.weight, act=1, save_pre=True)
+        u, pre, u8 = _vit_linear(m, h2, blk.mlp.fc1, x8=h28, next_w=blk.mlp.fc2.weight, act=m.gelu_act, save_pre=True)   # (act 2: `pre` holds gelu')
         x2 = _vit_linear(m, u, blk.mlp.fc2, x8=u8, residual=x1)
         ctx.s = (x, mean1, rstd1, h, qkv, a, lse, x1, mean2, rstd2, h2, pre, u)
         ctx.cfg = (blk, m, B, T, heads)
@@ -207,7 +207,7 @@ class VitBlockFn(torch.autograd.Function):
         x, mean1, rstd1, h, qkv, a, lse, x1, mean2, rstd2, h2, pre, u = ctx.s
         blk, m, B, T, heads = ctx.cfg
         _wgrad(A, dx2, u, fc2.weight, gb=G(fc2.bias))
-        dpre = ops.linear_dgrad(dx2, A.w(fc2.weight), gmul=pre)
+        dpre = ops.linear_dgrad(dx2, A.w(fc2.weight), gmul=pre, gmul_is_grad=m.gelu_act == 2)
         _wgrad(A, dpre, h2, fc1.weight, gb=G(fc1.bias))
         dh2 = ops.linear_dgrad(dpre, A.w(fc1.weight))
         dx1 = ops.layernorm_bwd(dh2, x1, mean2, rstd2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), dres=dx2)
@@ -492,7 +492,7 @@ def _self_attn_bwd(m, rec, dout, B, S, key_mask, pa, ph):
 def _ffn_fwd(m, inter, out, x, ph, tape, x8=None):
     """BertIntermediate + BertOutput: LN(dropout(W2 gelu(W1 x)) + x)."""
     A = m.arena
-    u, pre, u8 = _dense(m, x, inter.dense.weight, inter.dense.bias.data, x8=x8, next_w=out.dense.weight, act=1, save_pre=True)
+    u, pre, u8 = _dense(m, x, inter.dense.weight, inter.dense.bias.data, x8=x8, next_w=out.dense.weight, act=m.gelu_act, save_pre=True)
     y = _dense(m, u, out.dense.weight, out.dense.bias.data, x8=u8)
     s, o = m.next_rng()
     ln = out.LayerNorm
@@ -511,7 +511,7 @@ def _ffn_bwd(m, rec, dout, ph):
     else:
         dz = dy = ops.layernorm_bwd(dout, z, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
     _wgrad(A, dy, u, out.dense.weight, gb=G(out.dense.bias))
-    dpre = ops.linear_dgrad(dy, A.w(out.dense.weight), gmul=pre)
+    dpre = ops.linear_dgrad(dy, A.w(out.dense.weight), gmul=pre, gmul_is_grad=m.gelu_act == 2)
     _wgrad(A, dpre, x, inter.dense.weight, gb=G(inter.dense.bias))
     dx = ops.linear_dgrad(dpre, A.w(inter.dense.weight), residual=dz)
     A.ready(ln.weight, ln.bias, out.dense.weight, out.dense.bias, inter.dense.weight, inter.dense.bias)

@@ -128,13 +128,15 @@ def linear_fwd_fp8(x, w8, w_scale, bias=None, act=0, residual=None, save_pre=Fal
     return (y, pre) if save_pre else y
 
 
-def linear_dgrad(dy, w, gmul=None, alpha=1.0, alpha_dev=None, residual=None):
-    """dx = alpha * (dy @ w) [* gelu'(gmul)] [+ residual];  dy [M,N], w [N,K]."""
+def linear_dgrad(dy, w, gmul=None, alpha=1.0, alpha_dev=None, residual=None, gmul_is_grad=False):
+    """dx = alpha * (dy @ w) [* gelu'(gmul)] [+ residual];  dy [M,N], w [N,K].  gmul_is_grad: `gmul` is what a forward with act=2 saved,
+    gelu' itself (ecamp_gemm act = 2), and multiplies the result as it is."""
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
     gemm(dy, w, dx, M, K, N, True, dy.stride(0), False, w.stride(0), K, gmul=gmul, ldg=gmul.stride(0) if gmul is not None else 0,
-         residual=residual, ldr=residual.stride(0) if residual is not None else 0, alpha=alpha, alpha_dev=alpha_dev)
+         residual=residual, ldr=residual.stride(0) if residual is not None else 0, alpha=alpha, alpha_dev=alpha_dev,
+         act=2 if (gmul_is_grad and gmul is not None) else 0)
     return dx
 
 

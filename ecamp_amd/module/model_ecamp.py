@@ -95,6 +95,10 @@ class ECAMP(nn.Module):
         self.fp8_forward = bool(fp8_forward)
         # fp8_forward also covers the MLM head (transform dense + vocabulary decoder) when set; ECAMP_FP8_HEAD=0/1 overrides the default
         self.fp8_head = os.environ.get("ECAMP_FP8_HEAD", "0") != "0"
+        # GELU of the MLP / FFN blocks (timm Mlp.act, HF BertIntermediate): 2 = the fc1 epilogue saves gelu'(pre-activation) instead of the
+        # pre-activation and the fc2 data gradient multiplies by it (no erf / exp in the backward pass; one more bf16 rounding of the
+        # derivative); 1 = save the pre-activation and recompute gelu' in the backward epilogue.  bf16 mode only; ECAMP_GELU_SAVED_GRAD=0 -> 1.
+        self.gelu_act = 2 if (compute_dtype == torch.bfloat16 and os.environ.get("ECAMP_GELU_SAVED_GRAD", "1") != "0") else 1
         self.bert_config = bert_config if bert_config is not None else BertConfig()
         # image encoder (model_ecamp.py:58-69)
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)

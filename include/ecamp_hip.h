@@ -32,7 +32,11 @@ const char* ecamp_last_error(void);
  * qkv/proj/fc1/fc2 (:66-68,80-82,233-234,254-255), decoder_embed/pred (:74,85,242,259), bert_mlp (:99,268), HF
  * Bert* dense layers (bert_modeling.py:113-131, context_fusion.py:32-72), MLM decoder (bert_modeling.py:209), and
  * their autograd dgrad/wgrad.  Epilogue: +bias[n]; save pre-activation; exact-erf GELU; *gelu'(gmul[m,n]);
- * +residual[m,n].  out_f32/accumulate: f32 output added into C (weight gradients).  split_k > 1: the contraction is cut
+ * +residual[m,n].  act: 0 none; 1 GELU (pre_out, if given, receives the pre-activation; gmul holds a pre-activation and the
+ * result is multiplied by gelu'(gmul)); 2 (bf16 only) GELU with the SAVED DERIVATIVE: pre_out receives gelu'(pre-activation)
+ * and, in the data-gradient call, gmul holds that derivative and multiplies the result as it is -- torch's GeluBackward
+ * (nn.GELU at timm Mlp.act / HF BertIntermediate.intermediate_act_fn) without erf / exp in the backward pass, at the price of
+ * one more bf16 rounding of the derivative.  out_f32/accumulate: f32 output added into C (weight gradients).  split_k > 1: the contraction is cut
  * into slabs written to `splitk_ws` (split_k*M*N floats) and combined by a deterministic reduce kernel (no atomics).
  * rowsum (optional, f32 [M]): rowsum[m] += alpha * sum_k opA[m,k] -- the bias gradient, computed inside the wgrad GEMM from the
  * M-side fragments it already holds (v_dot2c_f32_bf16 sums placed between the MFMAs) instead of a separate pass over dY. */
@@ -89,7 +93,7 @@ int ecamp_set_option(const char* name, int32_t value);
  * reference runs these nn.Linear layers under torch.cuda.amp, main_pretrain.py:138).  Per-tensor scaling, OCP e4m3:
  *   ecamp_amax      out[0] = max(out[0], max|x|)               (caller zeroes out[0]; n % 4 == 0)
  *   ecamp_quant_fp8 scale_out[0] = max(amax[0], tiny) / 448;  q[i] = e4m3(clamp(x[i] / scale, +-448))   (one byte per element)
- *   ecamp_gemm_fp8  C[M,N] (bf16) = act((A8[M,K] . B8[N,K]^T) * scale_a[0] * scale_b[0] + bias) (+ residual); act 0 none, 1 exact GELU
+ *   ecamp_gemm_fp8  C[M,N] (bf16) = act((A8[M,K] . B8[N,K]^T) * scale_a[0] * scale_b[0] + bias) (+ residual); act 0 none, 1 exact GELU, 2 exact GELU with gelu'(pre-activation) saved to pre_out (see ecamp_gemm),
  *                   with the bf16 pre-activation saved to pre_out -- the forward of timm Attention.qkv / proj and Mlp.fc1 / fc2
  *                   (call sites model_ecamp.py:233-234, 254-255).  K, lda, ldb multiples of 16 bytes.  f32 accumulation on
  *                   v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales. */
@@ -114,7 +118,7 @@ int ecamp_quant_fp8(const void* x, const float* amax, void* q, float* scale_out,
 int ecamp_gemm_fp8(const void* A8, const void* B8, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    const float* scale_a, const float* scale_b, const float* bias, const void* residual, int64_t ldr, void* pre_out,
                    int64_t ldp, int act, void* q8_out, const float* q8_scale, float* q8_amax_slots, ecampStream_t stream);
-/* q8_out (nullable; needs act = 1, pre_out, no residual, ldc = N): also leave the e4m3 copy of C for the NEXT dense layer (timm Mlp.fc2 /
+/* q8_out (nullable; needs act = 1 or 2, pre_out, no residual, ldc = N): also leave the e4m3 copy of C for the NEXT dense layer (timm Mlp.fc2 /
  * BertOutput.dense behind the GELU), quantised with that layer's input scale q8_scale[0], and max|C| in its amax slots -- the fp8
  * forward's quantisation folded into the epilogue that produces the activation (ecamp_quant_fp8_delayed's conventions). */
 

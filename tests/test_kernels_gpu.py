@@ -63,6 +63,36 @@ def test_gemm_fwd_epilogues(dev, dtype, M, N, K):
         check("linear f32-out", y32, x @ w.T + b, 2e-3)
 
 
+@pytest.mark.parametrize("M,N,K,q8", [(394, 768, 192, 0), (1000, 520, 200, 2), (512, 3072, 768, 2), (512, 3072, 768, 0)])
+def test_gemm_gelu_saved_derivative(dev, M, N, K, q8):
+    """ecamp_gemm act = 2 (bf16): the GELU epilogue leaves gelu'(pre-activation) in `pre_out` instead of the pre-activation, and the
+    data-gradient form multiplies by what it is handed -- torch's GeluBackward (nn.GELU at timm Mlp.act / HF BertIntermediate) split
+    over the two epilogues.  Both kernel families (128^2 and the persistent one); y is bit-identical to the act = 1 result, the saved
+    derivative is gelu' of the ROUNDED pre-activation to one bf16 rounding, and the two-step gradient equals the one-step (act = 1)
+    gradient to bf16 accuracy."""
+    o = ops()
+    dt = torch.bfloat16
+    x, w, b = rnd(gen(M, K, seed=1), dt), rnd(gen(N, K, seed=2, scale=K ** -0.5), dt), gen(N, seed=3)
+    dy, w2 = rnd(gen(M, 256, seed=5), dt), rnd(gen(256, N, seed=6, scale=256 ** -0.5), dt)   # the next layer: [M,256] = gelu(..)[M,N] @ w2^T
+    xd, wd, bd, dyd, w2d = x.to(dev, dt), w.to(dev, dt), b.to(dev), dy.to(dev, dt), w2.to(dev, dt)
+    try:
+        o.set_option("q8_mode", q8)
+        y1, pre = o.linear_fwd(xd, wd, bd, act=1, save_pre=True)
+        y2, der = o.linear_fwd(xd, wd, bd, act=2, save_pre=True)
+        assert torch.equal(y1, y2), "the activation must not depend on what is saved beside it"
+        pr = pre.float().cpu().requires_grad_(True)
+        F.gelu(pr).sum().backward()
+        check("saved gelu'", der, pr.grad, 2.0 ** -8)          # one bf16 rounding of a value in [-0.13, 1.13]
+        d1 = o.linear_dgrad(dyd, w2d, gmul=pre)
+        d2 = o.linear_dgrad(dyd, w2d, gmul=der, gmul_is_grad=True)
+        check("dgrad * saved gelu' vs dgrad * gelu'(pre)", d2, d1.float(), 2.0 ** -7)
+        check("dgrad * saved gelu' vs autograd", d2, (dy.float() @ w2.float()) * pr.grad, TOL[dt])
+        with pytest.raises(RuntimeError):
+            o.linear_fwd(xd.float(), wd.float(), bd, act=2, save_pre=True)   # bf16 only
+    finally:
+        o.set_option("q8_mode", -1)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 3072, 768), (256, 30000, 768)])
 def test_gemm_dgrad_wgrad(dev, dtype, M, N, K):
