@@ -34,4 +34,10 @@ for rep in range(2):
         _, der = o.linear_fwd(x, w1, b1, act=2, save_pre=True)
         t = [timeit(lambda: o.linear_fwd(x, w1, b1)), timeit(lambda: o.linear_fwd(x, w1, b1, act=1, save_pre=True)), timeit(lambda: o.linear_fwd(x, w1, b1, act=2, save_pre=True)),
              timeit(lambda: o.linear_dgrad(dy, w2)), timeit(lambda: o.linear_dgrad(dy, w2, gmul=pre)), timeit(lambda: o.linear_dgrad(dy, w2, gmul=der, gmul_is_grad=True))]
+        u = torch.randn(M, Hd, generator=g).to(dev, torch.bfloat16)
+        b2 = torch.randn(D, generator=g).to(dev)
+        dpre = torch.randn(M, Hd, generator=g).to(dev, torch.bfloat16)
+        t2 = [timeit(lambda: o.linear_fwd(u, w2, b2)), timeit(lambda: o.linear_fwd(u, w2, b2, residual=x)),
+              timeit(lambda: o.linear_dgrad(dpre, w1)), timeit(lambda: o.linear_dgrad(dpre, w1, residual=x))]
+        print("%-5s fc2 fwd: plain %6.1f  + residual %6.1f us   |  fc1 dgrad: plain %6.1f  + residual %6.1f us" % ((name,) + tuple(t2)), flush=True)
         print("%-5s fc1 fwd: plain %6.1f  gelu+pre %6.1f  gelu+gelu' %6.1f us   |  fc2 dgrad: plain %6.1f  * gelu'(pre) %6.1f  * saved gelu' %6.1f us" % ((name,) + tuple(t)), flush=True)
