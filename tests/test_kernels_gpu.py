@@ -900,6 +900,12 @@ def test_gemm_fp8_persistent_kernel_forced_on_ragged_shapes(dev, M, N, K):
         assert torch.equal(y8, o.quantize_fp8_site(y, sc, sl0, True))
         assert sl.view(16, 32)[:, 0].max().item() == y.float().abs().max().item()
         assert lib.ecamp_gemm_f8_q8_launches() - n0 == 5
+        # act = 2, the saved derivative: same activation and e4m3 copy, gelu'(rounded pre-activation) where the pre-activation was
+        y3, der, y83 = o.gemm_fp8(xq, xs, w8, ws, bd, act=2, save_pre=True, q8_site=(sc, torch.zeros(512, device=dev)))
+        assert torch.equal(y3, y) and torch.equal(y83, y8)
+        pr = pre.float().cpu().requires_grad_(True)
+        F.gelu(pr).sum().backward()
+        check("fp8 q8 saved gelu'", der, pr.grad, 2.0 ** -8)
     finally:
         o.set_option("q8_mode", -1)
 
