@@ -796,6 +796,11 @@ def test_gemm_full_size_kernels_agree(dev):
     for mode in (0, 8):   # 128^2 kernel, persistent 256^2 kernel (Q8)
         o.set_option("q8_mode", 2 if mode == 8 else 0)
         y, pre = o.linear_fwd(x, w, b, act=1, save_pre=True)
+        y2, der = o.linear_fwd(x, w, b, act=2, save_pre=True)   # the production form: gelu' saved in place of the pre-activation
+        assert torch.equal(y, y2)
+        pr = pre[::97].float().requires_grad_(True)
+        F.gelu(pr).sum().backward()
+        assert float((der[::97].float() - pr.grad).abs().max()) <= 2.0 ** -8 * 1.13 + 1e-6, "saved gelu' (mode %d)" % mode
         dx = o.linear_dgrad(dy, w)
         gw, gb = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
         o.linear_wgrad(dy, x, gw, gb=gb)
