@@ -244,7 +244,7 @@ def main():
     from ecamp_amd import _lib, optim
     from ecamp_amd.data import synthetic_batch
     from ecamp_amd.module import model_ecamp
-    from ecamp_amd.parallel import DistributedDataParallel, rccl_env_record
+    from ecamp_amd.parallel import DistributedDataParallel, ddp_defaults, rccl_env_record
     from ecamp_amd.util.misc import NativeScalerWithGradNormCount
 
     torch.manual_seed(42 + rank)  # main_pretrain.py:189
@@ -304,11 +304,12 @@ def main():
                 "payload_mb_per_step": round(red.payload_bytes() / 2 ** 20, 1), "payload_dtype": "bf16" if red.grad_dtype is not None else "f32",
                 "op": "AVG" if red.use_avg else "SUM+div",
                 "tail_bucket_mb": round((red.buckets[-1][1] - red.buckets[-1][0]) * 4 / 2 ** 20, 1),
-                "p8_wgrad_reserve_cus": int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")),
-                "q8_bwd_grid": int(os.environ.get("ECAMP_DDP_Q8_BWD_GRID", str(1 << 20))),
+                "p8_wgrad_reserve_cus": ddp_defaults()["p8_wgrad_reserve_cus"], "q8_bwd_grid": ddp_defaults()["q8_bwd_grid"],
+                "bucketwise_adamw": ddp_defaults()["bucketwise_adamw"],
                 "allreduce_ms_per_step": round(red.comm_ms() / args.steps, 3),
                 "channels": rccl_env_record(rccl_log),
-                "adamw": "bucket by bucket behind each bucket's all-reduce (%d of %d optimizer steps)" % (opt.bucketwise_steps, opt._step),
+                "adamw": "%d of %d optimizer steps ran bucket by bucket behind each bucket's all-reduce (ECAMP_BUCKETWISE_ADAMW; the rest: one pass "
+                         "after the last all-reduce)" % (opt.bucketwise_steps, opt._step),
                 "note": "all-reduce of the f32 gradient arena in buckets on a side HIP stream, overlapped with backward; ms = sum of the "
                         "buckets' event-bracketed durations on that stream on rank 0 (they overlap compute, so this is not added step time)"}
         red.timing = False
@@ -343,8 +344,20 @@ def main():
             net.set_grad_sync(True)
         opt.zero_grad()
 
+    def run_vit(n):   # the image side alone: stem -> encoder -> decoder -> image losses, forward + backward (the north-star's 40 % scope)
+        if hasattr(net, "set_grad_sync"):
+            net.set_grad_sync(False)
+        for _ in range(n):
+            mim, res, _ = model(batch, image_side_only=True)
+            (mim + res).backward()
+        if hasattr(net, "set_grad_sync"):
+            net.set_grad_sync(True)
+        opt.zero_grad()
+
     dt_fwd = timed(run_fwd, side_n) / side_n
     dt_fb = timed(run_fwd_bwd, side_n) / side_n
+    run_vit(1)
+    dt_vit = timed(run_vit, side_n) / side_n
     losses = [float(t.detach()) for t in out[:3]]
     # Roofline pass (not part of `value`): the same step, with the weight-gradient GEMMs back on the main stream so that every
     # launch runs alone and its HIP-event duration is its own (in the timed region above they overlap the dgrad chain on a side
@@ -370,9 +383,9 @@ def main():
             hip_ops.OVERLAP_WGRAD = wgrad
             hip_ops.OVERLAP_BRANCHES = branches
     if world > 1:
-        t = torch.tensor([dt, dt_res, dt_fwd, dt_fb], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, dt_res, dt_fwd, dt_fb, dt_vit], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_res, dt_fwd, dt_fb = (float(x) for x in t.tolist())
+        dt, dt_res, dt_fwd, dt_fb, dt_vit = (float(x) for x in t.tolist())
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -390,6 +403,14 @@ def main():
                "resident_pairs_per_s": round(args.batch * world / dt_res, 2), "resident_ms_per_step": round(1e3 * dt_res, 3),
                "fwd_only_ms": round(1e3 * dt_fwd, 3), "fwd_only_pairs_per_s": round(args.batch * world / dt_fwd, 2),
                "fwd_bwd_ms": round(1e3 * dt_fb, 3), "fwd_bwd_pairs_per_s": round(args.batch * world / dt_fb, 2)}
+        # the north-star's ">= 40 % MFMA roofline on the ViT-B/16 forward+backward at bs=256/GPU" in its own scope: the image side alone
+        # (model_ecamp.py:218-264,276-300), 7.154 GMAC forward per image x 2 FLOP x 3 (fwd + dgrad + wgrad) = 42.92 GFLOP per image
+        # (SURVEY.md 8(d)); production stream layout (weight gradients on the side stream), inputs resident
+        if args.seq in (128, 256) and args.dtype == "bf16":
+            vit_tf = 42.92e9 * args.batch / dt_vit / 1e12
+            res.update({"vit_fwd_bwd_ms": round(1e3 * dt_vit, 3), "vit_tflops": round(vit_tf, 2), "vit_frac": round(vit_tf / PEAK_BF16_TFLOPS, 4),
+                        "vit_note": "image side only (stem, 12 encoder blocks, decoder, SR head, image losses), forward + backward, per GPU: "
+                                    "42.92 GFLOP per image (SURVEY.md 8(d)) x pairs_per_gpu / vit_fwd_bwd_ms against the 2.5 PF dense bf16 peak"})
         if rccl is not None:
             res["rccl"] = rccl
         if not args.no_prof:
@@ -400,16 +421,26 @@ def main():
             lib.ecamp_prof_collect(2, ctypes.byref(ams), ctypes.byref(afl), ctypes.byref(an))
             ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-            # HBM-side traffic per GEMM launch: not measurable from inside this process -- taken from the committed PMC passes of this
-            # very command (profiles/r04_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); null if absent
+            # HBM-side traffic per GEMM launch: not measurable from inside this process -- taken from the newest committed PMC passes of
+            # this very command (profiles/rNN_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), and only when that
+            # file is stamped with the hash of the GEMM sources this library was built from; otherwise null (never last round's number)
             traffic, traffic_src = None, None
-            tj = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-            if args.dtype == "bf16" and args.batch == 256 and args.seq == 128 and os.path.exists(tj):
-                try:
-                    traffic = round(json.load(open(tj))["gemm_traffic_bytes_per_launch"])
-                    traffic_src = "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per GEMM launch)"
-                except Exception:
-                    traffic = None
+            if args.dtype == "bf16" and args.batch == 256 and args.seq == 128:
+                import glob
+                from ecamp_amd.build import gemm_source_hash
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+                if cands:
+                    tj = cands[-1]
+                    try:
+                        rec = json.load(open(tj))
+                        if rec.get("gemm_source_sha256") == gemm_source_hash():
+                            traffic = round(rec["gemm_traffic_bytes_per_launch"])
+                            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per GEMM launch; stamped with this build's GEMM source hash)" % os.path.basename(tj)
+                        else:
+                            traffic_src = ("profiles/%s was collected on other GEMM sources (hash mismatch): not quoted -- re-run tools/pmc_traffic.sh"
+                                           % os.path.basename(tj))
+                    except Exception:
+                        traffic = None
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": "gemm_bf16_q8_kernel + gemm_bf16_kernel (bf16 GEMM family)" if args.dtype == "bf16" else "gemm_f32_kernel",

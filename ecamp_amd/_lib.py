@@ -42,6 +42,13 @@ def parse_header(path=HEADER):
     return protos
 
 
+def abi_version_of_header(path=HEADER):
+    m = re.search(r"#define\s+ECAMP_ABI_VERSION\s+(\d+)", open(path).read())
+    if m is None:
+        raise EcampHipError("include/ecamp_hip.h does not define ECAMP_ABI_VERSION")
+    return int(m.group(1))
+
+
 _lib = None
 _protos = None
 
@@ -61,8 +68,12 @@ def load():
         fn = getattr(lib, name)  # raises AttributeError if the symbol is not exported
         fn.restype = ret
         fn.argtypes = [a[0] for a in args]
-    if lib.ecamp_abi_version() != 1:
-        raise EcampHipError("ABI version mismatch")
+    want = abi_version_of_header()
+    got = lib.ecamp_abi_version()
+    if got != want:
+        raise EcampHipError("ABI version mismatch: %s was built for version %d, include/ecamp_hip.h declares %d -- rebuild "
+                            "(`python -m ecamp_amd.build`); an older build must not be called with this header's argument lists"
+                            % (LIB_PATH, got, want))
     _lib = lib
     return lib
 

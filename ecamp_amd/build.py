@@ -18,6 +18,17 @@ LIB = os.path.join(HERE, "libecamp_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-result"]
 
 
+def gemm_source_hash():
+    """sha256 over the sources of the GEMM family (csrc/gemm.hip, gemm_q8.h, gemm_args.h): the identity `profiles/rNN_pmc_traffic.json`
+    is stamped with (tools/pmc_traffic.py) and bench.py checks before it quotes that file's bytes per GEMM launch as `roofline.traffic`
+    -- a PMC pass of OTHER kernels must read as "not measured", not as last round's number."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "gemm_q8.h", "gemm_args.h"):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -32,6 +43,7 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "ecamp_hip.h"))   # core.hip takes ECAMP_ABI_VERSION from it
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)

@@ -1082,6 +1082,8 @@ static void lds_optin(K kern, size_t bytes) {
     } while (0)
 #define LDS_MAX (160 * 1024)
 // ECAMP_ATTN_HEAD=0 keeps the 64-row streaming kernels (A/B measurements)
+static long g_head_launches = 0;   // development ABI: launches of the head-resident kernels so far (tests assert that they really ran)
+extern "C" int64_t ecamp_attn_head_launches(void) { return g_head_launches; }
 static int g_head_mode = -1;   // ecamp_set_option("attn_head", v): -1 = the environment decides
 void attn_set_head_mode(int on) { g_head_mode = on < 0 ? -1 : (on ? 1 : 0); }
 static bool head_enabled() {
@@ -1103,6 +1105,7 @@ static bool head_fwd(const AttnArgs& a, hipStream_t st) {
     const int nw = head_waves((a.Tq + 15) / 16, 8);
     if (a.key_mask != nullptr || a.drop_p > 0.f) LAUNCH_H((attn_head_fwd_kernel<HD, 1>), grid, nw * 64, shm, st, a);
     else LAUNCH_H((attn_head_fwd_kernel<HD, 0>), grid, nw * 64, shm, st, a);
+    ++g_head_launches;
     return true;
 }
 template <int HD>
@@ -1117,6 +1120,7 @@ static bool head_bwd(const AttnArgs& a, hipStream_t st) {
     const int nw = head_waves(nkt > nqt ? nkt : nqt, 4);
     if (a.key_mask != nullptr || a.drop_p > 0.f) LAUNCH_H((attn_head_bwd_kernel<HD, 1>), grid, nw * 64, shm, st, a);
     else LAUNCH_H((attn_head_bwd_kernel<HD, 0>), grid, nw * 64, shm, st, a);
+    ++g_head_launches;
     return true;
 }
 template <int HD>

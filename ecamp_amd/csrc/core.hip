@@ -1,5 +1,6 @@
 // Error reporting + ABI version for libecamp_hip.so
 #include "common.h"
+#include "../../include/ecamp_hip.h"
 #include <stdarg.h>
 
 thread_local char g_ecamp_err[512] = {0};
@@ -13,7 +14,7 @@ int ecamp_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* ecamp_last_error(void) { return g_ecamp_err; }
-extern "C" int ecamp_abi_version(void) { return 1; }
+extern "C" int ecamp_abi_version(void) { return ECAMP_ABI_VERSION; }
 
 // Development aid (tools/hog_probe.py): `blocks` workgroups that spin for `cycles` shader clocks -- a stand-in for a communication
 // kernel (RCCL all-reduce) that shares the GPU with the training step on another stream.

@@ -228,6 +228,24 @@ extern "C" int ecamp_seq_bcast(const void* g, void* y, int64_t B, int32_t S, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// development ABI (tests only): the dropout keep-mask every kernel of this library derives from (seed, offset) -- element e of the
+// flattened tensor is kept iff word (e & 3) of Philox(counter e >> 2) maps to u >= p (dropout_scale, common.h) -- materialised as one
+// byte per element, so that a test or the oracle can replay the SAME mask in plain PyTorch (attention probabilities: e = ((b * H + h)
+// * Tq + i) * Tk + j; LayerNorm / embedding dropout: e = row * cols + col)
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, float p, uint64_t seed, uint64_t offset) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        keep[e] = dropout_scale(seed, offset, (uint64_t)e, p, 1.0f) != 0.0f ? 1 : 0;
+}
+extern "C" int ecamp_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, hipStream_t stream) {
+    ECAMP_CHECK_ARG(keep && n > 0 && p >= 0.f && p < 1.f, "ecamp_dropout_mask: bad args");
+    int nb = (int)((n + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(nb), dim3(256), 0, stream, keep, (long)n, p, seed, offset);
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // uniform [0,1) noise for MAE masking (stands in for torch.rand(N, L), model_ecamp.py:177)
 __global__ void uniform_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t offset) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < n; i += (long)gridDim.x * blockDim.x) {

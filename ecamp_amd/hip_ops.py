@@ -361,6 +361,14 @@ def seq_bcast(g, y, s0, s1, scale, mode):
     return y
 
 
+def dropout_mask(shape, device, p, seed, offset):
+    """Development ABI: the keep-mask (uint8, 1 = kept) of a tensor of `shape` under dropout(p) keyed by (seed, offset) -- what the
+    LayerNorm / embedding / attention kernels regenerate from the same pair (element index = flat index of the contiguous tensor)."""
+    out = torch.empty(shape, device=device, dtype=torch.uint8)
+    call("ecamp_dropout_mask", ptr(out), out.numel(), float(p), seed, offset, stream())
+    return out
+
+
 def uniform(shape, device, seed, offset):
     out = torch.empty(shape, device=device, dtype=torch.float32)
     call("ecamp_uniform", ptr(out), out.numel(), seed, offset, stream())

@@ -71,6 +71,9 @@ def get_args_parser():
     p.add_argument("--dist_url", default="env://")
     # additions of this implementation
     p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--gelu_saved_grad", default=1, type=int, choices=[0, 1], help="bf16 mode: 1 = the fc1 / BertIntermediate epilogue saves gelu'(x) "
+                   "for the backward pass (no erf in backward; one more bf16 rounding of the derivative), 0 = save x and recompute gelu' in f32 like "
+                   "the reference's GeluBackward")
     p.add_argument("--max_caption_length", default=256, type=int)
     p.add_argument("--synthetic", action="store_true", help="train on the synthetic stand-in dataset (random images and tokens) instead "
                    "of <data_path>/mimic-cxr-2.0.0-entity-llm.csv; without this flag a missing CSV is an error, as in the reference")
@@ -135,7 +138,7 @@ def main(args):
                                    pin_memory=args.pin_mem, drop_last=True, collate_fn=dataset_train.collate_fn)
 
     dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
-    model = model_ecamp.__dict__[args.model](norm_pix_loss=args.norm_pix_loss, compute_dtype=dtype)
+    model = model_ecamp.__dict__[args.model](norm_pix_loss=args.norm_pix_loss, compute_dtype=dtype, gelu_saved_grad=bool(args.gelu_saved_grad))
     model.to(device)
     model_without_ddp = model
     print("Model = %s" % str(model_without_ddp))

@@ -76,7 +76,7 @@ class InterpolateConvSuperResolution(nn.Module):
 class ECAMP(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=768,
                  decoder_depth=4, decoder_num_heads=6, mlp_ratio=4.0, norm_layer=nn.LayerNorm, norm_pix_loss=False,
-                 bert_config=None, compute_dtype=torch.bfloat16, sr_window=None, fp8_forward=False):
+                 bert_config=None, compute_dtype=torch.bfloat16, sr_window=None, fp8_forward=False, gelu_saved_grad=None):
         super().__init__()
         if in_chans != 3 or patch_size % 4 != 0:
             raise ValueError("in_chans must be 3 and patch_size a multiple of 4")
@@ -97,8 +97,14 @@ class ECAMP(nn.Module):
         self.fp8_head = os.environ.get("ECAMP_FP8_HEAD", "0") != "0"
         # GELU of the MLP / FFN blocks (timm Mlp.act, HF BertIntermediate): 2 = the fc1 epilogue saves gelu'(pre-activation) instead of the
         # pre-activation and the fc2 data gradient multiplies by it (no erf / exp in the backward pass; one more bf16 rounding of the
-        # derivative); 1 = save the pre-activation and recompute gelu' in the backward epilogue.  bf16 mode only; ECAMP_GELU_SAVED_GRAD=0 -> 1.
-        self.gelu_act = 2 if (compute_dtype == torch.bfloat16 and os.environ.get("ECAMP_GELU_SAVED_GRAD", "1") != "0") else 1
+        # derivative -- a departure from the reference's GeluBackward, which recomputes gelu' in f32 from the pre-activation; drift over 200
+        # steps 2.3e-5, profiles/r04_gelu_saved_grad_drift.json); 1 = save the pre-activation and recompute gelu' in the backward epilogue.
+        # bf16 mode only.  A constructor argument (`gelu_saved_grad`, main_pretrain.py --gelu_saved_grad, recorded in config.yaml); None =
+        # the environment's ECAMP_GELU_SAVED_GRAD, default on.
+        if gelu_saved_grad is None:
+            gelu_saved_grad = os.environ.get("ECAMP_GELU_SAVED_GRAD", "1") != "0"
+        self.gelu_saved_grad = bool(gelu_saved_grad) and compute_dtype == torch.bfloat16
+        self.gelu_act = 2 if self.gelu_saved_grad else 1
         self.bert_config = bert_config if bert_config is not None else BertConfig()
         # image encoder (model_ecamp.py:58-69)
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
@@ -130,6 +136,7 @@ class ECAMP(nn.Module):
         self._aux_logits = None
         self._rng_seed = None
         self._rng_ctr = 0
+        self._rng_trace = None
         self._norm_cache = {}
         self._register_load_state_dict_pre_hook(self._alias_old_keys)
         self.register_load_state_dict_post_hook(lambda mod, inc: mod.arena.sync_shadow() if mod.arena is not None else None)
@@ -198,7 +205,11 @@ class ECAMP(nn.Module):
             self.arena.sync_shadow()
 
     def next_rng(self):
+        """(seed, offset) of the next Philox stream (masking noise, or one dropout site).  `_rng_trace` (a list, tests only) records the
+        pairs in call order: the oracle replays the same masks through the development ABI `ecamp_dropout_mask`."""
         self._rng_ctr += 1
+        if self._rng_trace is not None:
+            self._rng_trace.append((self._rng_seed, self._rng_ctr))
         return self._rng_seed, self._rng_ctr
 
     def _loss_norm(self, n1, n2, dev):
@@ -308,9 +319,11 @@ class ECAMP(nn.Module):
         out = self.bert_encoder(lat, gap, caption_ids, labels, attention_mask, token_type_ids, weights, self, B, T)
         return out.loss
 
-    def forward(self, batch, mask_ratio=0.75, noise=None):
+    def forward(self, batch, mask_ratio=0.75, noise=None, image_side_only=False):
         """batch: dict with the schema of pretrain_datasets.py:228-237 (CPU or device tensors).
-        noise: optional [B, L] masking noise standing in for torch.rand at model_ecamp.py:177 (parity tests)."""
+        noise: optional [B, L] masking noise standing in for torch.rand at model_ecamp.py:177 (parity tests).
+        image_side_only (measurement aid, bench.py `vit_*`): stem -> encoder -> decoder -> image losses (model_ecamp.py:218-264,276-300),
+        i.e. the "ViT-B/16 forward+backward" the north-star target is quoted on, without the report side -> (mim_loss, res_loss, None)."""
         from ..functions import DecStemFn, ImgLossFn, NormFn, StemFn, VitBlockFn
         A = self.prepare()
         dev = A.device
@@ -348,6 +361,9 @@ class ECAMP(nn.Module):
             return ImgLossFn.apply(xd, imgs, big, mask, column, row, self, B)
 
         from .. import hip_ops as ops
+        if image_side_only:
+            img_losses = image_decoder()
+            return img_losses[0], img_losses[1], None
         if ops.OVERLAP_BRANCHES and latent.is_cuda:
             # the two consumers of `latent` on two streams (see hip_ops.branch_stream)
             main, bs = torch.cuda.current_stream(dev), ops.branch_stream(dev)

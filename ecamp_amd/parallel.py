@@ -31,6 +31,18 @@ import torch.nn as nn
 # bench.py prints what was in force.
 RCCL_ENV_DEFAULTS = {"NCCL_MAX_NCHANNELS": "32", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
 
+# Switches that only matter at N > 1.  The two that change WHAT RUNS beside RCCL -- the optimizer bucket by bucket behind each bucket's
+# all-reduce, and the data-gradient GEMMs as one output tile per workgroup -- were tuned against a spinning stand-in kernel
+# (tools/hog_probe.py), never against RCCL with more than one rank (this pool has one GPU per box), so they are OFF until
+# tests/test_rccl_gpu.py has run on a box with two GPUs (it arms itself there and checks both against the plain path, bit for bit):
+# ECAMP_BUCKETWISE_ADAMW=1 / ECAMP_DDP_Q8_BWD_GRID=1048576 switch them on.  The weight-gradient launches' 32-CU reserve is only a
+# smaller grid of the same kernel and stays.
+def ddp_defaults(env=None):
+    env = os.environ if env is None else env
+    return {"bucketwise_adamw": env.get("ECAMP_BUCKETWISE_ADAMW", "0") != "0",
+            "q8_bwd_grid": int(env.get("ECAMP_DDP_Q8_BWD_GRID", "0")),
+            "p8_wgrad_reserve_cus": int(env.get("ECAMP_P8_RESERVE_CUS", "32"))}
+
 
 def rccl_env_defaults(env=None):
     """setdefault() RCCL_ENV_DEFAULTS into `env` (default: this process's environment; call before init_process_group)."""
@@ -292,12 +304,13 @@ class DistributedDataParallel(nn.Module):
             arena.sync_shadow()
             # RCCL's all-reduce workgroups share the CUs with the backward pass, and a persistent one-workgroup-per-CU GEMM
             # whose CU is taken starts that workgroup late and holds its static share of the tiles back (tools/hog_probe.py).
-            # The data-gradient GEMMs (the critical chain) therefore run one output tile per workgroup -- the dispatcher deals
-            # the tiles to whatever CUs are free, however many the collective takes (+0.15 ms per step on a GPU of its own,
-            # tools/grid_ab.sh) -- and the weight-gradient launches of the side stream leave 32 CUs to the communication kernels
+            # The weight-gradient launches of the side stream leave 32 CUs to the communication kernels; opt-in (ddp_defaults):
+            # the data-gradient GEMMs (the critical chain) as one output tile per workgroup -- the dispatcher deals the tiles to
+            # whatever CUs are free, however many the collective takes (+0.15 ms per step on a GPU of its own, tools/grid_ab.sh)
             from . import hip_ops
-            hip_ops.set_option("p8_wgrad_reserve_cus", int(os.environ.get("ECAMP_P8_RESERVE_CUS", "32")))
-            hip_ops.set_option("q8_bwd_grid", int(os.environ.get("ECAMP_DDP_Q8_BWD_GRID", str(1 << 20))))
+            dd = ddp_defaults()
+            hip_ops.set_option("p8_wgrad_reserve_cus", dd["p8_wgrad_reserve_cus"])
+            hip_ops.set_option("q8_bwd_grid", dd["q8_bwd_grid"])
         self.reducer = GradReducer(arena.flat_g, arena.offsets, arena.sizes, arena.unused, bucket_cap_mb, process_group, force_comm,
                                    tail_bucket_mb=tail_bucket_mb, tail_span_mb=tail_span_mb, grad_dtype=grad_dtype)
         arena.on_ready = self.reducer.mark_ready

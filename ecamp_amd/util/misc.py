@@ -252,7 +252,9 @@ def get_grad_norm_(parameters, norm_type=2.0):
     return torch.norm(torch.stack([torch.norm(p.grad.detach(), norm_type).to(device) for p in parameters]), norm_type)
 
 
-_BUCKETWISE_ADAMW = os.environ.get("ECAMP_BUCKETWISE_ADAMW", "1") != "0"   # data parallel: AdamW bucket by bucket behind each bucket's all-reduce
+# data parallel: AdamW bucket by bucket behind each bucket's all-reduce -- opt-in until it has run beside RCCL with two ranks
+# (ecamp_amd/parallel.py ddp_defaults; tests/test_rccl_gpu.py)
+_BUCKETWISE_ADAMW = os.environ.get("ECAMP_BUCKETWISE_ADAMW", "0") != "0"
 _FUSED_GRAD_NORM = os.environ.get("ECAMP_FUSED_GRAD_NORM", "1") != "0"   # 0: separate sum-of-squares pass, as the reference does
 
 

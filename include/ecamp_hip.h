@@ -23,6 +23,12 @@ typedef struct ihipStream_t* ecampStream_t; /* == hipStream_t */
 #define ECAMP_F32 0
 #define ECAMP_BF16 1
 
+/* Bumped whenever an exported signature changes (2: ecamp_wgrad_group gained table_bytes, ecamp_gemm_fp8 its q8_* arguments;
+ * 3: round 5 -- ecamp_dropout_mask, the fused vocabulary-head statistics, LayerNorm column-gradient partials).  ecamp_abi_version()
+ * returns the value the library was BUILT with; a consumer compares it with the header it was compiled against -- the Python binding
+ * (ecamp_amd/_lib.py) refuses a library of another version, which is what protects an A/B of two builds (ECAMP_LIB, tools/ab_lib.sh)
+ * from calling an older build with a newer argument list. */
+#define ECAMP_ABI_VERSION 3
 int ecamp_abi_version(void);
 const char* ecamp_last_error(void);
 
@@ -254,12 +260,19 @@ int64_t ecamp_prof_live_events(void);
  *                               for a communication kernel sharing the GPU with the training step)
  *   ecamp_gemm_q8_launches      GEMM calls routed to the persistent 256x256x64 kernel so far (tests assert that it really ran)
  *   ecamp_wgrad_group_launches  grouped weight-gradient launches issued so far (tests assert that the grouped path really ran)
- *   ecamp_gemm_f8_q8_launches   ecamp_gemm_fp8 calls routed to the persistent 256 x 256 x 128 e4m3 kernel so far */
+ *   ecamp_gemm_f8_q8_launches   ecamp_gemm_fp8 calls routed to the persistent 256 x 256 x 128 e4m3 kernel so far
+ *   ecamp_attn_head_launches    launches of the head-resident bf16 attention kernels (one workgroup per (batch, head)) so far
+ *   ecamp_dropout_mask          keep[e] = 1 iff element e of a tensor survives dropout(p) under (seed, offset): the Philox mask every kernel
+ *                               of this library regenerates (attention probabilities: e = ((b*H + h)*Tq + i)*Tk + j; LayerNorm / embedding
+ *                               dropout: e = row*cols + col), as bytes -- lets the tests and the oracle replay the reference's dropout
+ *                               sites (context_fusion.py:28-57, bert_modeling.py:113,131) under the SAME masks in plain PyTorch */
 #ifdef ECAMP_DEV_ABI
+int ecamp_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, ecampStream_t stream);
 int ecamp_dev_spin(int32_t blocks, int32_t threads, int64_t cycles, ecampStream_t stream);
 int64_t ecamp_gemm_q8_launches(void);
 int64_t ecamp_wgrad_group_launches(void);
 int64_t ecamp_gemm_f8_q8_launches(void);
+int64_t ecamp_attn_head_launches(void);
 #endif
 
 #ifdef __cplusplus

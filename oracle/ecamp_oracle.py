@@ -308,6 +308,14 @@ def forward_loss(P, cfg, imgs, big_imgs, pred, mask, column, row):
 
 # ---- BERT side (transformers 4.42.4 arithmetic) ----------------------------------------------
 def _drop(x, p, train):
+    """nn.Dropout(p) at the reference's dropout sites (BertEmbeddings bert_modeling.py:113; attention probabilities and the
+    BertSelfOutput / BertOutput dense outputs of the fusion layer, context_fusion.py:28-57, and of the six BertLayers,
+    bert_modeling.py:131).  `train`: False = eval, True = torch's generator (what the reference draws from), or a callable
+    (shape, p) -> 0/1 keep-mask: the masks of ANOTHER implementation replayed in the reference's call order (embeddings; fusion:
+    self-attention probabilities, attention output, cross-attention probabilities, out_layer, FFN output; per layer: probabilities,
+    attention output, FFN output), so that a train-mode step can be compared to tolerance instead of statistically."""
+    if callable(train):
+        return x if p == 0.0 else x * train(tuple(x.shape), p) / (1.0 - p)
     return F.dropout(x, p, training=train)
 
 

@@ -35,7 +35,17 @@ def test_header_declares_the_hot_path_entry_points():
 def test_library_exports_every_declared_symbol(lib):
     for name in _lib.parse_header():
         assert hasattr(lib, name), name
-    assert lib.ecamp_abi_version() == 1
+    # the library reports the version of the header it was built against; the binding refuses any other (an older build must never be
+    # called with this header's argument lists: ECAMP_LIB / tools/ab_lib.sh)
+    assert lib.ecamp_abi_version() == _lib.abi_version_of_header() >= 3
+
+
+def test_binding_refuses_a_library_of_another_abi_version(lib, monkeypatch):
+    v = _lib.abi_version_of_header()
+    monkeypatch.setattr(_lib, "abi_version_of_header", lambda path=None: v + 1)   # a header one version ahead of the built library
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.EcampHipError, match="ABI version mismatch"):
+        _lib.load()
 
 
 def test_signatures_have_no_torch_types():

@@ -232,3 +232,19 @@ def test_meters_match_the_reference_meters():
                 got = [m.median, m.avg, m.global_avg, m.max, m.value]
                 assert got == pytest.approx(list(want[i, j]), rel=1e-12, abs=0), (i, k, got, want[i, j])
             assert str(ml) == bytes(lines[i, :lens[i]]).decode(), i
+
+
+def test_roofline_traffic_is_quoted_only_for_the_sources_it_was_measured_on():
+    """bench.py takes `roofline.traffic` from the newest committed PMC passes (profiles/rNN_pmc_traffic.json); tools/pmc_traffic.py
+    stamps that file with the hash of the GEMM sources it was collected on, and bench.py quotes it only when the hash equals this
+    tree's -- a stale file yields null, never last round's number (VERDICT r4, weak #10)."""
+    import glob, json
+    from ecamp_amd.build import gemm_source_hash
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = gemm_source_hash()
+    assert len(h) == 64 and h == gemm_source_hash()
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "gemm_source_hash()" in src and "r04_pmc_traffic.json" not in src
+    assert "gemm_source_sha256" in open(os.path.join(root, "tools", "pmc_traffic.py")).read()
+    for f in glob.glob(os.path.join(root, "profiles", "r0[1-4]_pmc_traffic.json")):   # the unstamped files of rounds 1-4 can never match
+        assert "gemm_source_sha256" not in json.load(open(f))

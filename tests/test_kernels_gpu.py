@@ -361,6 +361,89 @@ def test_attention_saved_dropout_bits_equal_regenerated_mask(dev, B, H, Tq, Tk, 
     assert abs(kept / total - (1 - p)) < 0.02
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,Tq,Tk,hd,masked,cross,p", [(2, 6, 128, 128, 128, True, False, 0.1),    # report side: key mask, hd 128 (every timed BERT layer)
+                                                         (2, 6, 128, 49, 128, False, True, 0.1),     # fusion cross-attention onto tokens 1..49, odd key count
+                                                         (2, 3, 33, 17, 32, True, False, 0.3),       # odd Tk: the per-element Philox path
+                                                         (2, 12, 50, 50, 64, False, False, 0.2),
+                                                         (1, 4, 250, 256, 64, True, False, 0.1)])    # the longest head-resident sequence
+def test_attention_dropout_matches_pytorch_under_the_same_mask(dev, dtype, B, H, Tq, Tk, hd, masked, cross, p):
+    """HF BertSelfAttention in TRAIN mode (context_fusion.py:28-57 / bert_modeling.py:131: `attention_probs = self.dropout(probs)`):
+    out = (softmax(s) * keep / (1 - p)) @ v and its gradients, against plain fp32 PyTorch under the SAME keep-mask -- the Philox mask of
+    (seed, offset) materialised by the development ABI `ecamp_dropout_mask` (element index ((b*H + h)*Tq + i)*Tk + j).  Both the
+    backward that reads the forward's saved mask bits and the one that regenerates the mask are held to the reference."""
+    o = ops()
+    D = H * hd
+    seed, offset = 0x1234ABCD5678, 41
+    q = rnd(gen(B, Tq, D, seed=31), dtype)
+    kvlen = Tk + 1 if cross else Tk
+    k = rnd(gen(B, kvlen, D, seed=32), dtype)
+    v = rnd(gen(B, kvlen, D, seed=33), dtype)
+    do = rnd(gen(B, Tq, D, seed=34), dtype)
+    km = None
+    if masked:
+        lens = torch.randint(max(1, Tk // 3), Tk + 1, (B,), generator=torch.Generator().manual_seed(7))
+        km = (torch.arange(Tk)[None, :] < lens[:, None]).int()
+    keep = o.dropout_mask((B, H, Tq, Tk), dev, p, seed, offset).float().cpu()
+    assert abs(keep.mean().item() - (1 - p)) < 0.02
+    off = 1 if cross else 0
+    qr, kr, vr = q.clone().requires_grad_(True), k.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    sp = lambda t, n: t.view(B, n, H, hd).permute(0, 2, 1, 3)
+    sc = (sp(qr, Tq) @ sp(kr[:, off:], Tk).transpose(-1, -2)) / math.sqrt(hd)
+    if km is not None:
+        sc = sc + (1.0 - km[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    out = ((sc.softmax(-1) * keep / (1 - p)) @ sp(vr[:, off:], Tk)).permute(0, 2, 1, 3).reshape(B, Tq, D)
+    out.backward(do)
+    qd, kd, vd = q.to(dev, dtype), k.to(dev, dtype), v.to(dev, dtype)
+    kmd = km.to(dev) if km is not None else None
+    qs, ks = (Tq * D, D, hd), (kvlen * D, D, hd)
+    kp, vp = kd.view(-1)[off * D:], vd.view(-1)[off * D:]
+    og, lse, bits = o.attn_fwd(qd, kp, vp, B, H, Tq, Tk, hd, qs, ks, ks, 1 / math.sqrt(hd), kmd, p, seed, offset, want_mask=True)
+    tol = TOL[dtype]
+    check("dropout attn out", og, out, tol)
+    for b_ in ([bits, None] if bits is not None else [None]):
+        dq, dk, dv = torch.empty_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+        o.attn_bwd(qd, kp, vp, og, do.to(dev, dtype), lse, dq, dk.view(-1)[off * D:], dv.view(-1)[off * D:], B, H, Tq, Tk, hd, qs, ks, ks,
+                   qs, ks, ks, 1 / math.sqrt(hd), kmd, p, seed, offset, drop_bits=b_)
+        tag = "saved bits" if b_ is not None else "regenerated"
+        check("dropout attn dq (%s)" % tag, dq, qr.grad, tol * 2)
+        check("dropout attn dk (%s)" % tag, dk, kr.grad, tol * 2)
+        check("dropout attn dv (%s)" % tag, dv, vr.grad, tol * 2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols,p", [(512, 768, 0.1), (100, 768, 0.1), (37, 192, 0.3), (64, 1024, 0.1)])
+def test_layernorm_dropout_residual_matches_pytorch_under_the_same_mask(dev, dtype, rows, cols, p):
+    """HF BertSelfOutput / BertOutput in TRAIN mode (LN(dropout(dense_out) + residual), context_fusion.py:37-39,56,70-72 and the six
+    BertLayers of bert_modeling.py:131): forward, the gradient reaching the dense output through the mask, the residual gradient and
+    the LayerNorm parameter gradients against fp32 PyTorch under the SAME keep-mask (ecamp_dropout_mask, element index row*cols + col)."""
+    o = ops()
+    seed, offset, eps = 987654321, 17, 1e-12
+    x = rnd(gen(rows, cols, seed=1), dtype)
+    res = rnd(gen(rows, cols, seed=2), dtype)
+    g = 1 + 0.1 * gen(cols, seed=3)
+    b = 0.1 * gen(cols, seed=4)
+    dy = rnd(gen(rows, cols, seed=5), dtype)
+    keep = o.dropout_mask((rows, cols), dev, p, seed, offset).float().cpu()
+    assert abs(keep.mean().item() - (1 - p)) < 0.03
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z_ref = xr * keep / (1 - p) + rr
+    y_ref = F.layer_norm(z_ref, (cols,), gr, br, eps)
+    y_ref.backward(dy)
+    y, z, mean, rstd = o.layernorm_fwd(x.to(dev, dtype), g.to(dev), b.to(dev), eps, residual=res.to(dev, dtype), drop_p=p, seed=seed, offset=offset)
+    tol = TOL[dtype]
+    check("ln dropout z", z, z_ref, tol)
+    check("ln dropout y", y, y_ref, tol * 2)
+    gg, gb = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    dz, dxd = o.layernorm_bwd(dy.to(dev, dtype), z, mean, rstd, g.to(dev), gg, gb, drop_p=p, seed=seed, offset=offset, want_drop=True)
+    check("ln dropout d residual", dz, rr.grad, tol * 2)
+    check("ln dropout d dense-out", dxd, xr.grad, tol * 2)
+    ptol = 1e-2 if dtype == torch.bfloat16 else 2e-5
+    check("ln dropout dgamma", gg, gr.grad, ptol)
+    check("ln dropout dbeta", gb, br.grad, ptol)
+
+
 # ------------------------------------------------------------------------------------------------ image side
 @pytest.mark.parametrize("Hs,Hd", [(448, 224), (64, 32), (48, 20), (40, 40)])
 def test_bicubic_from_uint8_crops_equals_the_f32_schema(dev, Hs, Hd):
@@ -577,6 +660,39 @@ def test_bert_embeddings(dev, dtype):
     check("d token_type_embeddings", gt, tr.grad, gtol)
     check("d LN gamma", gg, gr.grad, gtol)
     check("d LN beta", gb, br.grad, gtol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bert_embeddings_dropout_matches_pytorch_under_the_same_mask(dev, dtype):
+    """HF BertEmbeddings in TRAIN mode (bert_modeling.py:113): dropout(LayerNorm(word + position + type)) and the embedding / LayerNorm
+    gradients behind it, against fp32 PyTorch under the SAME keep-mask (ecamp_dropout_mask over [B*S, H])."""
+    o = ops()
+    B, S, H, V, p = 4, 48, 768, 300, 0.1
+    seed, offset = 55555, 3
+    g0 = torch.Generator().manual_seed(2)
+    ids = torch.randint(1, V, (B, S), generator=g0)
+    ids[:, 0] = 2
+    ids[:, -7:] = 0
+    ty = torch.zeros(B, S, dtype=torch.long)
+    word, pos, typ = gen(V, H, seed=2, scale=0.5), gen(64, H, seed=3, scale=0.5), gen(2, H, seed=4, scale=0.5)
+    g, b = 1 + 0.1 * gen(H, seed=5), 0.1 * gen(H, seed=6)
+    de = rnd(gen(B * S, H, seed=7), dtype)
+    keep = o.dropout_mask((B * S, H), dev, p, seed, offset).float().cpu().view(B, S, H)
+    wr, pr, tr, gr, br = (t.clone().requires_grad_(True) for t in (word, pos, typ, g, b))
+    e = F.embedding(ids, wr, padding_idx=0) + F.embedding(ty, tr) + pr[:S][None]
+    ref = F.layer_norm(e, (H,), gr, br, 1e-12) * keep / (1 - p)
+    ref.backward(de.view(B, S, H))
+    ed, z, mean, rstd = o.bert_embed_fwd(ids.to(dev), ty.to(dev), word.to(dev), pos.to(dev), typ.to(dev), g.to(dev), b.to(dev), 1e-12, dtype,
+                                         drop_p=p, seed=seed, offset=offset)
+    check("bert embed (dropout)", ed.view(B, S, H), ref, TOL[dtype])
+    gw, gp, gt = torch.zeros(V, H, device=dev), torch.zeros(64, H, device=dev), torch.zeros(2, H, device=dev)
+    gg, gb = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    o.bert_embed_bwd(de.to(dev, dtype), z, mean, rstd, g.to(dev), ids.to(dev), ty.to(dev), gw, gp, gt, gg, gb, B, S, H, drop_p=p, seed=seed, offset=offset)
+    gtol = 1e-4 if dtype == torch.float32 else 2e-2
+    check("d word_embeddings (dropout)", gw, wr.grad, gtol)
+    check("d position_embeddings (dropout)", gp, pr.grad, gtol)
+    check("d LN gamma (dropout)", gg, gr.grad, gtol)
+    check("d LN beta (dropout)", gb, br.grad, gtol)
 
 
 @pytest.mark.parametrize("dtype", DT)

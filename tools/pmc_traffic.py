@@ -9,6 +9,9 @@ reported; both counters are in KB."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ecamp_amd.build import gemm_source_hash
+
 
 def load(d, counter):
     acc = defaultdict(lambda: [0, 0.0])
@@ -34,7 +37,8 @@ for k in sorted(set(fetch) | set(write)):
     w = write.get(k, [0, 0.0])[1] * 1024
     per[k] = {"calls": c, "fetch_bytes_per_launch": f / max(c, 1), "write_bytes_per_launch": w / max(c, 1)}
     n += c; fb += f; wb += w
-print(json.dumps({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof (ECAMP_OVERLAP_WGRAD=0 ECAMP_OVERLAP_BRANCHES=0), separate passes",
+print(json.dumps({"gemm_source_sha256": gemm_source_hash(),
+                  "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof (ECAMP_OVERLAP_WGRAD=0 ECAMP_OVERLAP_BRANCHES=0), separate passes",
                   "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; both in KB",
                   "gemm_launches": n, "gemm_fetch_bytes_per_launch": fb / max(n, 1), "gemm_write_bytes_per_launch": wb / max(n, 1),
                   "per_kernel": per, "gemm_traffic_bytes_per_launch": (fb + wb) / max(n, 1)}, indent=1))
