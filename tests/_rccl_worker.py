@@ -58,13 +58,14 @@ def main():
     # the update does not modify the gradient arena: replay it in one pass from the saved state
     p, m, v = before
     s = torch.zeros(1, device=dev)
-    p16 = torch.empty_like(A.flat_p16)
+    p16 = torch.empty_like(A.flat_p16) if A.flat_p16 is not None else None   # (f32 parity mode keeps no bf16 shadow)
     g0 = opt.param_groups[0]
     hip_ops.adamw_grouped(p, A.flat_g, m, v, p16, opt._table, [g["lr"] for g in opt.param_groups], [g["weight_decay"] for g in opt.param_groups],
                           g0["betas"][0], g0["betas"][1], g0["eps"], 1, 1.0, s)
     torch.cuda.synchronize()
     used = opt._table.repeat_interleave(64) < 8
-    replay_equal = bool(torch.equal(p, A.flat_p) and torch.equal(m, opt._m) and torch.equal(v, opt._v) and torch.equal(p16[used], A.flat_p16[used]))
+    replay_equal = bool(torch.equal(p, A.flat_p) and torch.equal(m, opt._m) and torch.equal(v, opt._v)
+                        and (p16 is None or torch.equal(p16[used], A.flat_p16[used])))
     # every rank must hold the same reduced arena and the same parameters
     chk = torch.stack([A.flat_g.double().sum(), A.flat_p.double().sum()])
     lo_, hi_ = chk.clone(), chk.clone()

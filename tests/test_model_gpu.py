@@ -272,7 +272,11 @@ def test_train_mode_matches_oracle_under_the_same_dropout_masks(dev, dtype, ltol
     for n, prm in model.named_parameters():
         if not prm.requires_grad or P[n].grad is None:
             continue
-        gr = P[n].grad     # (the floor: the key biases' true gradient is zero -- softmax is shift-invariant -- and what is left is rounding)
+        gr = P[n].grad
+        # (the key biases' true gradient is zero -- softmax is shift-invariant -- and what is left is rounding: f32 holds them to a floor
+        # of 1e-5 of the largest tensor's norm; bf16 skips tensors below 1e-3 of it, as the eval-mode golden test does)
+        if dtype == torch.bfloat16 and gr.norm().item() < 1e-3 * gmax:
+            continue
         errs[n] = (prm.grad.float().cpu() - gr).norm().item() / (gr.norm().item() + 1e-5 * gmax)
     worst = max(errs, key=errs.get)
     med = float(np.median(list(errs.values())))
