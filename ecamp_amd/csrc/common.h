@@ -242,7 +242,7 @@ template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) { retu
 
 // profile.hip
 int ecamp_prof_active();
-void ecamp_prof_begin(int cat, double work, hipStream_t s);
+void ecamp_prof_begin(int cat, double work, hipStream_t s, const char* tag = nullptr);
 void ecamp_prof_end(hipStream_t s);
 #define ECAMP_PROF_GEMM_BF16 0
 #define ECAMP_PROF_GEMM_F32 1

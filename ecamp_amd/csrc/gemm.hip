@@ -903,7 +903,11 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
                 if (n_attr < 32) attr_done[n_attr++] = fn;
             }
             const bool prof8 = ecamp_prof_active();
-            if (prof8) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream);
+            if (prof8) {   // tag: form (f = forward x w^T, d = data gradient dy w, w = weight gradient dy^T x), epilogue, M N K, split
+                char tag[40];
+                snprintf(tag, sizeof tag, "q8:%c:e%d:%ld:%ld:%ld:s%d", a_kc && b_kc ? 'f' : a_kc ? 'd' : 'w', epi, (long)M, (long)N, (long)K, split_k);
+                ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream, tag);
+            }
             {   // data-gradient form beside a co-tenant (see g_q8_bwd_grid): the hardware dispatcher deals the items
                 static const int env_bwd = getenv("ECAMP_Q8_BWD_GRID") ? atoi(getenv("ECAMP_Q8_BWD_GRID")) : 0;
                 const int bg = g_q8_bwd_grid > 0 ? g_q8_bwd_grid : env_bwd;
@@ -932,7 +936,11 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
         else hipLaunchKernelGGL((KERN<false, false, false>), grid, block, 0, stream, g);                   \
     } while (0)
     const bool prof = ecamp_prof_active();
-    if (prof) ecamp_prof_begin(dtype == ECAMP_BF16 ? ECAMP_PROF_GEMM_BF16 : ECAMP_PROF_GEMM_F32, 2.0 * (double)M * (double)N * (double)K, stream);
+    if (prof) {
+        char tag[40];
+        snprintf(tag, sizeof tag, "t128:%c:e-:%ld:%ld:%ld:s%d", a_kc && b_kc ? 'f' : a_kc ? 'd' : 'w', (long)M, (long)N, (long)K, split_k);
+        ecamp_prof_begin(dtype == ECAMP_BF16 ? ECAMP_PROF_GEMM_BF16 : ECAMP_PROF_GEMM_F32, 2.0 * (double)M * (double)N * (double)K, stream, tag);
+    }
     if (dtype == ECAMP_BF16) LAUNCH(gemm_bf16_kernel); else LAUNCH(gemm_f32_kernel);
 #undef LAUNCH
     if (split_k > 1) {
@@ -1180,7 +1188,11 @@ extern "C" int ecamp_wgrad_group(int32_t n, const void* const* dy, const void* c
     double work = 0.0;
     for (int p = 0; p < n; ++p) work += 2.0 * (double)n_out[p] * (double)k_in[p] * (double)rows;
     const bool prof = ecamp_prof_active();
-    if (prof) ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, work, stream);
+    if (prof) {
+        char tag[40];
+        snprintf(tag, sizeof tag, "grp:w:n%d:%ld:%ld:%ld:wg%d", n, (long)rows, (long)n_out[0], (long)k_in[0], pl->nwg);
+        ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, work, stream, tag);
+    }
     hipLaunchKernelGGL(fn, dim3(pl->nwg), dim3(512), shm, stream, g, G);
     g_q8_launches += n;
     ++g_wg_launches;

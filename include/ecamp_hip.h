@@ -273,6 +273,7 @@ int64_t ecamp_gemm_q8_launches(void);
 int64_t ecamp_wgrad_group_launches(void);
 int64_t ecamp_gemm_f8_q8_launches(void);
 int64_t ecamp_attn_head_launches(void);
+int64_t ecamp_prof_dump(char* buf, int64_t cap);   /* per (form, epilogue, shape) totals of the profiled GEMM launches: "<tag> <n> <ms> <flop>" lines */
 #endif
 
 #ifdef __cplusplus

@@ -134,7 +134,8 @@ def test_gemm_rejects_bad_alignment(dev):
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("rows,cols,eps", [(100, 768, 1e-6), (394, 512, 1e-6), (7, 192, 1e-6), (256, 768, 1e-12), (33, 1024, 1e-6)])
+@pytest.mark.parametrize("rows,cols,eps", [(100, 768, 1e-6), (394, 512, 1e-6), (7, 192, 1e-6), (256, 768, 1e-12), (33, 1024, 1e-6),
+                                           (40, 2048, 1e-6)])   # 2048 = the documented maximum (64 KB of reduction slices in the backward)
 def test_layernorm(dev, dtype, rows, cols, eps):
     o = ops()
     x = rnd(gen(rows, cols, seed=1) * 2 + 0.3, dtype)

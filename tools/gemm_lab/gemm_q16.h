@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_q16_kernel(GemmArgs g) {
         if (s__ < NW) Q16_RDB(NS, NKS, (s__ < NW ? s__ : 0), SN_);                                                       \
         else if (s__ < NW + 8) Q16_RDA(NS, NKS, (s__ >= NW && s__ < NW + 8 ? s__ - NW : 0), SM_);                        \
         else if (s__ < NW + 12) { if ((DP0) >= 0) Q16_ISSUE1((DP0) < 0 ? 0 : (DP0), (s__ - NW - 8) & 3); }               \
-        else if (s__ < NW + 16) { if ((DP1) >= 0) Q16_ISSUE1((DP1) < 0 ? 0 : (DP1), (s__ - NW - 12) & 3); }              \
-        else if (s__ == NW + 16) { if ((DP0) >= 0) Q16_ADVANCE((DP0) < 0 ? 0 : (DP0)); }                                 \
+        else if (s__ == NW + 12) { if ((DP0) >= 0) Q16_ADVANCE((DP0) < 0 ? 0 : (DP0)); }   /* before DP1's pieces: part 3's advance moves the stream to the next K tile */ \
+        else if (s__ < NW + 17) { if ((DP1) >= 0) Q16_ISSUE1((DP1) < 0 ? 0 : (DP1), (s__ - NW - 13) & 3); }              \
         else if (s__ == NW + 17) { if ((DP1) >= 0) Q16_ADVANCE((DP1) < 0 ? 0 : (DP1)); }                                 \
     } while (0)
 #define Q16_PAIR(S, ZERO, NS, NKS, SM_, SN_, DP0, DP1, s_)                                                               \

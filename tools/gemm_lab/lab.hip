@@ -2,6 +2,7 @@
 // header as the product, checks it against the product's 128^2 kernel (ecamp_gemm with q8_mode = 0) and times variants.
 //   make -C tools/gemm_lab        (cross-compiles here)          gpurun -- tools/gemm_lab/lab [shape-substr ...]
 #include "gemm_q4.h"
+#include "gemm_q16.h"
 #include "../../include/ecamp_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,6 +43,19 @@ static int g_sch = 0;   // schedule variant of the launches that follow (gemm_q8
 static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
     (void)nslot;
 #define W(A, B, E, S) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, false, S>)
+    if (g_sch == 16 || g_sch == 12) {   // four waves on the 16 x 16 x 32 MFMA (gemm_q16.h): 256- (16) or 192-column (12) tiles; forward form, plain / bias / residual
+        if (!(a_kc && b_kc)) return nullptr;
+        if (dbg != 0) {
+            if (g_sch != 16 || epi != 0) return nullptr;
+            if (dbg == 1) return (q8_fn)gemm_bf16_q16_kernel<0, 8, 1>;
+            if (dbg == 2) return (q8_fn)gemm_bf16_q16_kernel<0, 8, 2>;
+            if (dbg == 4) return (q8_fn)gemm_bf16_q16_kernel<0, 8, 4>;
+            return nullptr;
+        }
+        if (g_sch == 16) { if (epi == 0) return (q8_fn)gemm_bf16_q16_kernel<0, 8>; if (epi == 2) return (q8_fn)gemm_bf16_q16_kernel<2, 8>; }
+        else             { if (epi == 0) return (q8_fn)gemm_bf16_q16_kernel<0, 6>; if (epi == 2) return (q8_fn)gemm_bf16_q16_kernel<2, 6>; }
+        return nullptr;
+    }
     if (g_sch == 4 || g_sch == 5) {   // four waves of 128 x 128 (gemm_q4.h): forward form only; 5 = all DMA parts right behind the barrier (EARLY)
         if (!(a_kc && b_kc)) return nullptr;
         if (dbg != 0) {   // timing decomposition of the plain kernel: 1 no MFMA, 2 no DMA, 4 no fragment reads (results are garbage)
@@ -118,7 +132,7 @@ static void launch_q8(const Run& r, int nslot, int dbg, int grid_override, hipSt
     g.wide = (r.ldc % 8 == 0) && (r.N % 8 == 0);
     g.ldp = g.ldg = g.ldr = r.N;
     g.dbg = dbg;
-    const long total = (long)g.nbm * g.nbn * split;
+    const long total = nslot == 12 ? (long)g.nbm * ((r.N + 191) / 192) : (long)g.nbm * g.nbn * split;
     int ncu = grid_override > 0 ? grid_override : 256;
     dim3 grid((unsigned)(total < ncu ? total : ncu));
     const int epi = r.out_f32 ? 4 : r.gmul ? 3 : r.residual ? 2 : r.pre ? 1 : 0;
@@ -127,7 +141,7 @@ static void launch_q8(const Run& r, int nslot, int dbg, int grid_override, hipSt
     if (!fn) { fprintf(stderr, "no Q8 instance for form %d%d epi %d dbg %d sch %d\n", r.a_kc, r.b_kc, epi, dbg, nslot); return; }
     const size_t shm = (size_t)10 * Q8_HALF;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(fn, grid, dim3(nslot == 4 || nslot == 5 ? 256 : 512), shm, s, g);
+    hipLaunchKernelGGL(fn, grid, dim3(nslot == 4 || nslot == 5 || nslot == 16 || nslot == 12 ? 256 : 512), shm, s, g);
 }
 
 static int launch_ref(const Run& r, int /*unused*/, hipStream_t s) {   // the product's 128^2 kernel
@@ -256,6 +270,7 @@ int main(int argc, char** argv) {
             for (int ns : nslots)
                 for (int dbg : dbgs) {
                     if (ns != 0 && ns != 4 && ns != 1 && dbg != 0) continue;
+                    if (ns == 16 || ns == 12) continue;   // no GELU epilogue in the 16 x 16 x 32 lab kernel
                     CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s));
                     launch_q8(q, ns, dbg, grid_override, s);
                     CK(hipStreamSynchronize(s));
@@ -270,7 +285,7 @@ int main(int argc, char** argv) {
             launch_ref(r2, 0, s);
             for (int ns : nslots)
             for (int dbg : dbgs) {
-                if (ns != 0 && ns != 4 && ns != 1 && dbg != 0) continue;
+                if (ns != 0 && ns != 4 && ns != 1 && ns != 16 && dbg != 0) continue;
                 CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s));
                 launch_q8(q2, ns, dbg, grid_override, s);
                 CK(hipStreamSynchronize(s));
