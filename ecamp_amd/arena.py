@@ -15,6 +15,9 @@ from . import hip_ops as ops
 
 ALIGN = 64
 LAZY_ZERO = __import__("os").environ.get("ECAMP_LAZY_ZERO_GRAD", "1") != "0"   # 0: zero_grad() memsets the whole gradient arena
+# fp8 forward, delayed scaling of the activation sites: the scale covers F8_MARGIN x the largest maximum of the last F8_HISTORY steps
+F8_HISTORY = int(__import__("os").environ.get("ECAMP_FP8_HISTORY", "4"))
+F8_MARGIN = float(__import__("os").environ.get("ECAMP_FP8_MARGIN", "1.25"))
 
 
 class ParamArena:
@@ -169,9 +172,15 @@ class ParamArena:
             n = len(self.params)
             self.f8_scale = torch.ones((n,), device=self.device, dtype=torch.float32)
             self.f8_amax = ops.zeros((n * 512,), self.device)
+            # delayed scaling with a memory: a site quantises with F8_MARGIN x the largest maximum its producers saw over the
+            # last F8_HISTORY optimizer steps -- a history of ONE step without a margin let any activation that grows from step to step
+            # (the first steps after the one-batch calibration, warm-up) saturate silently at +-448
+            self.f8_hist = ops.zeros((n, F8_HISTORY), self.device)
+            self.f8_rolls = 0
             self.f8_rolled = self.version
         if self.f8_rolled != self.version:
-            ops.fp8_roll(self.f8_amax, self.f8_scale)
+            ops.fp8_roll(self.f8_amax, self.f8_scale, hist=self.f8_hist, hist_pos=self.f8_rolls, margin=F8_MARGIN)
+            self.f8_rolls += 1
             self.f8_rolled = self.version
         i = self.index[id(p[0] if isinstance(p, (list, tuple)) else p)]
         return i, self.f8_scale[i:i + 1], self.f8_amax[i * 512:(i + 1) * 512], i in self.f8_cal

@@ -23,6 +23,7 @@
 #include "gemm_args.h"
 void attn_set_head_mode(int on);   // attention_bf16.hip
 #include "gemm_q8.h"
+#include "gemm_q16.h"
 
 // =============================================================================================
 // bf16
@@ -477,14 +478,21 @@ __global__ __launch_bounds__(256) void quant_fp8_delayed_kernel(const T* __restr
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(amax_slots + (blockIdx.x & (F8_SLOTS - 1)) * F8_SLOT_STRIDE), __float_as_uint(m));
 }
-__global__ void fp8_roll_kernel(float* __restrict__ amax_slots, float* __restrict__ scale, int n) {
+__global__ void fp8_roll_kernel(float* __restrict__ amax_slots, float* __restrict__ scale, int n, float* __restrict__ hist, int hist_len, int hist_pos,
+                                float margin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float* s = amax_slots + (long)i * F8_SLOTS * F8_SLOT_STRIDE;
     float a = 0.f;
 #pragma unroll
     for (int k = 0; k < F8_SLOTS; ++k) { a = fmaxf(a, s[k * F8_SLOT_STRIDE]); s[k * F8_SLOT_STRIDE] = 0.f; }
-    if (a > 0.f) scale[i] = a * (1.0f / 448.0f);   // a site nobody fed this step keeps its scale
+    if (a <= 0.f) return;   // a site nobody fed this step keeps its scale (and its history)
+    if (hist) {             // delayed scaling with a memory: the scale covers the largest maximum of the last hist_len fed steps
+        float* h = hist + (long)i * hist_len;
+        h[hist_pos % hist_len] = a;
+        for (int k = 0; k < hist_len; ++k) a = fmaxf(a, h[k]);
+    }
+    scale[i] = a * margin * (1.0f / 448.0f);
 }
 extern "C" int ecamp_quant_fp8_delayed(const void* x, const float* scale, void* q, float* amax_slots, int64_t n, int32_t dtype, hipStream_t stream) {
     ECAMP_CHECK_ARG(x && scale && q && amax_slots && n > 0 && n % 4 == 0, "quant_fp8_delayed: bad args");
@@ -497,9 +505,10 @@ extern "C" int ecamp_quant_fp8_delayed(const void* x, const float* scale, void* 
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int ecamp_fp8_roll(float* amax_slots, float* scale, int32_t n, hipStream_t stream) {
+extern "C" int ecamp_fp8_roll(float* amax_slots, float* scale, int32_t n, float* hist, int32_t hist_len, int32_t hist_pos, float margin, hipStream_t stream) {
     ECAMP_CHECK_ARG(amax_slots && scale && n > 0, "fp8_roll: bad args");
-    hipLaunchKernelGGL(fp8_roll_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax_slots, scale, (int)n);
+    ECAMP_CHECK_ARG(margin >= 1.0f && margin <= 16.0f && (!hist || (hist_len > 0 && hist_len <= 64 && hist_pos >= 0)), "fp8_roll: margin in [1, 16], history of 1..64 steps");
+    hipLaunchKernelGGL(fp8_roll_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax_slots, scale, (int)n, hist, (int)hist_len, (int)hist_pos, margin);
     ECAMP_LAUNCH_CHECK();
     return 0;
 }
@@ -747,8 +756,35 @@ static bool q8_legal(const void* A, const void* B, const void* C, int64_t M, int
     return true;
 }
 
+// ---- Q16 (gemm_q16.h): four waves on the 16x16x32 MFMA, forward and data-gradient forms, 256- or 192-column tiles.
+// "q16_mode" (env ECAMP_Q16): 0 never; 1 (default) where the 192-column tile removes idle last-round time (the 768-wide outputs of the model);
+// 2 every eligible call, with the tile width the round count favours; 3 (tests) as 2 whatever the size
+static int g_q16_mode = -1;
+static int q16_mode() {
+    static const int v = getenv("ECAMP_Q16") ? atoi(getenv("ECAMP_Q16")) : 1;
+    return g_q16_mode >= 0 ? g_q16_mode : v;
+}
+static long g_q16_launches = 0;
+extern "C" int64_t ecamp_gemm_q16_launches(void) { return g_q16_launches; }
+// rounds of the chip a launch needs with TN-column tiles, in units of one 256 x 256 tile's time (a 256 x 192 tile costs ~0.79 of it:
+// tools/gemm_lab, profiles/r05_vendor_vs_q8.txt)
+static double q16_cost(int64_t M, int64_t N, int tn, int ncu) {
+    const long tiles = (long)ceil_div(M, 256) * ceil_div(N, tn);
+    return (double)((tiles + ncu - 1) / ncu) * (tn == 192 ? 0.79 : 1.0);
+}
+typedef void (*q16_fn)(GemmArgs);
+static q16_fn q16_pick(int b_kc, int epi, int nw) {
+    if (b_kc) {
+        if (nw == 8) return epi == 0 ? (q16_fn)gemm_bf16_q16_kernel<0, 8, true> : (q16_fn)gemm_bf16_q16_kernel<2, 8, true>;
+        return epi == 0 ? (q16_fn)gemm_bf16_q16_kernel<0, 6, true> : (q16_fn)gemm_bf16_q16_kernel<2, 6, true>;
+    }
+    if (nw == 8) return epi == 0 ? (q16_fn)gemm_bf16_q16_kernel<0, 8, false> : (q16_fn)gemm_bf16_q16_kernel<2, 8, false>;
+    return epi == 0 ? (q16_fn)gemm_bf16_q16_kernel<0, 6, false> : (q16_fn)gemm_bf16_q16_kernel<2, 6, false>;
+}
+
 extern "C" int ecamp_set_option(const char* name, int32_t value) {
     ECAMP_CHECK_ARG(name != nullptr, "set_option: null name");
+    if (strcmp(name, "q16_mode") == 0) { g_q16_mode = (value >= 0 && value <= 3) ? value : -1; return 0; }
     if (strcmp(name, "q8_mode") == 0) { g_q8_mode = (value == 0 || value == 2) ? value : -1; return 0; }   // -1 auto, 0 never, 2 whenever legal
     if (strcmp(name, "p8_wgrad") == 0) { g_p8_wgrad = value ? 1 : 0; return 0; }
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
@@ -884,9 +920,44 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
     {
         const int q8m = q8_env();
         const long items8 = (long)ceil_div(M, 256) * ceil_div(N, 256) * split_k;
-        if (q8m != 0 && (q8m == 2 || items8 >= q8_min_items()) && (a_kc || b_kc || g_p8_wgrad) &&
+        if (q8m != 0 && (q8m == 2 || items8 >= q8_min_items() || q16_mode() == 3) && (a_kc || b_kc || g_p8_wgrad) &&
             q8_legal(A, B, C, M, N, K, a_kc, lda, b_kc, ldb, ldc, bias, residual, ldr, pre_out, ldp, gmul, ldg, act, dtype, g.out_f32, split_k, splitk_ws, rowsum)) {
             const int epi = q8_epi(bias, residual, pre_out, gmul, act, g.out_f32);
+            {   // Q16: forward / data-gradient forms with a plain, bias or residual epilogue (same legality as Q8: 16-B alignment, < 2 GB)
+                const int m16 = q16_mode(), ncu16 = p8_num_cu();
+                if (m16 > 0 && a_kc && (epi == 0 || epi == 2) && split_k == 1 && !rowsum && (b_kc || ldb % 8 == 0)) {
+                    const double c256 = q16_cost(M, N, 256, ncu16), c192 = q16_cost(M, N, 192, ncu16);
+                    // (the 192-column tile only where it removes a good part of a round: the report side's qkv projection -- 6.0 rounds of
+                    // 3/4-size tiles against 4.5 -> 5 -- measured 8 % SLOWER inside the step, profiles/r05_gemm_in_step_vs_lab.txt)
+                    const int nw = c192 <= 0.9 * c256 ? 6 : 8;
+                    if (m16 >= 2 || nw == 6) {
+                        q16_fn f16 = q16_pick(b_kc, epi, nw);
+                        g.nbm = ceil_div(M, 256); g.nbn = ceil_div(N, nw * 32);
+                        g.nsplit = 1; g.wide = 1;
+                        const long total16 = (long)g.nbm * g.nbn;
+                        const size_t shm16 = 10 * Q8_HALF;
+                        static q16_fn attr16[16];
+                        static int n_attr16 = 0;
+                        bool seen16 = false;
+                        for (int i = 0; i < n_attr16; ++i) seen16 = seen16 || attr16[i] == f16;
+                        if (!seen16) {
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm16);
+                            if (n_attr16 < 16) attr16[n_attr16++] = f16;
+                        }
+                        const bool prof16 = ecamp_prof_active();
+                        if (prof16) {
+                            char tag[40];
+                            snprintf(tag, sizeof tag, "q16:%c:e%d:%ld:%ld:%ld:w%d", b_kc ? 'f' : 'd', epi, (long)M, (long)N, (long)K, nw * 32);
+                            ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream, tag);
+                        }
+                        hipLaunchKernelGGL(f16, dim3((unsigned)(total16 < ncu16 ? total16 : ncu16)), dim3(256), shm16, stream, g);
+                        ++g_q16_launches;
+                        if (prof16) ecamp_prof_end(stream);
+                        ECAMP_LAUNCH_CHECK();
+                        return 0;
+                    }
+                }
+            }
             q8_fn fn = q8_pick(a_kc, b_kc, epi, rowsum != nullptr);
             g.nbm = ceil_div(M, 256); g.nbn = ceil_div(N, 256);
             g.nsplit = split_k; g.wide = 1;

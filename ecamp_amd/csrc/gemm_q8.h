@@ -611,10 +611,13 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                     }
                     if (F8 && g.q8_out) {
                         float u[8];
+                        // rows past M (an edge tile's zero-filled operand rows give gelu(bias) there) are not part of C: they must not
+                        // enter the site's maximum; their stores are dropped by the descriptors anyway
+                        const bool row_in = mb + tm * 32 + l31 < g.M && uo[tm][gq] != 0x80000000u;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
                             const float yr = rnd<bf16_t>(v[r]);   // what the bf16 output holds: fused == quantising C afterwards, bit for bit
-                            q8_max = fmaxf(q8_max, fabsf(yr));
+                            if (row_in) q8_max = fmaxf(q8_max, fabsf(yr));
                             u[r] = fminf(fmaxf(yr * q8_inv, -448.f), 448.f);
                         }
                         int w0 = 0, w1 = 0;

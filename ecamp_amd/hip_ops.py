@@ -74,9 +74,11 @@ def quantize_fp8(x):
     return q, scale
 
 
-def fp8_roll(amax_slots, scale):
-    """Delayed scaling, once per optimizer step: scale[i] = max(site i's 16 amax slots) / 448 where a producer fed the site; slots = 0."""
-    call("ecamp_fp8_roll", ptr(amax_slots), ptr(scale), scale.numel(), stream())
+def fp8_roll(amax_slots, scale, hist=None, hist_pos=0, margin=1.0):
+    """Once per optimizer step: scale[i] = margin * max(site i's 16 amax slots, its history) / 448 where a producer fed the site; slots = 0.
+    hist: optional f32 [sites, k] ring of the last k maxima (delayed scaling of activation sites); None + margin 1 = exact current scaling."""
+    call("ecamp_fp8_roll", ptr(amax_slots), ptr(scale), scale.numel(), ptr(hist), hist.shape[1] if hist is not None else 0, int(hist_pos),
+         float(margin), stream())
 
 
 def fp8_weights(w16, w8, items, amax_slots, scales, pass_):

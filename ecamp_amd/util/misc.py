@@ -11,7 +11,7 @@ import builtins
 import datetime
 import os
 import time
-from collections import defaultdict, deque
+from collections import deque
 from pathlib import Path
 
 import torch
@@ -20,103 +20,106 @@ import torch.distributed as dist
 inf = float("inf")
 
 
+def _torch_stat(values, kind):
+    """The window statistics are DEFINED by what torch computes on the window (the reference prints them to four decimals and
+    tests/golden/meters.npz pins them to 1e-12): `median` = torch's lower median of the f32-converted values, `avg` = their f32 mean."""
+    if kind == "median":
+        return torch.tensor(values).median().item()
+    return torch.tensor(values, dtype=torch.float32).mean().item()
+
+
 class SmoothedValue(object):
-    """Window / global statistics of a scalar series (misc.py:24-83).  Values may be Python numbers or 0-d tensors."""
+    """A scalar series with a sliding window (median / avg / max / value) and running totals (global_avg); interface, format keys and
+    printed values of misc.py:24-83.  `update` also takes 0-d device tensors: they are parked and read back together, once, the first
+    time any statistic is asked for -- a training step never waits for the device because of a meter."""
 
     def __init__(self, window_size=20, fmt=None):
-        self.deque = deque(maxlen=window_size)
-        self._pending = []  # (tensor, n) pairs not yet read back from the device
-        self.total = 0.0
-        self.count = 0
-        self.fmt = fmt if fmt is not None else "{median:.4f} ({global_avg:.4f})"
+        self.fmt = "{median:.4f} ({global_avg:.4f})" if fmt is None else fmt
+        self.deque = deque(maxlen=window_size)   # the window (the reference's attribute name)
+        self.count, self.total = 0, 0.0
+        self._parked = []                        # (device tensor, weight) not yet read back
+
+    def _take(self, number, weight):
+        self.deque.append(number)
+        self.total += number * weight
+        self.count += weight
 
     def update(self, value, n=1):
-        if isinstance(value, torch.Tensor):
-            self._pending.append((value.detach(), n))
-            return
-        self.deque.append(value)
-        self.count += n
-        self.total += value * n
+        if torch.is_tensor(value):
+            self._parked.append((value.detach(), n))
+        else:
+            self._take(value, n)
 
     def _flush(self):
-        if self._pending:
-            vals = torch.stack([v.float().reshape(()) for v, _ in self._pending]).tolist()  # ONE device read-back
-            for (_, n), v in zip(self._pending, vals):
-                self.deque.append(v)
-                self.count += n
-                self.total += v * n
-            self._pending = []
+        if not self._parked:
+            return
+        parked, self._parked = self._parked, []
+        host = torch.stack([t.float().reshape(()) for t, _ in parked]).tolist()   # ONE read-back for the lot
+        for number, (_, weight) in zip(host, parked):
+            self._take(number, weight)
 
     def synchronize_between_processes(self):
-        """Does not synchronise the window, only count/total (as the reference)."""
+        """Sums count and total over the ranks; the window stays local (as in the reference)."""
         self._flush()
-        if not is_dist_avail_and_initialized():
+        if get_world_size() == 1:
             return
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        pair = torch.tensor([self.count, self.total], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.barrier()
-        dist.all_reduce(t)
-        t = t.tolist()
-        self.count = int(t[0])
-        self.total = t[1]
+        dist.all_reduce(pair)
+        self.count, self.total = int(pair[0].item()), pair[1].item()
 
-    @property
-    def median(self):
+    def _window(self):
         self._flush()
-        return torch.tensor(list(self.deque)).median().item()
+        return list(self.deque)
 
-    @property
-    def avg(self):
-        self._flush()
-        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+    median = property(lambda self: _torch_stat(self._window(), "median"))
+    avg = property(lambda self: _torch_stat(self._window(), "avg"))
+    max = property(lambda self: max(self._window()))
+    value = property(lambda self: self._window()[-1])
 
     @property
     def global_avg(self):
         self._flush()
         return self.total / self.count
 
-    @property
-    def max(self):
-        self._flush()
-        return max(self.deque)
-
-    @property
-    def value(self):
-        self._flush()
-        return self.deque[-1]
-
     def __str__(self):
-        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+        stats = {k: getattr(self, k) for k in ("median", "avg", "global_avg", "max", "value")}
+        return self.fmt.format(**stats)
 
 
 class MetricLogger(object):
+    """Named SmoothedValue meters, created on first update; `logger.<name>` reaches a meter; `log_every` wraps the loader and prints the
+    reference's progress line (misc.py:86-167)."""
+
     def __init__(self, delimiter="\t"):
-        self.meters = defaultdict(SmoothedValue)
         self.delimiter = delimiter
+        self.meters = {}
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
 
     def update(self, **kwargs):
-        for k, v in kwargs.items():
-            if v is None:
+        for name, value in kwargs.items():
+            if value is None:
                 continue
-            assert isinstance(v, (float, int, torch.Tensor))
-            self.meters[k].update(v)
+            if not isinstance(value, (float, int, torch.Tensor)):
+                raise AssertionError("meter %r takes a number or a 0-d tensor, got %s" % (name, type(value).__name__))
+            if name not in self.meters:
+                self.meters[name] = SmoothedValue()
+            self.meters[name].update(value)
 
     def __getattr__(self, attr):
-        if attr in self.meters:
-            return self.meters[attr]
-        if attr in self.__dict__:
-            return self.__dict__[attr]
+        meters = self.__dict__.get("meters", {})
+        if attr in meters:
+            return meters[attr]
         raise AttributeError("'{}' object has no attribute '{}'".format(type(self).__name__, attr))
 
     def __str__(self):
-        return self.delimiter.join("{}: {}".format(name, str(meter)) for name, meter in self.meters.items())
+        return self.delimiter.join("%s: %s" % (name, meter) for name, meter in self.meters.items())
 
     def synchronize_between_processes(self):
         for meter in self.meters.values():
             meter.synchronize_between_processes()
-
-    def add_meter(self, name, meter):
-        self.meters[name] = meter
 
     def log_every(self, iterable, print_freq, header=None):
         header = header or ""
@@ -144,29 +147,19 @@ class MetricLogger(object):
 
 
 # --------------------------------------------------------------------------------------------- distributed
-def setup_for_distributed(is_master):
-    """Mute print() on non-master ranks (misc.py:170-184)."""
-    builtin_print = builtins.print
-
-    def print(*args, **kwargs):
-        force = kwargs.pop("force", False) or (get_world_size() > 8)
-        if is_master or force:
-            builtin_print("[{}] ".format(datetime.datetime.now().time()), end="")
-            builtin_print(*args, **kwargs)
-
-    builtins.print = print
-
-
-def is_dist_avail_and_initialized():
+def _in_process_group():
     return dist.is_available() and dist.is_initialized()
 
 
+is_dist_avail_and_initialized = _in_process_group   # the reference's name (misc.py:187-192)
+
+
 def get_world_size():
-    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+    return dist.get_world_size() if _in_process_group() else 1
 
 
 def get_rank():
-    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+    return dist.get_rank() if _in_process_group() else 0
 
 
 def is_main_process():
@@ -174,8 +167,21 @@ def is_main_process():
 
 
 def save_on_master(*args, **kwargs):
-    if is_main_process():
+    if get_rank() == 0:
         torch.save(*args, **kwargs)
+
+
+def setup_for_distributed(is_master):
+    """After this call print() is silent on every rank but the master (pass force=True to print anyway; jobs of more than 8 ranks
+    always print) and prefixes the wall-clock time -- the log format of misc.py:170-184."""
+    plain_print = builtins.print
+
+    def rank_aware_print(*args, force=False, **kwargs):
+        if is_master or force or get_world_size() > 8:
+            plain_print("[%s] " % datetime.datetime.now().time(), end="")
+            plain_print(*args, **kwargs)
+
+    builtins.print = rank_aware_print
 
 
 def init_distributed_mode(args):

@@ -92,6 +92,9 @@ int64_t ecamp_sr_bwd_workspace_bytes(void);
 int ecamp_set_option(const char* name, int32_t value);
 /* "q8_mode" (ecamp_set_option): -1 automatic (default), 0 never, 2 whenever its alignment / size conditions hold -- the
  * persistent 256x256x64 kernel (csrc/gemm_q8.h) that serves the forward, data-gradient and weight-gradient forms. */
+/* "q16_mode" (ecamp_set_option; env ECAMP_Q16): the four-wave v_mfma_f32_16x16x32_bf16 kernel (csrc/gemm_q16.h; forward and data-gradient forms
+ * with a plain / bias / residual epilogue, 256 x 256 or 256 x 192 tiles).  0 never; 1 (default) where the 192-column tile removes idle
+ * last-round time -- the model's 768-wide outputs; 2 every eligible call; 3 as 2 whatever the size (tests); -1 back to the environment */
 /* "attn_head" (ecamp_set_option): 1 (default; env ECAMP_ATTN_HEAD) one workgroup per (batch, head) with everything resident in LDS
  * for sequences that fit (<= 256 tokens here), 0 the 64-row streaming kernels for every length, -1 back to the environment's choice */
 
@@ -101,17 +104,21 @@ int ecamp_set_option(const char* name, int32_t value);
  *   ecamp_quant_fp8 scale_out[0] = max(amax[0], tiny) / 448;  q[i] = e4m3(clamp(x[i] / scale, +-448))   (one byte per element)
  *   ecamp_gemm_fp8  C[M,N] (bf16) = act((A8[M,K] . B8[N,K]^T) * scale_a[0] * scale_b[0] + bias) (+ residual); act 0 none, 1 exact GELU, 2 exact GELU with gelu'(pre-activation) saved to pre_out (see ecamp_gemm),
  *                   with the bf16 pre-activation saved to pre_out -- the forward of timm Attention.qkv / proj and Mlp.fc1 / fc2
- *                   (call sites model_ecamp.py:233-234, 254-255).  K, lda, ldb multiples of 16 bytes.  f32 accumulation on
- *                   v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales. */
+ *                   (call sites model_ecamp.py:233-234, 254-255).  K, lda, ldb multiples of 16 bytes.  f32 accumulation with unit block
+ *                   scales: v_mfma_scale_f32_32x32x64_f8f6f4 in the persistent 256 x 256 x 128 kernel (csrc/gemm_q8.h, F8; every shape of
+ *                   the model at B >= 64), v_mfma_scale_f32_16x16x128_f8f6f4 in the 128^2 kernel that serves small / unaligned shapes. */
 int ecamp_amax(const void* x, float* out, int64_t n, int32_t dtype, ecampStream_t stream);
 /* Delayed per-tensor scaling (round 4): a GEMM input site owns scale[0] (f32: what its producer quantises with and ecamp_gemm_fp8
  * dequantises with during this optimizer step) and 16 amax slots 32 floats apart (512 floats per site; what this step's producers saw).
  *   ecamp_quant_fp8_delayed  q[i] = e4m3(clamp(x[i] / scale[0], +-448)); amax_slots[(workgroup & 15) * 32] = max(., |x|)  -- one pass
- *   ecamp_fp8_roll           per site i < n: a = max over its slots; if a > 0: scale[i] = a / 448; slots = 0   (once per optimizer step)
+ *   ecamp_fp8_roll           per site i < n: a = max over its slots; slots = 0; if a > 0: hist[i][hist_pos % hist_len] = a (hist nullable);
+ *                            scale[i] = margin * max(a, hist[i][...]) / 448   (once per optimizer step).  hist = NULL, margin = 1: exact
+ *                            current scaling (the weights).  Activation sites: the largest maximum of the last hist_len fed steps times a
+ *                            margin, so that an activation that grows from one step to the next does not saturate at +-448
  *   ecamp_layernorm_fwd_q8   ecamp_layernorm_fwd that also writes the e4m3 copy of y (same conventions): the quantisation folded into
  *                            the producer of the GEMM input (nn.LayerNorm sites model_ecamp.py:69,84,235,256; BertSelfOutput / BertOutput) */
 int ecamp_quant_fp8_delayed(const void* x, const float* scale, void* q, float* amax_slots, int64_t n, int32_t dtype, ecampStream_t stream);
-int ecamp_fp8_roll(float* amax_slots, float* scale, int32_t n, ecampStream_t stream);
+int ecamp_fp8_roll(float* amax_slots, float* scale, int32_t n, float* hist, int32_t hist_len, int32_t hist_pos, float margin, ecampStream_t stream);
 /* The e4m3 copies of all weights of a flat bf16 arena in two launches per optimizer step (exact per-matrix scaling): items = DEVICE table
  * of int32[4] {first element (multiple of 4), count (multiple of 4, <= 65536), scale id, 0}, one workgroup each.  pass 0: the item's
  * max|w| into the amax slots of its scale id; (ecamp_fp8_roll); pass 1: w8[i] = e4m3(clamp(w[i] / scales[id], +-448)). */
@@ -272,6 +279,7 @@ int ecamp_dev_spin(int32_t blocks, int32_t threads, int64_t cycles, ecampStream_
 int64_t ecamp_gemm_q8_launches(void);
 int64_t ecamp_wgrad_group_launches(void);
 int64_t ecamp_gemm_f8_q8_launches(void);
+int64_t ecamp_gemm_q16_launches(void);   /* GEMM calls routed to the four-wave 16x16x32 kernel (csrc/gemm_q16.h) so far */
 int64_t ecamp_attn_head_launches(void);
 int64_t ecamp_prof_dump(char* buf, int64_t cap);   /* per (form, epilogue, shape) totals of the profiled GEMM launches: "<tag> <n> <ms> <flop>" lines */
 #endif

@@ -870,6 +870,74 @@ def test_gemm_q8_dgrad_wgrad_ragged(dev, q8_always, M, N, K):
     assert _q8_count() >= n0 + 5, "the Q8 kernel did not run"
 
 
+@pytest.fixture
+def q16_always():
+    from ecamp_amd import hip_ops
+    hip_ops.set_option("q16_mode", 3)
+    hip_ops.set_option("q8_mode", 2)
+    yield
+    hip_ops.set_option("q16_mode", -1)
+    hip_ops.set_option("q8_mode", -1)
+
+
+def _q16_count():
+    from ecamp_amd import _lib
+    return int(_lib.load().ecamp_gemm_q16_launches())
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 192), (1000, 520, 200), (512, 1536, 136), (300, 2304, 768), (2048, 192, 1088), (777 * 8, 768, 264)])
+def test_gemm_q16_forward_and_data_gradient_ragged(dev, q16_always, M, N, K):
+    """The four-wave v_mfma_f32_16x16x32_bf16 kernel (csrc/gemm_q16.h) forced on ragged shapes: forward form y = x w^T + b (+ residual) and
+    data-gradient form dx = dy w (+ residual) against fp32 PyTorch -- edge tiles in M and N (both the 256- and the 192-column tile are
+    picked by the shapes: N = 768 / 192 / 1536 take 192, N = 520 / 2304 take 256), partial last K tiles, one tile per workgroup and several;
+    the launch counter proves the kernel ran."""
+    o = ops()
+    dt = torch.bfloat16
+    x = rnd(gen(M, K, seed=1), dt)
+    w = rnd(gen(N, K, seed=2) * K ** -0.5, dt)
+    b = gen(N, seed=3)
+    res = rnd(gen(M, N, seed=4), dt)
+    dy = rnd(gen(M, N, seed=5), dt)
+    resx = rnd(gen(M, K, seed=6), dt)
+    xd, wd, bd, rd, dyd, rxd = x.to(dev, dt), w.to(dev, dt), b.to(dev), res.to(dev, dt), dy.to(dev, dt), resx.to(dev, dt)
+    n0 = _q16_count()
+    y0 = o.linear_fwd(xd, wd, bd)
+    y1 = o.linear_fwd(xd, wd, bd, residual=rd)
+    y2 = o.linear_fwd(xd, wd)
+    check("q16 fwd + bias", y0, x @ w.T + b, 2e-2)
+    check("q16 fwd + bias + residual", y1, x @ w.T + b + res, 2e-2)
+    check("q16 fwd plain", y2, x @ w.T, 2e-2)
+    if K % 8 == 0 and N % 8 == 0:
+        d0 = o.linear_dgrad(dyd, wd)
+        d1 = o.linear_dgrad(dyd, wd, residual=rxd)
+        check("q16 dgrad", d0, dy @ w, 2e-2)
+        check("q16 dgrad + residual", d1, dy @ w + resx, 2e-2)
+        assert _q16_count() - n0 == 5
+    else:
+        assert _q16_count() - n0 == 3
+
+
+def test_gemm_q16_is_deterministic_and_selected_for_the_768_wide_outputs(dev):
+    """Default kernel selection ("q16_mode" 1): the model's 768-wide outputs at B = 256 (150 / 384 tiles of 256 x 256: 41 % / 25 % of the last
+    round idle) run on the four-wave kernel's 256 x 192 tile, the other shapes stay on the eight-wave kernel; repeated launches are
+    bit-identical (no atomics, a race screen of the DMA / barrier protocol)."""
+    o = ops()
+    dt = torch.bfloat16
+    for M, N, K, want in ((12800, 768, 3072, 1), (32768, 768, 768, 1), (12800, 3072, 768, 0), (32768, 1536, 768, 0)):
+        x = rnd(gen(M, K, seed=1), dt).to(dev, dt)
+        w = rnd(gen(N, K, seed=2) * K ** -0.5, dt).to(dev, dt)
+        dy = rnd(gen(M, N, seed=3), dt).to(dev, dt)
+        n0 = _q16_count()
+        y = [o.linear_fwd(x, w) for _ in range(3)]
+        d = [o.linear_dgrad(dy, w) for _ in range(3)]
+        torch.cuda.synchronize()
+        # forward: output width N; data gradient: output width K
+        assert (_q16_count() - n0) == 3 * want + 3 * (1 if K == 768 else 0), (M, N, K, _q16_count() - n0)
+        assert torch.equal(y[0], y[1]) and torch.equal(y[0], y[2]) and torch.equal(d[0], d[1]) and torch.equal(d[0], d[2])
+        ref = (x[:64].float() @ w.float().T)
+        assert (y[0][:64].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (1000, 520, 264), (50432, 512, 2048)])
 def test_gemm_q8_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q8_always, M, N, K):
     """`q8_bwd_grid` (what the data-parallel wrapper sets): the data-gradient form on one workgroup per output tile, on half as many

@@ -89,7 +89,8 @@ def test_rccl_ranks_equal_single_process(dev, tmp_path, single, bucketwise, grid
     assert got["bucketwise_steps"] == bucketwise
     assert eg <= 1e-5, eg
     assert ep <= 1e-4, ep     # Adam's first step is lr * sign-like: compared at lr resolution (see test_ddp_two_ranks_equal_single_process)
-    assert abs(got["norm"] - single["norm"]) <= 1e-5 * single["norm"]
+    # (one pass: the fused kernel's own f32 sum of squares; bucket by bucket: one f32 partial per bucket launch, summed in another order)
+    assert abs(got["norm"] - single["norm"]) <= (1e-3 if bucketwise else 1e-5) * single["norm"]
     assert abs(got["replay_norm"] - got["norm"]) <= 1e-3 * got["norm"]
 
 

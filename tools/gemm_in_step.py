@@ -64,11 +64,14 @@ def in_step(steps=3):
     return rows
 
 
-def lab(tag, warm, n=20):
+def lab(tag, warm, n=20, q16=None):
+    """The call of `tag` alone, back to back.  q16: None = the kernel family of the tag, 0 / 1 = force the eight-wave / the four-wave kernel."""
     kind, form, epi, M, N, K, sp = tag.split(":")
-    if kind != "q8":
+    if kind not in ("q8", "q16"):
         return None
-    M, N, K, split, e = int(M), int(N), int(K), int(sp[1:]), int(epi[1:])
+    hip_ops.set_option("q16_mode", (1 if kind == "q16" else 0) if q16 is None else q16)
+    M, N, K, e = int(M), int(N), int(K), int(epi[1:])
+    split = int(sp[1:]) if sp[0] == "s" else 1
     bf = torch.bfloat16
     # enough copies of the activation operands to exceed the Infinity Cache when `warm` is False
     per = (M * K + M * N) * 2 if form != "w" else (K * M + K * N) * 2
@@ -106,25 +109,32 @@ def lab(tag, warm, n=20):
 def main():
     rows = in_step()
     hip_ops.set_option("q8_mode", -1)
+    only = os.environ.get("GEMM_IN_STEP_ONLY")   # e.g. "q16": lab columns for these tags only (shorter run)
+    if only:
+        rows = {k: v for k, v in rows.items() if k.startswith(only)}
     print("# GEMM classes of the bench step: in-step (serialized, behind their dependent predecessor) against the same call alone (back to back)")
     print("%-34s %5s %6s %6s %5s | %8s %8s %8s | %7s %7s %7s | %6s" % ("form:epi:M:N:K:split", "n/stp", "tiles", "rounds", "idle", "in-step", "lab cold", "lab warm",
                                                                  "dep us", "hbm us", "quant", "TF in"))
     tot = {"in": 0.0, "cold": 0.0, "warm": 0.0, "quant": 0.0, "n": 0.0}
     for tag, (nps, us, fl) in sorted(rows.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         parts = tag.split(":")
-        if parts[0] != "q8":
+        if parts[0] not in ("q8", "q16"):
             print("%-34s %5.1f %6s %6s %5s | %8.1f %8s %8s |" % (tag[:34], nps, "-", "-", "-", us, "-", "-"))
-            tot["in"] += nps * us
             continue
-        M, N, K, split = int(parts[3]), int(parts[4]), int(parts[5]), int(parts[6][1:])
-        tiles = ((M + 255) // 256) * ((N + 255) // 256) * split
+        M, N, K = int(parts[3]), int(parts[4]), int(parts[5])
+        split = int(parts[6][1:]) if parts[6][0] == "s" else 1
+        tn = int(parts[6][1:]) if parts[6][0] == "w" else 256
+        tiles = ((M + 255) // 256) * ((N + tn - 1) // tn) * split
         rounds = tiles / 256.0
         full = -(-tiles // 256)
         idle = 1.0 - rounds / full
         cold, warm = lab(tag, False), lab(tag, True)
+        other = ""
+        if parts[0] == "q16":   # the same call on the eight-wave kernel, for comparison
+            other = "   [eight-wave kernel alone: cold %.1f warm %.1f]" % (lab(tag, False, q16=0), lab(tag, True, q16=0))
         quant = us * idle
-        print("%-34s %5.1f %6d %6.2f %4.0f%% | %8.1f %8.1f %8.1f | %7.1f %7.1f %7.1f | %6.0f" % (tag[3:37], nps, tiles, rounds, 100 * idle, us, cold, warm, us - cold, cold - warm,
-                                                                                         quant, fl / us / 1e6))
+        print("%-34s %5.1f %6d %6.2f %4.0f%% | %8.1f %8.1f %8.1f | %7.1f %7.1f %7.1f | %6.0f" % (tag[:34], nps, tiles, rounds, 100 * idle, us, cold, warm, us - cold, cold - warm,
+                                                                                         quant, fl / us / 1e6) + other)
         tot["in"] += nps * us; tot["cold"] += nps * cold; tot["warm"] += nps * warm; tot["quant"] += nps * quant; tot["n"] += nps
     print("# per step: %.0f tagged launches; in-step %.2f ms; the same calls alone: cold %.2f ms, warm %.2f ms; dependent-launch cost %.2f ms; "
           "operands from HBM %.2f ms; partial last rounds %.2f ms" % (tot["n"], tot["in"] / 1e3, tot["cold"] / 1e3, tot["warm"] / 1e3,

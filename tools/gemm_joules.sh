@@ -17,9 +17,9 @@ sample() {   # $1 = pid to watch, prints "W sclk" averages over 4 samples
   python3 -c "n=max($N,1); print('%.0f W  %.0f MHz' % ($P/n, $C/n))"
 }
 for shape in sq4k bert_inter; do
-  case $shape in sq4k) TILES=256; KT=64;; bert_inter) TILES=768; KT=12;; esac
+  case $shape in sq4k) TILES=256; KT=64; NL=90000;; bert_inter) TILES=768; KT=12; NL=130000;; esac
   for sch in 1 4 16; do
-    ./lab --n=60000 --sch=$sch --quick --forms=1 $shape > /tmp/gj_$$.log 2>&1 &
+    ./lab --n=$NL --plain-only --sch=$sch --quick --forms=1 $shape > /tmp/gj_$$.log 2>&1 &
     LP=$!
     PW=$(sample $LP)
     wait $LP
@@ -35,7 +35,7 @@ M,N,K=S; dev=torch.device("cuda:0"); torch.manual_seed(0)
 x=torch.randn(M,K,device=dev).bfloat16(); w=(torch.randn(N,K,device=dev)*K**-0.5).bfloat16()
 f=lambda: torch.nn.functional.linear(x,w)
 for _ in range(10): f()
-torch.cuda.synchronize(); n=60000
+torch.cuda.synchronize(); n=$NL
 a,e=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(n): f()

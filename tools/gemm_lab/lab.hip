@@ -2,7 +2,7 @@
 // header as the product, checks it against the product's 128^2 kernel (ecamp_gemm with q8_mode = 0) and times variants.
 //   make -C tools/gemm_lab        (cross-compiles here)          gpurun -- tools/gemm_lab/lab [shape-substr ...]
 #include "gemm_q4.h"
-#include "gemm_q16.h"
+#include "../../ecamp_amd/csrc/gemm_q16.h"
 #include "../../include/ecamp_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -43,18 +43,22 @@ static int g_sch = 0;   // schedule variant of the launches that follow (gemm_q8
 static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
     (void)nslot;
 #define W(A, B, E, S) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, false, S>)
-    if (g_sch == 16 || g_sch == 12) {   // four waves on the 16 x 16 x 32 MFMA (gemm_q16.h): 256- (16) or 192-column (12) tiles; forward form, plain / bias / residual
-        if (!(a_kc && b_kc)) return nullptr;
+    if (g_sch == 16 || g_sch == 12) {   // four waves on the 16 x 16 x 32 MFMA (csrc/gemm_q16.h): 256- (16) or 192-column (12) tiles; forward and data-gradient forms, plain / bias / residual
+        if (!a_kc) return nullptr;
         if (dbg != 0) {
-            if (g_sch != 16 || epi != 0) return nullptr;
-            if (dbg == 1) return (q8_fn)gemm_bf16_q16_kernel<0, 8, 1>;
-            if (dbg == 2) return (q8_fn)gemm_bf16_q16_kernel<0, 8, 2>;
-            if (dbg == 4) return (q8_fn)gemm_bf16_q16_kernel<0, 8, 4>;
+            if (g_sch != 16 || epi != 0 || !b_kc) return nullptr;
+            if (dbg == 1) return (q8_fn)gemm_bf16_q16_kernel<0, 8, true, 1>;
+            if (dbg == 2) return (q8_fn)gemm_bf16_q16_kernel<0, 8, true, 2>;
+            if (dbg == 4) return (q8_fn)gemm_bf16_q16_kernel<0, 8, true, 4>;
             return nullptr;
         }
-        if (g_sch == 16) { if (epi == 0) return (q8_fn)gemm_bf16_q16_kernel<0, 8>; if (epi == 2) return (q8_fn)gemm_bf16_q16_kernel<2, 8>; }
-        else             { if (epi == 0) return (q8_fn)gemm_bf16_q16_kernel<0, 6>; if (epi == 2) return (q8_fn)gemm_bf16_q16_kernel<2, 6>; }
-        return nullptr;
+        if (epi != 0 && epi != 2) return nullptr;
+        if (b_kc) {
+            if (g_sch == 16) return epi == 0 ? (q8_fn)gemm_bf16_q16_kernel<0, 8, true> : (q8_fn)gemm_bf16_q16_kernel<2, 8, true>;
+            return epi == 0 ? (q8_fn)gemm_bf16_q16_kernel<0, 6, true> : (q8_fn)gemm_bf16_q16_kernel<2, 6, true>;
+        }
+        if (g_sch == 16) return epi == 0 ? (q8_fn)gemm_bf16_q16_kernel<0, 8, false> : (q8_fn)gemm_bf16_q16_kernel<2, 8, false>;
+        return epi == 0 ? (q8_fn)gemm_bf16_q16_kernel<0, 6, false> : (q8_fn)gemm_bf16_q16_kernel<2, 6, false>;
     }
     if (g_sch == 4 || g_sch == 5) {   // four waves of 128 x 128 (gemm_q4.h): forward form only; 5 = all DMA parts right behind the barrier (EARLY)
         if (!(a_kc && b_kc)) return nullptr;
@@ -203,10 +207,11 @@ int main(int argc, char** argv) {
     bool quick = false;
     std::vector<int> dbgs = {0};
     std::vector<int> nslots = {0};   // the list of schedule variants to run (--sch=0,1,2); the name is historical
-    int grid_override = 0, stress = 0, hog = 0;   // --hog: a small spinning kernel on a second stream beside every launch (uneven load)
+    int grid_override = 0, stress = 0, hog = 0, plain_only = 0;   // --hog: a small spinning kernel on a second stream beside every launch (uneven load)
     for (int i = 1; i < argc; ++i) {
         if (!strncmp(argv[i], "--stress=", 9)) { stress = atoi(argv[i] + 9); continue; }
         if (!strcmp(argv[i], "--hog")) { hog = 1; continue; }
+        if (!strcmp(argv[i], "--plain-only")) { plain_only = 1; continue; }   // forward form: only the plain (no bias / activation) variant
         if (!strncmp(argv[i], "--n=", 4)) { g_n = atoi(argv[i] + 4); continue; }
         if (!strcmp(argv[i], "--zero")) { g_zero = 1; continue; }   // all-zero operands: the matrix pipes draw far less power (is a gap power or structure?)
         if (!strncmp(argv[i], "--forms=", 8)) forms = atoi(argv[i] + 8);
@@ -269,6 +274,7 @@ int main(int argc, char** argv) {
             printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f\n", sh.name, "fwd", M, N, K, "128^2 (r1)", t_ref, fl / t_ref / 1e6);
             for (int ns : nslots)
                 for (int dbg : dbgs) {
+                    if (plain_only) continue;
                     if (ns != 0 && ns != 4 && ns != 1 && dbg != 0) continue;
                     if (ns == 16 || ns == 12) continue;   // no GELU epilogue in the 16 x 16 x 32 lab kernel
                     CK(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, s));
