@@ -443,7 +443,7 @@ def main():
                         traffic = None
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "gemm_bf16_q8_kernel + gemm_bf16_kernel (bf16 GEMM family)" if args.dtype == "bf16" else "gemm_f32_kernel",
+                               "kernel": "gemm_bf16_q8_kernel + gemm_bf16_q16_kernel + gemm_bf16_kernel (bf16 GEMM family)" if args.dtype == "bf16" else "gemm_f32_kernel",
                                "launches_per_step": n.value // max(prof_steps, 1),
                                "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2),
                                "algorithmic_gflop_per_launch": round(fl.value / max(n.value, 1) / 1e9, 3),
