@@ -486,6 +486,49 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 3 ? g.gmul : g.C), 0, (int)(unsigned)((long)g.M * g.ldg * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == 2 || EPI == 3) && g.residual ? g.residual : g.C), 0,
                                                                         (int)(unsigned)((long)g.M * g.ldr * 2), 0x00020000);
+    // Bias of the wave's 64 output columns, per lane the 4 x 8 values it adds (NH, group of 8, half): requested ONCE per output tile by
+    // eight 16-B loads behind the previous tile's epilogue and landed by the first K tile's counted DMA wait (they are older than the
+    // parts that wait leaves in flight).  Round 5: the epilogue used to fetch them per quadrant through scalar loads -- four exposed
+    // scalar-memory round trips and 190 move / select instructions per tile with the matrix pipes idle (tools/epilogue_scale.py: 7-8 us
+    // of every 256 x 256 tile are not its K loop).  Inline asm: hipcc drains the whole DMA queue (vmcnt(0)) in front of the first use of
+    // a vector load it tracks; columns past N read 0 (descriptor bounds; N % 8 == 0).
+    q8_u32x4 bq[2][2][2];
+    typedef unsigned q8_u32x4s __attribute__((ext_vector_type(4)));
+    constexpr bool HAS_BIAS = (EPI <= 2) && !ITEMS;
+    const unsigned bias_lane = (unsigned)((wc * 64 + 8 * lh) * 4);
+    auto bias_request = [&](int tn0) __attribute__((always_inline)) {
+        if constexpr (HAS_BIAS) {
+            if (g.bias) {
+                const unsigned long long bp = (unsigned long long)g.bias;
+                const q8_u32x4s rs_ = {(unsigned)bp, (unsigned)(bp >> 32) & 0xffffu, (unsigned)g.N * 4u, 0x00020000u};
+                const unsigned vo = (unsigned)tn0 * 4u + bias_lane;
+                // ONE statement: the descriptor may reach its SGPRs through v_readlane (the kernel spills scalars), and hipcc's hazard
+                // recogniser does not look inside inline asm -- a VALU-written SGPR needs five wait states before a VMEM instruction reads it
+                // (without the s_nop the e4m3 GELU kernel faulted on a stale descriptor word)
+#define Q8_BOF(NH_, GQ_, H_) "n"(((NH_) * 32 + (GQ_) * 16 + (H_) * 4) * 4)
+                asm volatile("s_nop 4\n\t"
+                             "buffer_load_dwordx4 %0, %8, %9, 0 offen offset:%10\n\t"
+                             "buffer_load_dwordx4 %1, %8, %9, 0 offen offset:%11\n\t"
+                             "buffer_load_dwordx4 %2, %8, %9, 0 offen offset:%12\n\t"
+                             "buffer_load_dwordx4 %3, %8, %9, 0 offen offset:%13\n\t"
+                             "buffer_load_dwordx4 %4, %8, %9, 0 offen offset:%14\n\t"
+                             "buffer_load_dwordx4 %5, %8, %9, 0 offen offset:%15\n\t"
+                             "buffer_load_dwordx4 %6, %8, %9, 0 offen offset:%16\n\t"
+                             "buffer_load_dwordx4 %7, %8, %9, 0 offen offset:%17"
+                             : "=&v"(bq[0][0][0]), "=&v"(bq[0][0][1]), "=&v"(bq[0][1][0]), "=&v"(bq[0][1][1]),
+                               "=&v"(bq[1][0][0]), "=&v"(bq[1][0][1]), "=&v"(bq[1][1][0]), "=&v"(bq[1][1][1])
+                             : "v"(vo), "s"(rs_), Q8_BOF(0, 0, 0), Q8_BOF(0, 0, 1), Q8_BOF(0, 1, 0), Q8_BOF(0, 1, 1),
+                               Q8_BOF(1, 0, 0), Q8_BOF(1, 0, 1), Q8_BOF(1, 1, 0), Q8_BOF(1, 1, 1));
+#undef Q8_BOF
+            }
+        }
+    };
+    // (names the eight results behind the wait that landed them: nothing may copy the registers while the loads travel)
+    auto bias_landed = [&]() __attribute__((always_inline)) {
+        if constexpr (HAS_BIAS)
+            asm volatile("" : "+v"(bq[0][0][0]), "+v"(bq[0][0][1]), "+v"(bq[0][1][0]), "+v"(bq[0][1][1]),
+                              "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]), "+v"(bq[1][1][1]));
+    };
     // quadrant (MH, NH) of the output tile at (tm0, tn0), split tz: 2 tiles x 2 groups of 8 consecutive columns per lane.
     // The accumulators are only READ: the first K tile of the next output tile starts from C = 0 in the MFMA itself.
     auto store_quadrant = [&](int tm0, int tn0, int tz, auto mh_c, auto nh_c) {
@@ -530,21 +573,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) bias[gq][r] = 0.f;
-        if (EPI <= 2 && g.bias) {
-            // each group of 8 is clamped on its own, so groups inside N read exactly their columns
-#pragma unroll
-            for (int gq = 0; gq < 2; ++gq) {
-                cfloat4* b0 = (cfloat4*)(g.bias + min(nb + 16 * gq, g.N - 8));
-                cfloat4* b1 = (cfloat4*)(g.bias + min(nb + 16 * gq + 8, g.N - 8));
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    float x0 = b0[r], x1 = b1[r];
-                    asm volatile("" : "+s"(x0), "+s"(x1));
-                    bias[gq][r] = lh ? x1 : x0;
-                }
-            }
-        }
+            for (int r = 0; r < 8; ++r) bias[gq][r] = HAS_BIAS ? __uint_as_float(bq[NH][gq][r >> 2][r & 3]) : 0.f;
         // byte offsets: uniform tile part + lane part; a group past N gets offset 2^31, past every descriptor (< 2 GB, host-checked): dropped / reads 0
         unsigned uo[2][2], up[2][2], ug[2][2], ur[2][2];
 #pragma unroll
@@ -699,6 +728,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     do {                                                                                                                 \
         if (PRE_HOOK) {                                                                                                  \
             if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); } \
+            bias_request(cn0);                                                                                           \
             if (ROWSUM) { if (rsp_on) rowsum_flush(); }                                                                  \
             Q8_SB();                                                                                                     \
         }                                                                                                                \
@@ -738,6 +768,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
     do {                                                                                                                 \
         if (PRE_HOOK) {                                                                                                  \
             if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); } \
+            bias_request(cn0);                                                                                           \
             if (ROWSUM) { if (rsp_on) rowsum_flush(); }                                                                  \
             Q8_SB();                                                                                                     \
         }                                                                                                                \
@@ -772,6 +803,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         constexpr int MH_ = (MH);                                                                                        \
         if (PRE_HOOK) {                                                                                                  \
             if (have_pend) { Q8_STORE_Q(pm0, pn0, pz, 0); Q8_STORE_Q(pm0, pn0, pz, 1); Q8_STORE_Q(pm0, pn0, pz, 2); Q8_STORE_Q(pm0, pn0, pz, 3); } \
+            bias_request(cn0);                                                                                           \
             Q8_SB();                                                                                                     \
         }                                                                                                                \
         if ((MH) == 0) {                                                                                                 \
@@ -873,11 +905,11 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
             const int cm0 = nm0, cn0 = nn0, cz = nz, cnt = ncnt;
             if (ROWSUM) { rs_on = nrs; rs_ones = rs_on ? 0x3f803f80u : 0u; }
             if constexpr (F8) {
-                Q9F_KTILE(true);
+                Q9F_KTILE(true); bias_landed();
 #pragma unroll 1
                 for (int t = 1; t < cnt; ++t) Q9F_KTILE(false);
             } else {
-                Q9_KTILE(true);
+                Q9_KTILE(true); bias_landed();
 #pragma unroll 1
                 for (int t = 1; t < cnt; ++t) Q9_KTILE(false);
             }
@@ -901,7 +933,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
             cm0 = cit.m0; cn0 = cit.n0; cz = cit.z; cnt = cit.nt;
             if (ROWSUM) { rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0; rs_ones = rs_on ? 0x3f803f80u : 0u; }
         }
-        Q8_KTILE(true);
+        Q8_KTILE(true); bias_landed();
 #pragma unroll 1
         for (int t = 1; t < cnt; ++t) Q8_KTILE(false);
         have_pend = true; pm0 = cm0; pn0 = cn0; pz = cz;

@@ -840,11 +840,13 @@ def test_attention_long_sequence_bf16(dev, B, H, Tq, Tk, hd, masked):
 @pytest.fixture
 def q8_always():
     """Route every bf16 GEMM that meets its alignment / size conditions to the round-2 persistent kernel (gemm_q8.h); the automatic
-    rule only picks it from 128 tiles of 256x256 up."""
+    rule only picks it from 128 tiles of 256x256 up (and hands the 768-wide outputs to the four-wave kernel: switched off here)."""
     o = ops()
     o.set_option("q8_mode", 2)
+    o.set_option("q16_mode", 0)
     yield o
     o.set_option("q8_mode", -1)
+    o.set_option("q16_mode", -1)
 
 
 def _q8_count():
