@@ -674,6 +674,10 @@ static int p8_num_cu() {
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        // development (profiles/r05_epilogue_scale.txt): persistent launches on fewer workgroups than CUs, so that launches of two streams
+        // sit side by side instead of one behind the other
+        const char* cap = getenv("ECAMP_GEMM_GRID_CAP");
+        if (cap && atoi(cap) >= 32 && atoi(cap) < ncu) ncu = atoi(cap);
     }
     return ncu;
 }
