@@ -361,13 +361,103 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_reg_kernel(bf16_t* __restrict_
         }
     }
 }
+// Round 5: the same row-in-registers pass in THREE phases with ONE exp per logit (the kernel above evaluates two and rescales a running
+// sum whenever its maximum moves: ~570 us of VALU time per 1.97 GB of logits against the ~500 us a pure read + write of them takes,
+// profiles/r05_vocab_head.txt).  NT threads per row, NG 16-B loads per thread (V <= 8 NG NT):
+//   1  load the row, maximum                                        -> block maximum
+//   2  e = exp(x - max) kept in f32 registers over the loaded row, sum  -> block sum
+//   3  d = e * (w / (M sum)), minus w / M at the label, packed, stored over the logits
+// Lanes past the row hold -inf: they drop out of the maximum and add exp(-inf) = 0.  Measured directly behind the vocabulary GEMM
+// (tools/vocab_head_probe.py, V = 30000): two-exp kernel 1.33x the time of an in-place multiply over the same bytes, this one with 512
+// threads x 8 loads 1.25x, with 1024 x 4 (one row's 120 KB of e spread over all sixteen waves a CU's SIMDs take at 66 registers) 1.20-1.23x;
+// forms that keep the row packed and evaluate exp twice (fewer registers, more rows per CU) 1.25-1.33x.
+template <int NG, int NT>
+__global__ __launch_bounds__(NT) void ce_fwd_bwd_row_kernel(bf16_t* __restrict__ logits, const long* __restrict__ labels,
+                                                            const float* __restrict__ weights, float* __restrict__ loss_sum, int V,
+                                                            long ld, float inv_count) {
+    constexpr int NWV = NT / 64;
+    __shared__ float shm_[2 * NWV];
+    const long row = blockIdx.x;
+    bf16_t* x = logits + row * ld;
+    const int nv8 = V >> 3, wave = threadIdx.x >> 6;
+    uint4 q[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int c = threadIdx.x + NT * j;
+        q[j] = c < nv8 ? *reinterpret_cast<const uint4*>(x + c * 8) : make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);
+    }
+    float e[NG][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e[j][2 * r] = __uint_as_float(w[r] << 16);
+            e[j][2 * r + 1] = __uint_as_float(w[r] & 0xffff0000u);
+            mx = fmaxf(mx, fmaxf(e[j][2 * r], e[j][2 * r + 1]));
+        }
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) shm_[wave] = mx;
+    __syncthreads();
+    float gmx = shm_[0];
+#pragma unroll
+    for (int k = 1; k < NWV; ++k) gmx = fmaxf(gmx, shm_[k]);
+    const long label = labels[row];
+    const bool ign = label < 0 || label >= (long)V;   // ignore_index (see the generic kernel)
+    const float w = ign ? 0.f : weights[row];
+    const float xl = (threadIdx.x == 0 && !ign) ? to_f<bf16_t>(x[label]) : 0.f;   // read before anyone overwrites the row (barrier below)
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float nb = -gmx * LOG2E;
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            e[j][r] = __builtin_amdgcn_exp2f(fmaf(e[j][r], LOG2E, nb));
+            sm += e[j][r];
+        }
+    sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) shm_[NWV + wave] = sm;
+    __syncthreads();
+    float gsm = 0.f;
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) gsm += shm_[NWV + k];
+    if (threadIdx.x == 0 && !ign) atomicAdd(loss_sum, w * (gmx + __logf(gsm) - xl));
+    const float sc = w * inv_count, f = sc / gsm;
+    const int lg = ign ? -1 : (int)(label >> 3), lr = (int)(label & 7);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int c = threadIdx.x + NT * j;
+        if (c < nv8) {
+            float g[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) g[r] = e[j][r] * f;
+            if (c == lg) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) g[r] -= r == lr ? sc : 0.f;
+            }
+            uint4 o;
+            o.x = pack_bf16x2(g[0], g[1]); o.y = pack_bf16x2(g[2], g[3]); o.z = pack_bf16x2(g[4], g[5]); o.w = pack_bf16x2(g[6], g[7]);
+            *reinterpret_cast<uint4*>(x + c * 8) = o;
+        }
+    }
+}
 extern "C" int ecamp_ce_fwd_bwd(void* logits, const int64_t* labels, const float* weights, float* loss_sum, int64_t M, int32_t V,
                                 int64_t ld, float inv_count, int32_t dtype, hipStream_t stream) {
     ECAMP_CHECK_ARG(logits && labels && weights && loss_sum && V % 4 == 0 && ld % 4 == 0, "ce_fwd_bwd: bad args");
     dim3 grid((unsigned)M), block(256);
     if (dtype == ECAMP_BF16 && V % 8 == 0 && ld % 8 == 0 && V <= 32768 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
-        if (V <= 16384) hipLaunchKernelGGL(ce_fwd_bwd_reg_kernel<8>, grid, block, 0, stream, (bf16_t*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count);
-        else hipLaunchKernelGGL(ce_fwd_bwd_reg_kernel<16>, grid, block, 0, stream, (bf16_t*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count);
+        static const int ce_variant = getenv("ECAMP_CE_KERNEL") ? atoi(getenv("ECAMP_CE_KERNEL")) : 1;   // development A/B: 0 = the two-exp kernel of round 2
+        if (ce_variant == 0) {
+            if (V <= 16384) hipLaunchKernelGGL(ce_fwd_bwd_reg_kernel<8>, grid, block, 0, stream, (bf16_t*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count);
+            else hipLaunchKernelGGL(ce_fwd_bwd_reg_kernel<16>, grid, block, 0, stream, (bf16_t*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count);
+        } else {
+#define CE_ROW(NG_, NT_) hipLaunchKernelGGL((ce_fwd_bwd_row_kernel<NG_, NT_>), grid, dim3(NT_), 0, stream, (bf16_t*)logits, (const long*)labels, weights, loss_sum, V, (long)ld, inv_count)
+            if (V <= 4096) CE_ROW(1, 512); else if (V <= 8192) CE_ROW(2, 512); else if (V <= 16384) CE_ROW(4, 512); else CE_ROW(4, 1024);
+#undef CE_ROW
+        }
         ECAMP_LAUNCH_CHECK();
         return 0;
     }

@@ -54,7 +54,7 @@ add("adamw_grouped_kernel", 1, 28 * NPARAM, "p, g, m, v read (16 B) + p, m, v wr
 img224, img448 = B * 3 * R * R * f4, B * 3 * 4 * R * R * f4
 add("sr_pair_fwd_kernel", 1, img224 + img448, "pred_img (f32 224^2) + big (f32 448^2) in; loss scalar out")
 add("sr_pair_bwd_kernel", 1, img224 + img448 + img224, "pred_img + big in; d loss / d pred_img (f32 224^2) out")
-add("ce_fwd_bwd_reg_kernel<16>", 1, 2 * ROWS_T * V * bf, "bf16 logits [32768, 30000] read once, their gradient written over them")
+add("ce_fwd_bwd_row_kernel<4, 1024>", 1, 2 * ROWS_T * V * bf, "bf16 logits [32768, 30000] read once, their gradient written over them")
 add("bicubic_half_kernel", 1, img448 + img224, "f32 448^2 image in, 224^2 out")
 add("wgrad_group_reduce_kernel", 22, None, "f32 slabs of the grouped weight gradients in, gradient arena out (slab count per tile varies)")
 add("splitk_reduce_kernel", 13, None, "split-K slabs in, gradient arena out")
