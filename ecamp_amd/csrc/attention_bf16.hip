@@ -100,9 +100,9 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v, float mul) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
-// keep-mask scales of 4 consecutive attention probabilities (keys j0..j0+3 of query row `row`): element index e = row*Tk + j,
-// mask(e) = word (e & 3) of Philox(counter e >> 2) -- the convention of dropout_scale().  When Tk and j0 are multiples of 4 the
-// four elements share ONE Philox call (it was four, each using a single word: the dropout cost as much as the attention).
+// keep-mask scales of 4 consecutive attention probabilities (keys j0..j0+3 of query row `row`): element index e = row*Tk + j under the
+// library's convention (common.h: halfword (e & 7) of Philox(counter e >> 3)).  When Tk and j0 are multiples of 4 the four elements are
+// half of ONE Philox call; otherwise one call per element.
 __device__ __forceinline__ void attn_drop4(const AttnArgs& a, uint64_t row, int j0, float inv_keep, float (&m)[4]) {
     const uint64_t e0 = row * (uint64_t)a.Tk + (uint64_t)j0;
     if ((a.Tk & 3) == 0) {
@@ -113,22 +113,22 @@ __device__ __forceinline__ void attn_drop4(const AttnArgs& a, uint64_t row, int 
     }
 }
 
-// The dK/dV kernels hold the transposed tile: a lane owns ONE key kj and 4 consecutive query rows i0..i0+3, whose mask words
-// live in four different Philox outputs (one per row).  The 4 lanes of a quad own keys 4m..4m+3, i.e. exactly the 4 words of
-// each of those outputs: lane x of the quad computes the output of row i0+x, and the quad exchanges words with DPP quad
+// The dK/dV kernels hold the transposed tile: a lane owns ONE key kj and 4 consecutive query rows i0..i0+3, whose mask halfwords
+// live in four different Philox outputs (one per row).  The 4 lanes of a quad own keys 4m..4m+3, i.e. the same half (two words) of
+// each of those outputs: lane x of the quad computes the output of row i0+x, and the quad exchanges the two words with DPP quad
 // broadcasts -- one Philox call per lane instead of four.  Same mask(e) as everywhere else.
 __device__ __forceinline__ void attn_drop4_col(const AttnArgs& a, uint64_t row0, int kj, int li, float inv_keep, float (&m)[4]) {
     if ((a.Tk & 3) == 0) {
         const int x = li & 3;
-        const uint4 P = philox4x32(a.seed, a.offset, ((row0 + (uint64_t)x) * (uint64_t)a.Tk + (uint64_t)(kj & ~3)) >> 2);
+        const uint64_t e4 = ((row0 + (uint64_t)x) * (uint64_t)a.Tk + (uint64_t)(kj & ~3)) >> 2;   // the quad's group of four keys in row i0+x
+        const uint4 P = philox4x32(a.seed, a.offset, e4 >> 1);
+        const uint32_t thr = dropout_thr(a.drop_p);
 #define ECAMP_QUAD_WORD(R)                                                                                      \
         do {                                                                                                    \
-            const uint32_t w0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)P.x, (R) * 0x55, 0xf, 0xf, false);       \
-            const uint32_t w1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)P.y, (R) * 0x55, 0xf, 0xf, false);       \
-            const uint32_t w2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)P.z, (R) * 0x55, 0xf, 0xf, false);       \
-            const uint32_t w3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)P.w, (R) * 0x55, 0xf, 0xf, false);       \
-            const uint32_t w = x == 0 ? w0 : x == 1 ? w1 : x == 2 ? w2 : w3;                                     \
-            m[(R)] = ((float)(w >> 8) * (1.0f / 16777216.0f)) >= a.drop_p ? inv_keep : 0.0f;                     \
+            /* (whether a row's group is the low or the high half of its call depends on the row: Tk / 4 may be odd) */ \
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)((e4 & 1) ? P.z : P.x), (R) * 0x55, 0xf, 0xf, false); \
+            const uint32_t a1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)((e4 & 1) ? P.w : P.y), (R) * 0x55, 0xf, 0xf, false); \
+            m[(R)] = dropout_pick(x < 2 ? a0 : a1, x & 1, thr, inv_keep);                                        \
         } while (0)
         ECAMP_QUAD_WORD(0); ECAMP_QUAD_WORD(1); ECAMP_QUAD_WORD(2); ECAMP_QUAD_WORD(3);
 #undef ECAMP_QUAD_WORD

@@ -90,14 +90,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Philox4x32-10 counter RNG (Salmon et al. 2011).  One call yields 4 x 32 random bits for counter
-// (idx_lo, idx_hi, offset_lo, offset_hi) under key `seed`.  Forward and backward regenerate identical
-// masks from (seed, offset, element index): no mask tensor ever touches HBM.
+// Philox4x32 counter RNG (Salmon et al. 2011, "Parallel random numbers: as easy as 1, 2, 3"), SEVEN rounds: Philox4x32-7, the smallest
+// round count of that paper that passes BigCrush (10, its default, is a safety margin; rounds 1-4 of this library ran 10).  One call
+// yields 4 x 32 random bits for counter (idx_lo, idx_hi, offset_lo, offset_hi) under key `seed`.  Forward and backward regenerate
+// identical masks from (seed, offset, element index): no mask tensor ever touches HBM.
+// Why the round count matters: a round is two 32 x 32 -> 64-bit multiplies, quarter-rate VALU work -- at ten rounds and four elements per
+// call the mask cost 25 full-rate instruction slots per element, 18 us of a 44 us LayerNorm + dropout call on [32768, 768] (31 us is
+// what its bytes take) and as much again in every report-side attention.
+constexpr int PHILOX_ROUNDS = 7;
 __device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint64_t offset, uint64_t idx) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PHILOX_ROUNDS; ++r) {
         // one 32x32 -> 64-bit multiply per product (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32: integer multiplies are the
         // slow VALU operations and Philox is most of the report-side attention's arithmetic
         const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
@@ -109,22 +114,38 @@ __device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint64_t offset, uint
     }
     return make_uint4(c0, c1, c2, c3);
 }
-// keep-mask scale for element `e` of a tensor: returns 0 or 1/(1-p).  4 consecutive elements share one
-// Philox call (counter = e >> 2, word = e & 3).
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t offset, uint64_t e, float p, float inv_keep) {
-    uint4 r = philox4x32(seed, offset, e >> 2);
-    uint32_t w = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
-    // uniform in [0,1): keep iff u >= p
-    float u = (float)(w >> 8) * (1.0f / 16777216.0f);
-    return u >= p ? inv_keep : 0.0f;
+// THE dropout convention of this library (round 5; every kernel and ecamp_dropout_mask): element e of the flattened tensor is kept iff
+// halfword (e & 7) of Philox(counter e >> 3) -- words x, y, z, w in turn, low half first -- is >= round(p * 65536).  EIGHT consecutive
+// elements share one call (rounds 1-4: four, 24 bits each); the keep probability is 1 - round(65536 p) / 65536, within 8e-6 of 1 - p
+// (p = 0.1: 0.8999939), and the survivors are scaled by the caller's 1 / (1 - p).
+__device__ __forceinline__ uint32_t dropout_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ float dropout_pick(uint32_t word, int half, uint32_t thr, float inv_keep) {
+    return (half ? (word >> 16) : (word & 0xffffu)) >= thr ? inv_keep : 0.0f;
 }
+// keep-mask scale (0 or inv_keep) of element e
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t offset, uint64_t e, float p, float inv_keep) {
+    const uint4 r = philox4x32(seed, offset, e >> 3);
+    const int h = (int)(e & 7);
+    const uint32_t w = (h >> 1) == 0 ? r.x : (h >> 1) == 1 ? r.y : (h >> 1) == 2 ? r.z : r.w;
+    return dropout_pick(w, h & 1, dropout_thr(p), inv_keep);
+}
+// ... of the four elements 4 e4 .. 4 e4 + 3 (half a call: words x, y for even e4, z, w for odd)
 __device__ __forceinline__ void dropout_scale4(uint64_t seed, uint64_t offset, uint64_t e4, float p, float inv_keep,
                                                float (&s)[4]) {
-    uint4 r = philox4x32(seed, offset, e4);
-    s[0] = ((float)(r.x >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
-    s[1] = ((float)(r.y >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
-    s[2] = ((float)(r.z >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
-    s[3] = ((float)(r.w >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
+    const uint4 r = philox4x32(seed, offset, e4 >> 1);
+    const uint32_t wa = (e4 & 1) ? r.z : r.x, wb = (e4 & 1) ? r.w : r.y, thr = dropout_thr(p);
+    s[0] = dropout_pick(wa, 0, thr, inv_keep); s[1] = dropout_pick(wa, 1, thr, inv_keep);
+    s[2] = dropout_pick(wb, 0, thr, inv_keep); s[3] = dropout_pick(wb, 1, thr, inv_keep);
+}
+// ... of the eight elements 8 e8 .. 8 e8 + 7 (one whole call)
+__device__ __forceinline__ void dropout_scale8(uint64_t seed, uint64_t offset, uint64_t e8, float p, float inv_keep,
+                                               float (&s)[8]) {
+    const uint4 r = philox4x32(seed, offset, e8);
+    const uint32_t thr = dropout_thr(p);
+    s[0] = dropout_pick(r.x, 0, thr, inv_keep); s[1] = dropout_pick(r.x, 1, thr, inv_keep);
+    s[2] = dropout_pick(r.y, 0, thr, inv_keep); s[3] = dropout_pick(r.y, 1, thr, inv_keep);
+    s[4] = dropout_pick(r.z, 0, thr, inv_keep); s[5] = dropout_pick(r.z, 1, thr, inv_keep);
+    s[6] = dropout_pick(r.w, 0, thr, inv_keep); s[7] = dropout_pick(r.w, 1, thr, inv_keep);
 }
 
 // exact (erf) GELU and its derivative -- nn.GELU() default in timm Mlp / HF "gelu"

@@ -229,7 +229,7 @@ extern "C" int ecamp_seq_bcast(const void* g, void* y, int64_t B, int32_t S, int
 
 // ---------------------------------------------------------------------------------------------
 // development ABI (tests only): the dropout keep-mask every kernel of this library derives from (seed, offset) -- element e of the
-// flattened tensor is kept iff word (e & 3) of Philox(counter e >> 2) maps to u >= p (dropout_scale, common.h) -- materialised as one
+// flattened tensor is kept iff halfword (e & 7) of Philox4x32-7(counter e >> 3) is >= round(65536 p) (dropout_scale, common.h) -- materialised as one
 // byte per element, so that a test or the oracle can replay the SAME mask in plain PyTorch (attention probabilities: e = ((b * H + h)
 // * Tq + i) * Tk + j; LayerNorm / embedding dropout: e = row * cols + col)
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, float p, uint64_t seed, uint64_t offset) {

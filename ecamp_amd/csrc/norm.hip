@@ -34,15 +34,15 @@ template <> struct LnVec<bf16_t, 8> {
         return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
     }
 };
-// keep-mask scales of the VEC elements of chunk `c` of a row of `nv` chunks: one Philox call per 4 elements, counters as in the 4-wide form
+// keep-mask scales of the VEC elements of chunk `c` of a row of `nv` chunks (element index row * cols + c * VEC + r): a whole Philox call
+// for an 8-wide chunk, half a call for a 4-wide one (common.h: eight consecutive elements share a call)
 template <int VEC>
 __device__ __forceinline__ void ln_dropout(uint64_t seed, uint64_t offset, long row, int nv, int c, float p, float inv_keep, float (&m)[VEC]) {
-#pragma unroll
-    for (int k = 0; k < VEC / 4; ++k) {
-        float s[4];
-        dropout_scale4(seed, offset, (uint64_t)((row * nv + c) * (VEC / 4) + k), p, inv_keep, s);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m[4 * k + r] = s[r];
+    if constexpr (VEC == 8) {
+        dropout_scale8(seed, offset, (uint64_t)(row * nv + c), p, inv_keep, m);
+    } else {
+        static_assert(VEC == 4, "ln_dropout: 4- or 8-wide chunks");
+        dropout_scale4(seed, offset, (uint64_t)(row * nv + c), p, inv_keep, m);
     }
 }
 

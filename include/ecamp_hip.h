@@ -9,7 +9,7 @@
  *   - returns 0 on success, <0 on argument errors, >0 = hipError_t; message via ecamp_last_error() (thread-local)
  *   - parameter-gradient outputs ACCUMULATE (+=) into the caller's f32 buffers (gradient accumulation,
  *     main_pretrain.py:147-153); activation-gradient outputs are overwritten
- *   - dropout is a Philox4x32-10 stream keyed by (seed, offset, element index): backward regenerates the mask
+ *   - dropout is a Philox4x32-7 stream keyed by (seed, offset, element index >> 3; one 16-bit draw per element): backward regenerates the mask
  */
 #ifndef ECAMP_HIP_H
 #define ECAMP_HIP_H
@@ -24,7 +24,7 @@ typedef struct ihipStream_t* ecampStream_t; /* == hipStream_t */
 #define ECAMP_BF16 1
 
 /* Bumped whenever an exported signature changes (2: ecamp_wgrad_group gained table_bytes, ecamp_gemm_fp8 its q8_* arguments;
- * 3: round 5 -- ecamp_dropout_mask, the fused vocabulary-head statistics, LayerNorm column-gradient partials).  ecamp_abi_version()
+ * 3: round 5 -- ecamp_dropout_mask, ecamp_prof_dump, ecamp_fp8_roll's amax history and margin).  ecamp_abi_version()
  * returns the value the library was BUILT with; a consumer compares it with the header it was compiled against -- the Python binding
  * (ecamp_amd/_lib.py) refuses a library of another version, which is what protects an A/B of two builds (ECAMP_LIB, tools/ab_lib.sh)
  * from calling an older build with a newer argument list. */
