@@ -754,7 +754,7 @@ template <int HD> __device__ __forceinline__ bf16x8 htr(const unsigned char* img
 // Tiles are walked in pairs (32 keys); key tiles below `nfull` hold only attended keys and skip the bias.
 // FLAGS 0: no key mask, no dropout (the image side).  FLAGS 1: key bias on every tile + dropout if drop_p > 0 (the report side).
 template <int HD, int FLAGS>
-__global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void attn_head_fwd_kernel(AttnArgs a) {   // (four waves per SIMD = two 8-wave workgroups per CU: at 154 registers the report side ran one, its loads never under its arithmetic)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RB = HeadCfg<HD>::RB;
     const int nthr = blockDim.x, nw = nthr >> 6;
@@ -826,8 +826,26 @@ __global__ __launch_bounds__(512) void attn_head_fwd_kernel(AttnArgs a) {
             }
             if (FLAGS && a.drop_p > 0.f) {
                 float dm[4], dn[4];
-                attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 4 * g, inv_keep, dm);
-                attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 16 + 4 * g, inv_keep, dn);
+                if ((a.Tk & 7) == 0) {
+                    // A lane owns keys 4g..4g+3 of both tiles of the pair: two halves of two different Philox calls (eight keys each).  Lanes g
+                    // and g ^ 1 of a query row own the other halves: the even one evaluates the call of the first tile's eight keys, the odd
+                    // one the second tile's, and they swap the two words the other needs (ds_swizzle, lanes l <-> l ^ 16) -- one call per
+                    // lane and pair instead of two; same mask(e) as everywhere else (common.h).
+                    const bool odd = (g & 1) != 0;
+                    const uint64_t e8 = ((((uint64_t)bh * a.Tq + qi) * (uint64_t)a.Tk) >> 3) + (uint64_t)(pp * 4 + (odd ? 2 : 0) + (g >> 1));
+                    const uint4 P = philox4x32(a.seed, a.offset, e8);
+                    const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(odd ? P.x : P.z), 0x401f);   // xor_mask 0x10, and_mask 0x1f
+                    const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(odd ? P.y : P.w), 0x401f);
+                    const uint32_t wa0 = odd ? r0 : P.x, wa1 = odd ? r1 : P.y, wb0 = odd ? P.z : r0, wb1 = odd ? P.w : r1;
+                    const uint32_t thr = dropout_thr(a.drop_p);
+                    dm[0] = dropout_pick(wa0, 0, thr, inv_keep); dm[1] = dropout_pick(wa0, 1, thr, inv_keep);
+                    dm[2] = dropout_pick(wa1, 0, thr, inv_keep); dm[3] = dropout_pick(wa1, 1, thr, inv_keep);
+                    dn[0] = dropout_pick(wb0, 0, thr, inv_keep); dn[1] = dropout_pick(wb0, 1, thr, inv_keep);
+                    dn[2] = dropout_pick(wb1, 0, thr, inv_keep); dn[3] = dropout_pick(wb1, 1, thr, inv_keep);
+                } else {
+                    attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 4 * g, inv_keep, dm);
+                    attn_drop4(a, (uint64_t)bh * a.Tq + qi, pp * 32 + 16 + 4 * g, inv_keep, dn);
+                }
                 unsigned bits = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
