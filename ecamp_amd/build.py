@@ -19,12 +19,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-
 
 
 def gemm_source_hash():
-    """sha256 over the sources of the GEMM family (csrc/gemm.hip, gemm_q8.h, gemm_args.h): the identity `profiles/rNN_pmc_traffic.json`
+    """sha256 over the sources of the GEMM family (csrc/gemm.hip, gemm_q8.h, gemm_q16.h, gemm_args.h): the identity `profiles/rNN_pmc_traffic.json`
     is stamped with (tools/pmc_traffic.py) and bench.py checks before it quotes that file's bytes per GEMM launch as `roofline.traffic`
     -- a PMC pass of OTHER kernels must read as "not measured", not as last round's number."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "gemm_q8.h", "gemm_args.h"):
+    for f in ("gemm.hip", "gemm_q8.h", "gemm_q16.h", "gemm_args.h"):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()
 
