@@ -174,6 +174,35 @@ __device__ __forceinline__ void q16_body(const GemmArgs& g) {
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 2 && g.residual ? g.residual : g.C), 0, (int)(unsigned)((long)g.M * g.ldr * 2), 0x00020000);
     const unsigned lane_o = (unsigned)((l15 * ldo + 8 * lq) * 2), lane_r = (unsigned)((l15 * g.ldr + 8 * lq) * 2);
 #define Q16_SB() __builtin_amdgcn_sched_barrier(0)
+    // 192-column tiles (the register budget allows it: 140-164 of 256 VGPRs): the bias of the wave's 96 columns, per lane the 3 x 8 values
+    // it adds, is requested ONCE per output tile by six 16-B loads at the head of the tile's first K tile and landed by that K tile's
+    // counted DMA wait -- as in gemm_q8.h (one s_nop-opened asm statement; tests/test_isa.py checks both invariants on the built code).
+    // The 256-column form has no registers to spare and fetches it per 32-column block through scalar loads (below).
+    constexpr bool BIAS_PF = (NW == 6);
+    q8_u32x4 bq[3][2];
+    typedef unsigned q16_u32x4s __attribute__((ext_vector_type(4)));
+    const unsigned bias_lane = (unsigned)((wc * (16 * NW) + 8 * lq) * 4);
+    auto bias_request = [&](int tn0) __attribute__((always_inline)) {
+        if constexpr (BIAS_PF) {
+            if (g.bias) {
+                const unsigned long long bp = (unsigned long long)g.bias;
+                const q16_u32x4s rs_ = {(unsigned)bp, (unsigned)(bp >> 32) & 0xffffu, (unsigned)g.N * 4u, 0x00020000u};
+                const unsigned vo = (unsigned)tn0 * 4u + bias_lane;
+                asm volatile("s_nop 4\n\t"
+                             "buffer_load_dwordx4 %0, %6, %7, 0 offen\n\t"
+                             "buffer_load_dwordx4 %1, %6, %7, 0 offen offset:16\n\t"
+                             "buffer_load_dwordx4 %2, %6, %7, 0 offen offset:128\n\t"
+                             "buffer_load_dwordx4 %3, %6, %7, 0 offen offset:144\n\t"
+                             "buffer_load_dwordx4 %4, %6, %7, 0 offen offset:256\n\t"
+                             "buffer_load_dwordx4 %5, %6, %7, 0 offen offset:272"
+                             : "=&v"(bq[0][0]), "=&v"(bq[0][1]), "=&v"(bq[1][0]), "=&v"(bq[1][1]), "=&v"(bq[2][0]), "=&v"(bq[2][1])
+                             : "v"(vo), "s"(rs_));
+            }
+        }
+    };
+    auto bias_landed = [&]() __attribute__((always_inline)) {
+        if constexpr (BIAS_PF) asm volatile("" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]));
+    };
     // one 32-column block P of the wave's tile, all eight 16-row MFMA tiles of it: the bias of the block's columns is fetched ONCE (wave-uniform
     // scalar loads: lgkmcnt, they do not touch the DMA queue's vmcnt), the eight residual segments are requested together ahead of the first
     // store (a vector load makes hipcc wait vmcnt(0) at its first use: one exposed latency per block, four or three per tile -- per 16-row
@@ -188,7 +217,10 @@ __device__ __forceinline__ void q16_body(const GemmArgs& g) {
         float bsel[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) bsel[r] = 0.f;
-        if (g.bias) {
+        if (BIAS_PF && g.bias) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bsel[r] = __uint_as_float(bq[P < 3 ? P : 0][r >> 2][r & 3]);
+        } else if (g.bias) {
             // each group of 8 columns is clamped on its own, so a group inside N reads exactly its columns (a clamped group belongs to lanes
             // whose store is dropped anyway)
             cfloat4* b0 = (cfloat4*)(g.bias + min(nb, g.N - 8));
@@ -340,7 +372,9 @@ __device__ __forceinline__ void q16_body(const GemmArgs& g) {
     for (int cv = it_beg; cv < total; cv += G) {
         int cm0, cn0;
         decode(cv, cm0, cn0);
+        bias_request(cn0);
         Q16_KTILE(true);
+        bias_landed();
 #pragma unroll 1
         for (int t = 1; t < nt; ++t) Q16_KTILE(false);
         Q16_WAIT_SET(0);   // the next tile's first fragments (already requested): named before the epilogue's code moves registers around

@@ -21,5 +21,5 @@ def test_bias_registers_are_untouched_while_their_loads_travel():
         from ecamp_amd import build
         build.build()
     groups, problems = check_isa.check(lib)
-    assert groups >= 10, "no bias-request groups found: the checker no longer recognises the code"
+    assert groups >= 17, "no bias-request groups found: the checker no longer recognises the code"
     assert not problems, "\n".join(problems)

@@ -3,9 +3,9 @@
 
     python tools/check_isa.py [ecamp_amd/libecamp_hip.so]
 
-1. gemm_q8.h requests a tile's bias with eight inline-asm `buffer_load_dwordx4` whose results land asynchronously; hipcc treats the
+1. gemm_q8.h (and gemm_q16.h in its 192-column form) request a tile's bias with eight (six) inline-asm `buffer_load_dwordx4` whose results land asynchronously; hipcc treats the
    outputs as defined at the asm statement.  Between the loads and the counted `s_waitcnt vmcnt` that lands them (the first K tile's
-   DMA wait) NO instruction may name one of the 32 destination registers -- a copy or a spill there would read them before the data
+   DMA wait) NO instruction may name one of the 32 (24) destination registers -- a copy or a spill there would read them before the data
    arrived.  Checked for every persistent kernel that carries such a group.
 2. Inside those asm statements a scalar register written by a VALU instruction (v_readlane: the kernels spill scalars) must not be read
    by a VMEM instruction within five wait states; the statement starts with `s_nop 4` for that reason -- checked: every group of
@@ -63,7 +63,7 @@ def check_kernel(co, name, problems):
             m = LOAD.search(dis[j])
             dst.update(range(int(m.group(1)), int(m.group(2)) + 1))
             j += 1
-        if j - i == 8 and len(dst) == 32:   # a tile's bias request
+        if (j - i, len(dst)) in ((8, 32), (6, 24)):   # a tile's bias request (eight-wave kernel: 8 loads; four-wave kernel, 192-column form: 6)
             groups += 1
             if "s_nop 4" not in dis[i - 1]:
                 problems.append("%s: bias loads at line %d are not preceded by s_nop 4" % (name, i))
@@ -80,7 +80,7 @@ def check(lib):
     problems, groups = [], 0
     with tempfile.TemporaryDirectory() as tmp:
         for co in code_objects(lib, tmp):
-            for name in kernels(co, r"gemm_(bf16|f8)_q8_kernel"):
+            for name in kernels(co, r"gemm_(bf16|f8)_q(8|16)_kernel"):
                 groups += check_kernel(co, name, problems)
     return groups, problems
 
