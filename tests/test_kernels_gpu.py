@@ -1256,3 +1256,34 @@ def test_profiling_events_are_bounded(dev):
     assert n.value == 9000 and ms.value > 0 and fl.value == pytest.approx(9000 * 2.0 * 256 * 64 * 128)
     lib.ecamp_prof_collect(-1, None, None, None)
     assert int(lib.ecamp_prof_live_events()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_masks_are_statistically_sound(dev, p):
+    """The library's mask convention (csrc/common.h: halfword (e & 7) of Philox4x32-7(counter e >> 3) >= round(65536 p)) on 2^22
+    elements: keep rate = 1 - round(65536 p) / 65536 within 4 sigma -- overall and for each of the eight halfword positions of a call --
+    no serial correlation at lags 1, 2, 8 and 4096 (|r| < 4 / sqrt(n)), and masks of neighbouring streams (offset, seed) are uncorrelated
+    with each other.  (Seven rounds is the smallest Philox4x32 that passes BigCrush; this is a regression guard for the counter /
+    halfword plumbing, not a substitute for that battery.)"""
+    o = ops()
+    n = 1 << 22
+    q = 1.0 - round(65536 * p) / 65536.0
+    m = o.dropout_mask((n,), dev, p, 1234, 77).float()
+    sig = (q * (1 - q) / n) ** 0.5
+    assert abs(m.mean().item() - q) < 4 * sig
+    byp = m.view(-1, 8).mean(0)
+    assert (byp - q).abs().max().item() < 4 * sig * 8 ** 0.5, byp.tolist()
+    c = m - q
+    var = (c * c).mean().item()
+    for lag in (1, 2, 8, 4096):
+        r = (c[:-lag] * c[lag:]).mean().item() / var
+        assert abs(r) < 4 / n ** 0.5, (lag, r)
+    for seed, off in ((1234, 78), (1235, 77), (1234, 77 + (1 << 32))):
+        m2 = o.dropout_mask((n,), dev, p, seed, off).float() - q
+        r = (c * m2).mean().item() / var
+        assert abs(r) < 4 / n ** 0.5, (seed, off, r)
+    u = o.uniform((n,), dev, 99, 5)
+    assert abs(u.mean().item() - 0.5) < 4 * (1 / 12 / n) ** 0.5 and 0.0 <= u.min().item() and u.max().item() < 1.0
+    cu = u - 0.5
+    assert abs((cu[:-1] * cu[1:]).mean().item() * 12) < 4 / n ** 0.5
