@@ -708,6 +708,34 @@ __device__ __forceinline__ void head_stage(unsigned char* img, const bf16_t* bas
         }
     }
 }
+// Two images of `prow` rows staged together, U 16-B loads of EACH in flight per thread before the first LDS write (round 5).  One image at a
+// time, four loads per thread and round, the hd 128 backward pass (256 threads, 2 x 32 KB per phase) opened each of its two phases with four
+// memory round trips in series -- about half of a workgroup's own time on a kernel whose waves wait 50 % of their cycles
+// (profiles/r05_pmc_sq_all_kernels.txt); with U = 8 it is one.  The registers are free at both points (no accumulator is live yet).
+template <int HD, int U>
+__device__ __forceinline__ void head_stage_pair(unsigned char* imgA, const bf16_t* baseA, long stA, unsigned char* imgB, const bf16_t* baseB, long stB,
+                                                int nrows, int prow, int tid, int nthr) {
+    constexpr int CPR = HeadCfg<HD>::CPR;
+    const int n = prow * CPR;
+    for (int i0 = tid; i0 < n; i0 += U * nthr) {
+        uint4 va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = i0 + u * nthr, row = idx / CPR, ch = idx % CPR;
+            const bool in = idx < n && row < nrows;
+            va[u] = in ? *reinterpret_cast<const uint4*>(baseA + (long)row * stA + ch * 8) : make_uint4(0, 0, 0, 0);
+            vb[u] = in ? *reinterpret_cast<const uint4*>(baseB + (long)row * stB + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = i0 + u * nthr, row = idx / CPR, ch = idx % CPR;
+            if (idx < n) {
+                *reinterpret_cast<uint4*>(imgA + haddr<HD>(row, ch)) = va[u];
+                *reinterpret_cast<uint4*>(imgB + haddr<HD>(row, ch)) = vb[u];
+            }
+        }
+    }
+}
 // packed f32 pairs: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 cost one VALU slot for two lanes' worth of work
 // (tools/probes/valu_rate_probe.hip: same issue rate as v_fma_f32; v_exp_f32 1.5x)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -774,8 +802,7 @@ __global__ __launch_bounds__(512, 4) void attn_head_fwd_kernel(AttnArgs a) {   /
     // next block's a block ahead, into a second register set, measured the same: 228 vs 230 us on the T = 197 backward)
     bf16x8 qf[HD / 32];
     if (wave * 16 < a.Tq) load_row_frags<HD>(qf, qb, a.q_st, wave * 16, a.Tq, lane);
-    head_stage<HD>(KI, kb, a.k_st, a.Tk, prow, tid, nthr);
-    head_stage<HD>(VI, vb, a.v_st, a.Tk, prow, tid, nthr);
+    head_stage_pair<HD, 4>(KI, kb, a.k_st, VI, vb, a.v_st, a.Tk, prow, tid, nthr);
     head_key_bias(KB, a, b, prow, tid, nthr);
     __syncthreads();
     const HeadOff<HD> off(li, g);
@@ -917,8 +944,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
         if (use_bits && q0 + li < a.Tq) mw = *reinterpret_cast<const uint2*>(a.drop_bits + (((long)bh * a.Tq + q0 + li) * 4 + g) * 8);
     };
     if (wave * 16 < a.Tq) load_q(wave * 16, qf, gf, of, lse_c);
-    head_stage<HD>(XI, kb, a.k_st, a.Tk, prow, tid, nthr);
-    head_stage<HD>(YI, vb, a.v_st, a.Tk, prow, tid, nthr);
+    head_stage_pair<HD, (HD == 128 ? 8 : 4)>(XI, kb, a.k_st, YI, vb, a.v_st, a.Tk, prow, tid, nthr);
     head_key_bias(KB, a, b, prow, tid, nthr);
     for (int i = ((a.Tq + 15) & ~15) + tid; i < prow; i += nthr) { LS[i] = 1e30f; DL[i] = 0.f; }
     __syncthreads();
@@ -998,8 +1024,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
         load_row_frags<HD>(vf, vb, a.v_st, wave * 16, a.Tk, lane);
     }
     __syncthreads();
-    head_stage<HD>(XI, qb, a.q_st, a.Tq, prow, tid, nthr);
-    head_stage<HD>(YI, gb, a.do_st, a.Tq, prow, tid, nthr);
+    head_stage_pair<HD, (HD == 128 ? 8 : 4)>(XI, qb, a.q_st, YI, gb, a.do_st, a.Tq, prow, tid, nthr);
     if (use_bits) {   // the head's mask bytes, transposed so that the four query rows of a lane are four consecutive bytes
         for (int i = tid; i < a.Tq * 4; i += nthr) {
             const int row = i >> 2, gg = i & 3;
