@@ -16,8 +16,15 @@ from . import hip_ops as ops
 ALIGN = 64
 LAZY_ZERO = __import__("os").environ.get("ECAMP_LAZY_ZERO_GRAD", "1") != "0"   # 0: zero_grad() memsets the whole gradient arena
 # fp8 forward, delayed scaling of the activation sites: the scale covers F8_MARGIN x the largest maximum of the last F8_HISTORY steps
+# (validated here, where they are read: ecamp_fp8_roll refuses a history outside 1..64 steps and a margin outside [1, 16] on every step,
+# with a message that does not name the environment.  The one-batch calibration needs no seeding of the history: its maximum sits in the
+# site's amax slots until the first roll, which enters it as the history's first element.)
 F8_HISTORY = int(__import__("os").environ.get("ECAMP_FP8_HISTORY", "4"))
 F8_MARGIN = float(__import__("os").environ.get("ECAMP_FP8_MARGIN", "1.25"))
+if not 1 <= F8_HISTORY <= 64:
+    raise ValueError("ECAMP_FP8_HISTORY=%d: the delayed-scaling history is 1..64 optimizer steps" % F8_HISTORY)
+if not 1.0 <= F8_MARGIN <= 16.0:
+    raise ValueError("ECAMP_FP8_MARGIN=%g: the delayed-scaling margin is a factor in [1, 16]" % F8_MARGIN)
 
 
 class ParamArena:

@@ -72,7 +72,32 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n" + r.stderr)
         if verbose:
             print("[ecamp_amd.build] linked %s" % LIB, flush=True)
+        check_isa(verbose)
     return LIB
+
+
+def check_isa(verbose=True):
+    """The inline-asm invariants of the persistent GEMMs that hipcc does not promise (tools/check_isa.py), checked on every freshly
+    linked library: a violation is a wrong-bias race, so it fails the build.  Without the ROCm binutils the check cannot run: said
+    loudly, not silently (tests/test_isa.py then skips as well)."""
+    tools = os.path.join(os.path.dirname(HERE), "tools")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "check_isa.py")):
+        return
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objdump", "llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        print("[ecamp_amd.build] WARNING: ROCm LLVM binutils not found under %s -- the ISA invariants of the bias prefetch were NOT checked "
+              "on this build" % llvm, file=sys.stderr, flush=True)
+        return
+    sys.path.insert(0, tools)
+    try:
+        import check_isa as ci
+        groups, problems = ci.check(LIB)
+    finally:
+        sys.path.remove(tools)
+    if problems or groups == 0:
+        raise RuntimeError("ISA invariants violated in %s (%d bias-request groups):\n%s" % (LIB, groups, "\n".join(problems) or "no group recognised"))
+    if verbose:
+        print("[ecamp_amd.build] ISA invariants hold (%d bias-request groups)" % groups, flush=True)
 
 
 if __name__ == "__main__":

@@ -677,7 +677,11 @@ static int p8_num_cu() {
         // development (profiles/r05_epilogue_scale.txt): persistent launches on fewer workgroups than CUs, so that launches of two streams
         // sit side by side instead of one behind the other
         const char* cap = getenv("ECAMP_GEMM_GRID_CAP");
-        if (cap && atoi(cap) >= 32 && atoi(cap) < ncu) ncu = atoi(cap);
+        if (cap && atoi(cap) >= 32 && atoi(cap) < ncu) {
+            ncu = atoi(cap);
+            fprintf(stderr, "[ecamp_hip] WARNING: ECAMP_GEMM_GRID_CAP=%d -- a development switch: every persistent GEMM of this process runs on %d "
+                            "workgroups instead of one per CU\n", ncu, ncu);
+        }
     }
     return ncu;
 }
@@ -954,7 +958,14 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
                             snprintf(tag, sizeof tag, "q16:%c:e%d:%ld:%ld:%ld:w%d", b_kc ? 'f' : 'd', epi, (long)M, (long)N, (long)K, nw * 32);
                             ecamp_prof_begin(ECAMP_PROF_GEMM_BF16, 2.0 * (double)M * (double)N * (double)K, stream, tag);
                         }
-                        hipLaunchKernelGGL(f16, dim3((unsigned)(total16 < ncu16 ? total16 : ncu16)), dim3(256), shm16, stream, g);
+                        long grid16 = ncu16;
+                        {   // data-gradient form beside a co-tenant: the same switch as the eight-wave kernel's (g_q8_bwd_grid below) -- with
+                            // it on, one output tile per workgroup and the hardware dispatcher deals the tiles
+                            static const int env_bwd16 = getenv("ECAMP_Q8_BWD_GRID") ? atoi(getenv("ECAMP_Q8_BWD_GRID")) : 0;
+                            const int bg16 = g_q8_bwd_grid > 0 ? g_q8_bwd_grid : env_bwd16;
+                            if (!b_kc && bg16 > 0) grid16 = bg16;
+                        }
+                        hipLaunchKernelGGL(f16, dim3((unsigned)(total16 < grid16 ? total16 : grid16)), dim3(256), shm16, stream, g);
                         ++g_q16_launches;
                         if (prof16) ecamp_prof_end(stream);
                         ECAMP_LAUNCH_CHECK();

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dz, T* __restrict__ dxdrop, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, long rows, int cols, float drop_p,
-                                                     uint64_t seed, uint64_t offset, int dev_skip_tail) {
+                                                     uint64_t seed, uint64_t offset) {
     typedef LnVec<T, VEC> V;
     typedef typename V::raw_t raw_t;
     extern __shared__ __attribute__((aligned(16))) float sh[];  // [8][cols]
@@ -312,16 +312,6 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const T* __re
         if (dres && row + stride < rows) fetch_q(row + stride);
     }
     // workgroup reduction of the per-lane column partials, then one global atomic per column
-    // (dev_skip_tail, ECAMP_LN_BWD_SKIP_TAIL=1: a MEASUREMENT switch -- wrong dgamma / dbeta -- that bounds what the tail costs inside the step)
-    if (dev_skip_tail) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < IT; ++i)
-#pragma unroll
-            for (int r = 0; r < VEC; ++r) t += ag[i][r] + ab[i][r];
-        if (t == 1.2345e-30f) dgamma[0] = t;   // keeps the partials alive
-        return;
-    }
     for (int pass = 0; pass < 2; ++pass) {
         float tot[2] = {0.f, 0.f};   // columns threadIdx.x and threadIdx.x + blockDim.x (cols <= 2 * blockDim.x, host-checked)
         for (int half = 0; half < (LN_BWD_WAVES + 7) / 8; ++half) {
@@ -401,14 +391,13 @@ static int ln_bwd_launch(const void* dy, const void* z, const float* mean, const
     // 72 KB at 2048 columns without the opt-in)
     size_t shm = (size_t)8 * cols * sizeof(float);
     static const int variant = getenv("ECAMP_LN_BWD") ? atoi(getenv("ECAMP_LN_BWD")) : 0;   // development: 1 = 4-wide forms only
-    static const int skip_tail = getenv("ECAMP_LN_BWD_SKIP_TAIL") ? atoi(getenv("ECAMP_LN_BWD_SKIP_TAIL")) : 0;   // measurement only (wrong gradients)
     auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
 #define L(IT_, V_, W_, G_)                                                                                               \
     do {                                                                                                                 \
         int nb = ceil_div(rows, W_);                                                                                     \
         if (nb > 256) nb = 256;                                                                                          \
         hipLaunchKernelGGL((ln_bwd_kernel<T, IT_, V_, W_, G_>), dim3(nb), dim3(W_ * 64), shm, st, (const T*)dy, (const T*)z, mean, rstd, gamma, \
-                           (const T*)dres, (T*)dz, (T*)dxdrop, dgamma, dbeta, rows, cols, p, seed, off, skip_tail);      \
+                           (const T*)dres, (T*)dz, (T*)dxdrop, dgamma, dbeta, rows, cols, p, seed, off);      \
     } while (0)
     if constexpr (sizeof(T) == 2) {
         if (variant != 1 && cols % 8 == 0 && cols <= 1024 && al16(dy) && al16(z) && al16(dres) && al16(dz) && al16(dxdrop)) {   // 16-B lane accesses

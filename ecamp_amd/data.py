@@ -71,6 +71,16 @@ class DevicePrefetcher:
 
     def __init__(self, loader, device):
         self.loader, self.device = loader, torch.device(device)
+        self.timing = False    # bench.py: an event pair around every batch's copies on the copy stream
+        self._timed = []       # (start event, end event, bytes)
+
+    def copy_ms(self):
+        """(ms, bytes, batches) of the host -> HBM copies bracketed since the last call (`timing` on; their events must have completed: call
+        behind a synchronize).  The sum of the copies' own durations on the copy stream: what the PCIe path of this box delivers."""
+        ms = sum(a.elapsed_time(b) for a, b, _ in self._timed)
+        nbytes, n = sum(c for _, _, c in self._timed), len(self._timed)
+        self._timed = []
+        return ms, nbytes, n
 
     def __len__(self):
         return len(self.loader)
@@ -105,10 +115,15 @@ class DevicePrefetcher:
             with torch.cuda.stream(side):
                 if done[s] is not None:
                     side.wait_event(done[s])
+                if self.timing and todo:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(side)
                 for dst, v in todo:
                     dst.copy_(v, non_blocking=True)
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=bool(self.timing and todo))
                 ev.record(side)
+                if self.timing and todo:
+                    self._timed.append((t0, ev, sum(v.numel() * v.element_size() for _, v in todo)))
             return out, ev
 
         it = iter(self.loader)

@@ -26,7 +26,8 @@ def main():
     rccl_env_defaults()
     torch.cuda.set_device(rank)
     dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import datetime
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
     from ecamp_amd import hip_ops, optim
     from ecamp_amd.module import model_ecamp as me
     from ecamp_amd.util.misc import NativeScalerWithGradNormCount

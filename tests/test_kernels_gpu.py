@@ -969,6 +969,35 @@ def test_gemm_q8_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q8_a
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (1000, 520, 264), (32768, 768, 1536)])
+def test_gemm_q16_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q16_always, M, N, K):
+    """with the default kernel selection the 768-wide data gradients run on the FOUR-wave kernel, so `q8_bwd_grid` must reach
+    that launch too: persistent grid, one workgroup per tile and half as many workgroups as tiles give the same bits (plain and residual
+    epilogues -- the forms the four-wave kernel has), and the four-wave kernel is what ran."""
+    from ecamp_amd import hip_ops as o
+    g = torch.Generator().manual_seed(6)
+    dy = torch.randn(M, K, generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(dev, torch.bfloat16)
+    res = torch.randn(M, N, generator=g).to(dev, torch.bfloat16)
+    outs = []
+    tiles = -(-M // 256) * -(-N // 192)
+    try:
+        for grid in (0, 1 << 20, max(1, tiles // 2)):
+            o.set_option("q8_bwd_grid", grid)
+            n0 = _q16_count()
+            a = o.linear_dgrad(dy, w)
+            c = o.linear_dgrad(dy, w, residual=res)
+            assert _q16_count() == n0 + 2, "the four-wave kernel did not run"
+            outs.append((a, c))
+    finally:
+        o.set_option("q8_bwd_grid", 0)
+    ref = dy[:64].float() @ w.float()
+    assert (outs[0][0][:64].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
+
+
 def test_gemm_full_size_kernels_agree(dev):
     """BASELINE configs[1] sizes (timm Mlp.fc1 of the encoder at B=256: 12800 x 3072 x 768): forward with bias + GELU + saved
     pre-activation, data gradient through GELU', weight + bias gradient -- the persistent kernel against the 128^2 kernel on the

@@ -770,11 +770,12 @@ def test_production_kernel_selection_matches_oracle_bf16(dev, B):
     model = me.ecamp(compute_dtype=torch.bfloat16)
     model.load_state_dict(state, strict=True)
     model.to(dev).eval()
-    q0, w0 = int(lib.ecamp_gemm_q8_launches()), int(lib.ecamp_wgrad_group_launches())
+    q0, w0, s0 = int(lib.ecamp_gemm_q8_launches()), int(lib.ecamp_wgrad_group_launches()), int(lib.ecamp_gemm_q16_launches())
     out = model(batch, mask_ratio=0.75, noise=noise)
     sum(out).backward()
     torch.cuda.synchronize()
     nq, nw = int(lib.ecamp_gemm_q8_launches()) - q0, int(lib.ecamp_wgrad_group_launches()) - w0
+    n16 = int(lib.ecamp_gemm_q16_launches()) - s0
     got = np.array([t.item() for t in out])
     params = dict(model.named_parameters())
     names = [n for n in orc.trainable_names(cfg) if params[n].grad is not None]
@@ -790,9 +791,11 @@ def test_production_kernel_selection_matches_oracle_bf16(dev, B):
     ref = orc.forward(P, cfg, batch, 0.75, noise)
     sum(ref).backward()
     want = np.array([t.item() for t in ref])
-    print("B=%d: Q8 launches %d, grouped weight-gradient launches %d; oracle fwd+bwd %.1f s" % (B, nq, nw, time.time() - t0))
+    print("B=%d: Q8 launches %d (of them %d on the four-wave 16x16x32 kernel), grouped weight-gradient launches %d; oracle fwd+bwd %.1f s"
+          % (B, nq, n16, nw, time.time() - t0))
     print("  losses hip", got, "oracle", want, "rel", np.abs(got - want) / want)
     assert nq > 150 and nw >= 20, (nq, nw)     # the persistent kernel and the grouped launches (one per transformer block) are what ran
+    assert n16 >= 60, n16                      # the four-wave kernel -- the default of every 768-wide output -- is part of what was compared
     assert (np.abs(got - want) / want).max() < 3e-2
     names = [n for n in names if P[n].grad is not None]     # the two pooler tensors have no gradient in the reference
     ref_n = np.array([P[n].grad.double().norm().item() for n in names])

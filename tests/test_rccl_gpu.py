@@ -35,13 +35,20 @@ def _run_ranks(tmp_path, tag, world=WORLD, **env):
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **{k: str(v) for k, v in env.items()})
     worker = os.path.join(ROOT, "tests", "_rccl_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out], cwd=ROOT, env=e) for r in range(world)]
-    try:
-        rcs = [p.wait(timeout=900) for p in procs]
+    import time
+    t_end = time.time() + 900
+    try:   # poll ALL ranks: when one dies the others sit in an RCCL collective for ever -- stop them at once instead of after the timeout
+        while True:
+            rcs = [p.poll() for p in procs]
+            if all(rc is not None for rc in rcs) or any(rc not in (None, 0) for rc in rcs) or time.time() > t_end:
+                break
+            time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    assert rcs == [0] * world, rcs
+                p.wait()
+    assert rcs == [0] * world, "rank exit codes %s (None = still running when another rank failed or the 900 s limit passed)" % (rcs,)
     return torch.load(out, map_location="cpu")
 
 

@@ -6,7 +6,9 @@
 1. gemm_q8.h (and gemm_q16.h in its 192-column form) request a tile's bias with eight (six) inline-asm `buffer_load_dwordx4` whose results land asynchronously; hipcc treats the
    outputs as defined at the asm statement.  Between the loads and the counted `s_waitcnt vmcnt` that lands them (the first K tile's
    DMA wait) NO instruction may name one of the 32 (24) destination registers -- a copy or a spill there would read them before the data
-   arrived.  Checked for every persistent kernel that carries such a group.
+   arrived.  Checked for every persistent kernel that carries such a group, in program order up to the first wait that CAN land them:
+   vector-memory operations retire in order, so a `vmcnt(N)` with N above the number of vector-memory operations between it and the
+   group lands nothing of it and the scan continues behind it.  `python -m ecamp_amd.build` runs this check and fails on a problem.
 2. Inside those asm statements a scalar register written by a VALU instruction (v_readlane: the kernels spill scalars) must not be read
    by a VMEM instruction within five wait states; the statement starts with `s_nop 4` for that reason -- checked: every group of
    asm bias loads is preceded by it.
@@ -51,6 +53,18 @@ def regs_of(line):
     return found
 
 
+VMEM = re.compile(r"^\s*(buffer_|global_|flat_|scratch_)(load|store|atomic)")
+
+
+def vmcnt_of(line):
+    """The vmcnt a wait instruction enforces, or None (a wait without a vmcnt field leaves the vector-memory counter alone)."""
+    m = re.search(r"s_waitcnt\b(.*)", line.split("//")[0])
+    if not m:
+        return None
+    v = re.search(r"vmcnt\((\d+)\)", m.group(1))
+    return int(v.group(1)) if v else None
+
+
 def check_kernel(co, name, problems):
     dis = subprocess.run([LLVM + "/llvm-objdump", "-d", co, "--disassemble-symbols=" + name], capture_output=True, text=True, check=True).stdout.splitlines()
     groups, i = 0, 0
@@ -67,11 +81,26 @@ def check_kernel(co, name, problems):
             groups += 1
             if "s_nop 4" not in dis[i - 1]:
                 problems.append("%s: bias loads at line %d are not preceded by s_nop 4" % (name, i))
-            k = j
-            while k < len(dis) and "s_waitcnt vmcnt" not in dis[k]:
+            # In program order up to the wait that can land the group.  Vector-memory operations retire in order, so `vmcnt(N)` lands the
+            # bias loads only if at least N vector-memory operations were issued behind them: a wait whose count exceeds every
+            # vector-memory operation that stands between it and the group cannot be the landing wait on ANY path -- the scan goes on
+            # behind it (round 5 stopped at the first vmcnt of any count).  What this scan does not prove is which of the conditional DMA
+            # issues between the group and the wait run on a given path; that invariant lives in the source (gemm_q8.h: the counted wait is
+            # vmcnt(parts issued for tile t + 2) when another K tile follows and vmcnt(0) before the epilogue) and in the parity tests with
+            # one- and two-K-tile shapes (tests/test_kernels_gpu.py: K = 136, 192, 200, 264).
+            k, upper = j, 0
+            while k < len(dis):
+                n = vmcnt_of(dis[k])
+                if n is not None and n <= upper:
+                    break
                 if regs_of(dis[k]) & dst:
                     problems.append("%s: line %d names a bias register in flight: %s" % (name, k, dis[k].split("//")[0].strip()))
+                    break
+                if VMEM.search(dis[k].split("//")[0]):
+                    upper += 1
                 k += 1
+            else:
+                problems.append("%s: bias loads at line %d: no wait behind them can land them" % (name, i))
         i = j
     return groups
 
