@@ -305,14 +305,37 @@ def main():
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream(dev))
         step_marks.append(ev)
+        host_marks.append(time.perf_counter())
+
+    host_marks = []   # host clock when each step's launches had been queued (beside the device events: is a slow step the GPU's or the host's?)
 
     def step_stats(marks):
-        """ms between consecutive per-step events (call after a synchronize)."""
-        d = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+        """ms between consecutive per-step events (call after a synchronize): min / median / p90 / max, the steps in order, and for
+        the slowest step what the host was doing (ms the host took to queue that step; a host stall shows there, a GPU stall does not)."""
+        seq = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+        d = sorted(seq)
         if not d:
             return None
         q = lambda f: d[min(len(d) - 1, int(f * len(d)))]
-        return {"min": round(d[0], 3), "median": round(q(0.5), 3), "p90": round(q(0.9), 3), "max": round(d[-1], 3)}
+        out = {"min": round(d[0], 3), "median": round(q(0.5), 3), "p90": round(q(0.9), 3), "max": round(d[-1], 3),
+               "steps_over_1p1_median": sum(1 for v in seq if v > 1.1 * q(0.5)), "sequence": [round(v, 2) for v in seq]}
+        if len(host_marks) == len(marks):
+            hq = [1e3 * (b - a) for a, b in zip(host_marks[:-1], host_marks[1:])]
+            out["host_queue_ms"] = {"median": round(sorted(hq)[len(hq) // 2], 3), "max": round(max(hq), 3),
+                                    "of_slowest_step": round(hq[seq.index(d[-1])], 3)}
+        return out
+
+    def runtime_counters():
+        """What can stall a step from outside the kernels: device allocations by the caching allocator (a hipMalloc / hipFree inside a step
+        synchronises the device) and Python's cyclic garbage collector (a generation-2 pass over a large heap takes tens of ms)."""
+        import gc
+        ms = torch.cuda.memory_stats(dev)
+        return {"device_allocs": ms.get("num_device_alloc", 0), "device_frees": ms.get("num_device_free", 0), "alloc_retries": ms.get("num_alloc_retries", 0),
+                "reserved_mb": ms.get("reserved_bytes.all.current", 0) / 2 ** 20, "gc_gen2": gc.get_stats()[2]["collections"],
+                "gc_all": sum(g["collections"] for g in gc.get_stats())}
+
+    def counters_delta(a, b):
+        return {k: (round(b[k] - a[k], 1) if isinstance(b[k], float) else b[k] - a[k]) for k in a}
 
     def run_resident(n):
         nonlocal out
@@ -329,9 +352,11 @@ def main():
     lib = _lib.load()
     if world > 1:
         net.reducer.comm_ms()   # drop the warm-up's records
-    del step_marks[:]
+    del step_marks[:], host_marks[:]
+    c0 = runtime_counters()
     dt = timed(run_resident, args.steps)          # THE metric: K full steps, inputs resident in HBM when the timed region starts
     value_steps = step_stats(step_marks)
+    value_steps["runtime"] = counters_delta(c0, runtime_counters())
     rccl = None
     if world > 1:
         red = net.reducer
@@ -375,9 +400,11 @@ def main():
     run_inclusive(3)
     torch.cuda.synchronize()
     prefetcher.copy_ms()   # drop the priming copies' records
-    del step_marks[:]
+    del step_marks[:], host_marks[:]
+    c0 = runtime_counters()
     dt_host = timed(run_inclusive, args.steps)
     host_steps = step_stats(step_marks)
+    host_steps["runtime"] = counters_delta(c0, runtime_counters())
     h2d_ms, h2d_bytes, h2d_n = prefetcher.copy_ms()
     del pipeline
 

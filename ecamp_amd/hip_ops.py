@@ -627,3 +627,18 @@ def linear_wgrad_async(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None, accumulate
             _side["cb"] = True
         except RuntimeError:  # not inside a backward pass: join immediately
             _join_side()
+
+
+# --------------------------------------------------------------------------------------------- dataset image transform on the device
+def resample_crops_workspace_bytes(B, out, kmax, tmp_rows):
+    return int(_lib.load().ecamp_resample_crops_workspace_bytes(int(B), int(out), int(kmax), int(tmp_rows)))
+
+
+def resample_crops_u8(flat, table, out_t, out, kmax, tmp_rows, max_h, ws, err):
+    """B crops (flat uint8 + int64 table [B, 6], both on the device) -> out_t uint8 [B, out, out]: Pillow's crop().resize(BICUBIC) + flip,
+    byte for byte (csrc/augment.hip; pretrain_datasets.py:47-52)."""
+    _chk(flat, table, out_t, ws, err)
+    assert flat.dtype == torch.uint8 and table.dtype == torch.int64 and table.is_contiguous() and out_t.dtype == torch.uint8 and out_t.is_contiguous()
+    call("ecamp_resample_crops_u8", ptr(flat), ptr(table), ptr(out_t), table.shape[0], int(out), int(kmax), int(tmp_rows), int(max_h), ptr(ws), ws.numel(),
+         ptr(err), stream())
+    return out_t

@@ -80,6 +80,9 @@ def get_args_parser():
     p.add_argument("--synthetic_len", default=4096, type=int, help="samples per epoch of the synthetic dataset")
     p.add_argument("--image_u8", action="store_true", help="compact image schema: the dataset hands over the uint8 grayscale crop [448,448] instead of "
                    "the normalised f32 [3,448,448] (12x fewer bytes through the loader, PCIe and HBM; the kernels normalise on the fly, same bits)")
+    p.add_argument("--image_shard", default="", help="device image pipeline: a uint8 shard of the pre-decoded radiographs in CSV row order "
+                   "(module/pretrain_datasets.py: U8ShardWriter; tools/make_image_shard.py writes one): loader workers hand over the bytes of each sample's crop box, "
+                   "the GPU does RandomResizedCrop's resize + flip + Grayscale, byte for byte what the host transform gives on the same pixels")
     p.add_argument("--profile", action="store_true", help="roctx ranges around every optimizer step and its phases (rocprofv3 --marker-trace)")
     p.add_argument("--no_prefetch", action="store_false", dest="prefetch", help="copy each batch inside forward like the reference does")
     p.set_defaults(prefetch=True)
@@ -105,7 +108,8 @@ def main(args):
     elif os.path.exists(csv):
         from .module.pretrain_datasets import ContextBertDataset
         random.seed(seed)  # the item pipeline draws from Python's `random` (pretrain_datasets.py:98,121,123)
-        dataset_train = ContextBertDataset(os.path.join(args.data_path), max_caption_length=args.max_caption_length, image_u8=args.image_u8)
+        dataset_train = ContextBertDataset(os.path.join(args.data_path), max_caption_length=args.max_caption_length, image_u8=args.image_u8,
+                                           image_shard=args.image_shard or None)
         if misc.is_main_process():
             from .module.pretrain_datasets import measure_item_rate
             rate = measure_item_rate(dataset_train)

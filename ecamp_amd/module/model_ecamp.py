@@ -327,7 +327,15 @@ class ECAMP(nn.Module):
         from ..functions import DecStemFn, ImgLossFn, NormFn, StemFn, VitBlockFn
         A = self.prepare()
         dev = A.device
-        img = batch["image"]
+        if "image" not in batch and "image_crops" in batch:
+            # device image pipeline (pretrain_datasets.DeviceAugmenter, csrc/augment.hip): the loader handed over the BYTES of each sample's
+            # crop box + a table; RandomResizedCrop's resize, the flip and Grayscale run here, Pillow-exact -> the uint8 schema below
+            if getattr(self, "_augmenter", None) is None or self._augmenter.device != dev or self._augmenter.size != 2 * self.img_size:
+                from .pretrain_datasets import DeviceAugmenter
+                self._augmenter = DeviceAugmenter(dev, size=2 * self.img_size)
+            img = self._augmenter(batch["image_crops"], batch["image_table"])
+        else:
+            img = batch["image"]
         if img.dtype == torch.uint8:
             # compact schema (ecamp_amd.data / ContextBertDataset(image_u8=True)): the grayscale crop itself, [B, 2R, 2R] or [B, 1, 2R, 2R];
             # the bicubic and SR-loss kernels normalise it on the fly -- same bits as the f32 [B, 3, 2R, 2R] image, a twelfth of the bytes
@@ -345,7 +353,7 @@ class ECAMP(nn.Module):
         want = (2 * self.img_size, 2 * self.img_size) if big.dtype == torch.uint8 else (3, 2 * self.img_size, 2 * self.img_size)
         if tuple(big.shape[1:]) != want:
             raise ValueError("image must be f32 [B,3,%d,%d] or uint8 [B,%d,%d] (2x the encoder resolution), got %s %s"
-                             % (2 * self.img_size, 2 * self.img_size, 2 * self.img_size, 2 * self.img_size, big.dtype, tuple(batch["image"].shape)))
+                             % (2 * self.img_size, 2 * self.img_size, 2 * self.img_size, 2 * self.img_size, big.dtype, tuple(img.shape)))
         if noise is not None:
             noise = noise.to(dev, dtype=torch.float32).contiguous()
 

@@ -158,38 +158,56 @@ def pil_loader(path: str):
         return img.convert('RGB')
 
 
+def random_resized_crop_params(width, height, scale=(0.2, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """torchvision 0.14.1 `RandomResizedCrop.get_params` (transforms/transforms.py; the reference's first transform,
+    pretrain_datasets.py:48) restated: (top i, left j, h, w) of the crop, drawn from torch's GLOBAL generator with the same calls in
+    the same order, so a worker seeded like the reference's draws the reference's boxes.  Two details that matter for equal boxes:
+    the log-ratio bounds are float32 (`torch.log(torch.tensor(ratio))`) and the aspect ratio is exp'ed in float32 before `.item()`;
+    after ten misses the fallback is the ratio-clamped CENTRAL crop (whole width at ratio 3/4 for a narrow image, whole height at
+    4/3 for a wide one, else the whole image) -- rounds 1-5 took a min-side square there."""
+    import math
+    area = height * width
+    log_ratio = torch.log(torch.tensor(ratio))
+    for _ in range(10):
+        target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+        aspect_ratio = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+        w = int(round(math.sqrt(target_area * aspect_ratio)))
+        h = int(round(math.sqrt(target_area / aspect_ratio)))
+        if 0 < w <= width and 0 < h <= height:
+            i = torch.randint(0, height - h + 1, size=(1,)).item()
+            j = torch.randint(0, width - w + 1, size=(1,)).item()
+            return i, j, h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+def random_flip():
+    """torchvision `RandomHorizontalFlip.forward`: `torch.rand(1) < p` with p = 0.5 (pretrain_datasets.py:49)."""
+    return bool(torch.rand(1) < 0.5)
+
+
 def default_image_transform(size=448, image_u8=False):
     """pretrain_datasets.py:47-52 (RandomResizedCrop(448, scale=(0.2,1), bicubic) / flip / grayscale x3 / normalise) with PIL and
-    torch only (torchvision is not a dependency).  Draws from the torch RNG as torchvision's transforms do, so Python's `random`
-    stream -- which the text half of the item consumes -- is left exactly as in the reference.
+    torch only (torchvision is not a dependency).  Draws from the torch RNG as torchvision's transforms do
+    (`random_resized_crop_params`, `random_flip`), so Python's `random` stream -- which the text half of the item consumes -- is left
+    exactly as in the reference.
     image_u8: stop before ToTensor / Normalize and return the grayscale crop itself, uint8 [size, size] -- one byte per pixel instead
     of twelve through the DataLoader, pinned memory, PCIe and HBM; the model's kernels normalise it on the fly to the same bits."""
-    import math
-
-    import numpy as np
     from PIL import Image
-
-    def uni(a, b):
-        return float(torch.empty(1).uniform_(a, b).item())
 
     def tf(img):
         w, h = img.size
-        area = w * h
-        box = None
-        for _ in range(10):  # torchvision RandomResizedCrop.get_params
-            target = area * uni(0.2, 1.0)
-            ar = math.exp(uni(math.log(3.0 / 4.0), math.log(4.0 / 3.0)))
-            cw, ch = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
-            if 0 < cw <= w and 0 < ch <= h:
-                top = int(torch.randint(0, h - ch + 1, (1,)).item())
-                left = int(torch.randint(0, w - cw + 1, (1,)).item())
-                box = (left, top, left + cw, top + ch)
-                break
-        if box is None:
-            s = min(w, h)
-            box = ((w - s) // 2, (h - s) // 2, (w - s) // 2 + s, (h - s) // 2 + s)
-        img = img.crop(box).resize((size, size), Image.BICUBIC)
-        if float(torch.rand(1).item()) < 0.5:
+        i, j, ch, cw = random_resized_crop_params(w, h)
+        img = img.crop((j, i, j + cw, i + ch)).resize((size, size), Image.BICUBIC)   # torchvision F.resized_crop on a PIL image
+        if random_flip():
             img = img.transpose(Image.FLIP_LEFT_RIGHT)
         if image_u8:
             return torch.from_numpy(np.array(img.convert('L'), dtype=np.uint8))
@@ -200,13 +218,140 @@ def default_image_transform(size=448, image_u8=False):
     return tf
 
 
+# ---- the image half on the device (csrc/augment.hip) --------------------------------------------------------------
+# At 7 k pairs/s per GPU the per-sample PIL path above cannot feed the trainer (tools/loader_rate.py: a full-size MIMIC-CXR JPEG costs a
+# worker tens of milliseconds to decode and resample).  The path below keeps the reference's RESULT and moves the work: radiographs are
+# decoded ONCE, offline, into uint8 grayscale shards (`U8ShardWriter`); a loader worker only draws the crop box and the flip (the same
+# torch-RNG calls in the same order) and copies the box's bytes; the device resamples every crop of the batch to 448 x 448 with
+# Pillow's exact integer arithmetic (`DeviceAugmenter` -> ecamp_resample_crops_u8) and hands the model the uint8 [B, 448, 448] schema
+# it already reads.  Byte for byte the `image_u8` item of `default_image_transform` on the same stored pixels (tests/test_augment.py).
+
+
+class U8ShardWriter:
+    """Pre-decoded radiographs, back to back in one flat uint8 file + an index [N, 3] = (byte offset, H, W) (`<path>.idx.npy`).
+    `add` takes a PIL image or a uint8 [H, W] array; colour inputs go through PIL's convert('L') -- for MIMIC-CXR-JPG (grayscale JPEGs
+    the reference opens as RGB, pretrain_datasets.py:28-31) that is the identity on the common channel.  `max_side`: optionally
+    shrink the stored image so that its longer side is at most that many pixels (Pillow bicubic) -- a LOSSY choice of the user
+    (the reference crops from the full-size image); without it the crops are the reference's pixels."""
+
+    def __init__(self, path, max_side=None):
+        self.path, self.max_side = path, max_side
+        self.f = open(path, "wb")
+        self.index = []
+
+    def add(self, img):
+        from PIL import Image
+        if not isinstance(img, Image.Image):
+            img = Image.fromarray(np.ascontiguousarray(img, dtype=np.uint8), "L")
+        img = img.convert("L")
+        if self.max_side and max(img.size) > self.max_side:
+            r = self.max_side / float(max(img.size))
+            img = img.resize((max(1, int(round(img.size[0] * r))), max(1, int(round(img.size[1] * r)))), Image.BICUBIC)
+        a = np.asarray(img, dtype=np.uint8)
+        self.index.append((self.f.tell(), a.shape[0], a.shape[1]))
+        self.f.write(a.tobytes())
+        return len(self.index) - 1
+
+    def close(self):
+        self.f.close()
+        np.save(self.path + ".idx.npy", np.asarray(self.index, dtype=np.int64).reshape(-1, 3))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class U8ShardReader:
+    """Memory-mapped view of a `U8ShardWriter` file: `reader[i]` -> uint8 [H, W] (no copy, no decode)."""
+
+    def __init__(self, path):
+        self.index = np.load(path + ".idx.npy")
+        self.data = np.memmap(path, dtype=np.uint8, mode="r")
+
+    def __len__(self):
+        return len(self.index)
+
+    def __getitem__(self, i):
+        off, h, w = (int(v) for v in self.index[i])
+        return self.data[off:off + h * w].reshape(h, w)
+
+
+def device_crop_item(image):
+    """The loader worker's share of the device path: draw the crop box and the flip exactly as `default_image_transform` does (same
+    torch-RNG calls, same order) and return the BOX's bytes, contiguous uint8 [h, w], + the flip.  `image`: uint8 [H, W] (a shard
+    view) or a PIL image."""
+    if not isinstance(image, np.ndarray):
+        image = np.asarray(image.convert("L"), dtype=np.uint8)
+    H, W = image.shape
+    i, j, h, w = random_resized_crop_params(W, H)
+    flip = random_flip()
+    return np.ascontiguousarray(image[i:i + h, j:j + w]), flip
+
+
+def pack_crops(items, pin=False):
+    """Batch of `device_crop_item` results -> (flat uint8 tensor of all crops back to back, int64 table [B, 6] for
+    ecamp_resample_crops_u8: byte offset, h, w, flip, first intermediate row, 0)."""
+    sizes = [c.shape for c, _ in items]
+    total = sum(h * w for h, w in sizes)
+    flat = torch.empty((total,), dtype=torch.uint8, pin_memory=pin)
+    table = torch.zeros((len(items), 6), dtype=torch.int64, pin_memory=pin)
+    fa = flat.numpy()
+    off = row = 0
+    for n, (c, flip) in enumerate(items):
+        h, w = c.shape
+        fa[off:off + h * w] = c.reshape(-1)
+        table[n, 0], table[n, 1], table[n, 2], table[n, 3], table[n, 4] = off, h, w, int(flip), row
+        off += h * w
+        row += h
+    return flat, table
+
+
+class DeviceAugmenter:
+    """crops (flat uint8 + table, host or device) -> uint8 [B, size, size] on the device: RandomResizedCrop's resize + flip + Grayscale,
+    Pillow-exact (csrc/augment.hip).  The workspace grows to the largest batch seen and is reused (kernels never allocate)."""
+
+    def __init__(self, device, size=448):
+        self.device, self.size = torch.device(device), size
+        self.ws = None
+        self.err = torch.zeros((1,), dtype=torch.int32, device=self.device)
+
+    @staticmethod
+    def taps(max_side, size):
+        """Pillow's ksize for the batch's largest scale factor: 2 * ceil(2 * max(1, max_side / size)) + 1."""
+        import math
+        return 2 * int(math.ceil(2.0 * max(1.0, max_side / float(size)))) + 1
+
+    def __call__(self, flat, table, check=False):
+        from .. import hip_ops as ops
+        tab_host = table if table.device.type == "cpu" else table.cpu()
+        B = tab_host.shape[0]
+        hs, ws_ = tab_host[:, 1], tab_host[:, 2]
+        kmax = self.taps(int(max(hs.max(), ws_.max())), self.size)
+        rows, max_h = int(hs.sum()), int(hs.max())
+        need = ops.resample_crops_workspace_bytes(B, self.size, kmax, rows)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        out = torch.empty((B, self.size, self.size), dtype=torch.uint8, device=self.device)
+        ops.resample_crops_u8(flat.to(self.device, non_blocking=True), table.to(self.device, non_blocking=True), out, self.size, kmax, rows, max_h,
+                              self.ws, self.err)
+        if check and int(self.err.item()) != 0:
+            raise RuntimeError("ecamp_resample_crops_u8: a crop needed more taps than the table was sized for")
+        return out
+
+
 class ContextBertDataset(Dataset):
     """Same constructor and item tuple as the reference class (pretrain_datasets.py:34-199).  `data_root` holds
     `mimic_wordpiece.json`, `mimic-cxr-2.0.0-entity-llm.csv` (img_path, report, llm_output) and
     `mimic-cxr-2.0.0-attn-label.csv` (label_i, label_j)."""
 
-    def __init__(self, data_root, max_caption_length: int = 256, transform=None, image_u8=False):
+    def __init__(self, data_root, max_caption_length: int = 256, transform=None, image_u8=False, image_shard=None):
+        """image_shard: path of a `U8ShardWriter` file holding the radiographs of the CSV in row order, pre-decoded -- the DEVICE image
+        pipeline: an item then carries the bytes of its crop box instead of a resampled image (`device_crop_item`), `collate_fn` packs
+        them (`image_crops`, `image_table`) and `ECAMP.forward` resamples the batch on the GPU (same uint8 item, byte for byte)."""
         import tokenizers
+        self.shard = U8ShardReader(image_shard) if image_shard else None
         self.max_caption_length = max_caption_length
         self.data_root = data_root
         self.images_list, self.report_list, self.llm_out_list, self.attn_i_list, self.attn_j_list = self.read_csv()
@@ -239,7 +384,10 @@ class ContextBertDataset(Dataset):
         return ids, attention_mask, type_ids, masked_ids, weights
 
     def __getitem__(self, index):
-        image = self.transform(pil_loader(self.images_list[index]))
+        if getattr(self, "shard", None) is not None:
+            image = device_crop_item(self.shard[index])          # (uint8 [h, w] crop bytes, flip): same RNG draws as self.transform
+        else:
+            image = self.transform(pil_loader(self.images_list[index]))
         ids, attention_mask, type_ids, masked_ids, weights = self.text_item(index)
         column = torch.tensor(self.attn_i_list[index]).unsqueeze(0)
         row = torch.tensor(self.attn_j_list[index]).unsqueeze(0)
@@ -248,8 +396,12 @@ class ContextBertDataset(Dataset):
     def collate_fn(self, instances: List[Tuple]):
         cols = list(zip(*instances))
         st = lambda i: torch.cat(cols[i], 0)   # items are [1, L] / [1]: concatenating keeps the batch dimension at B == 1
-        return {"image": torch.stack(cols[0]), "labels": st(1), "attention_mask": st(2), "type_ids": st(3), "ids": st(4),
-                "weights": st(5), "column": st(6), "row": st(7)}
+        out = {"labels": st(1), "attention_mask": st(2), "type_ids": st(3), "ids": st(4), "weights": st(5), "column": st(6), "row": st(7)}
+        if getattr(self, "shard", None) is not None:
+            out["image_crops"], out["image_table"] = pack_crops(cols[0])
+        else:
+            out["image"] = torch.stack(cols[0])
+        return out
 
 
 class DeviceMasker:

@@ -201,6 +201,17 @@ int ecamp_im2col_gather(const float* imgs, const int32_t* ids_keep, void* out, i
                         int32_t p, int32_t dtype, ecampStream_t stream); /* model_ecamp.py:220 + :185 */
 int ecamp_assemble_tokens(void* x, const float* cls, const float* pos, const int32_t* ids_keep, int64_t B, int32_t Lk, int32_t D,
                           int32_t dtype, ecampStream_t stream); /* model_ecamp.py:222,228-230 */
+/* The dataset's image transform on the device (pretrain_datasets.py:47-52,113-115: RandomResizedCrop(448, bicubic) + RandomHorizontalFlip +
+ * Grayscale): B crops of a pre-decoded uint8 grayscale radiograph -> dst uint8 [B, out, out], equal BYTE FOR BYTE to
+ * PIL's img.crop(box).resize((out, out), BICUBIC) (+ FLIP_LEFT_RIGHT, convert('L')) on the same pixels -- Pillow's two-pass antialiased
+ * resample (Resample.c: double-precision coefficients -> 22-bit fixed point, uint8 intermediate) restated in csrc/augment.hip.
+ * src: the crops' bytes back to back (each h x w, contiguous); table int64 [B, 6] on the device = {byte offset in src, h, w, flip (0/1),
+ * first row of the sample in the intermediate (prefix sum of h), 0}; kmax >= the tap count of the batch's largest scale factor
+ * (2 * ceil(2 * max(1, size / out)) + 1); tmp_rows = sum of h; max_h = largest h; ws from ecamp_resample_crops_workspace_bytes;
+ * err_flag: int32 on the device, set to 1 if a sample needs more than kmax taps (the result is then undefined). */
+int64_t ecamp_resample_crops_workspace_bytes(int64_t B, int32_t out, int32_t kmax, int64_t tmp_rows);
+int ecamp_resample_crops_u8(const uint8_t* src, const int64_t* table, uint8_t* dst, int64_t B, int32_t out, int32_t kmax, int64_t tmp_rows,
+                            int32_t max_h, void* ws, int64_t ws_bytes, int32_t* err_flag, ecampStream_t stream);
 int ecamp_unshuffle_fwd(const void* y, const int32_t* ids_restore, const float* mask_token, const float* dpos, void* xd, int64_t B,
                         int32_t L, int32_t Lk, int32_t D, int32_t dtype, ecampStream_t stream); /* model_ecamp.py:245-251 */
 int ecamp_unshuffle_bwd(const void* dxd, const int32_t* ids_restore, const int32_t* ids_keep, void* dy, float* dmask_token,
