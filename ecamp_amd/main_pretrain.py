@@ -80,6 +80,9 @@ def get_args_parser():
     p.add_argument("--synthetic_len", default=4096, type=int, help="samples per epoch of the synthetic dataset")
     p.add_argument("--image_u8", action="store_true", help="compact image schema: the dataset hands over the uint8 grayscale crop [448,448] instead of "
                    "the normalised f32 [3,448,448] (12x fewer bytes through the loader, PCIe and HBM; the kernels normalise on the fly, same bits)")
+    p.add_argument("--loss_scale", default="none", choices=["none", "dynamic"], help="dynamic: the reference's torch.cuda.amp.GradScaler() semantics "
+                   "(util/misc.py:251-271: loss x scale, inf / nan check, skipped step + backoff, growth every 2000 clean steps; the scaler state of a "
+                   "reference checkpoint is continued).  none (default): bf16 / f32 need no loss scaling, the scale is 1")
     p.add_argument("--image_shard", default="", help="device image pipeline: a uint8 shard of the pre-decoded radiographs in CSV row order "
                    "(module/pretrain_datasets.py: U8ShardWriter; tools/make_image_shard.py writes one): loader workers hand over the bytes of each sample's crop box, "
                    "the GPU does RandomResizedCrop's resize + flip + Grayscale, byte for byte what the host transform gives on the same pixels")
@@ -162,7 +165,7 @@ def main(args):
     param_groups = optim_factory.add_weight_decay(model_without_ddp, args.weight_decay)
     optimizer = optim_factory.FusedAdamW(param_groups, lr=args.lr, betas=(0.9, 0.95))
     print(optimizer)
-    loss_scaler = NativeScaler()
+    loss_scaler = NativeScaler(dynamic=(args.loss_scale == "dynamic"))
     if args.output_dir and misc.is_main_process():
         dump(os.path.join(args.output_dir, "config.yaml"), args)
     misc.load_model(args=args, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler)

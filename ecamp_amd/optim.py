@@ -1,9 +1,20 @@
 """Optimizer side of the hot path: timm's decay / no-decay parameter grouping (timm 0.4.12
 optim_factory.add_weight_decay, call site main_pretrain.py:253) and AdamW(betas=(0.9, 0.95)) (:254) as ONE fused
 HIP launch over the parameter arena (ecamp_adamw_grouped), which also refreshes the bf16 shadow weights."""
+import collections
+import os
+
 import torch
 
 from . import hip_ops as ops
+
+# How many (micro-)steps the host may queue ahead of the GPU.  The host queues a step in ~15 ms, the GPU runs it in ~36: unbounded, the
+# host's lead grows by 20 ms per step, and every tensor a side stream reads (record_stream: the weight-gradient stream's x and dy, i.e.
+# most saved activations, ~10 GB per step) is only returned to the caching allocator when the GPU gets there -- round 6's bench record
+# showed 250-570 hipMalloc calls and 27-60 GB of reserve growth inside 20 timed steps, and steps of 2x the median when such a burst met
+# a small lead (BENCH_r05's 40.7 ms mean).  Two steps in flight keep the GPU fed through any host hiccup shorter than ~70 ms and the
+# reserve at its steady state after the warm-up.  0 = unbounded (the old behaviour).
+MAX_STEPS_IN_FLIGHT = int(os.environ.get("ECAMP_MAX_STEPS_IN_FLIGHT", "2"))
 
 
 def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
@@ -37,6 +48,18 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self.grad_scale = 1.0
         self.bucketwise_steps = 0   # optimizer steps that ran bucket by bucket behind the gradient all-reduces
+        self._inflight = collections.deque()
+
+    def pace(self):
+        """Called where a (micro-)step ends: records an event on the compute stream and blocks the host until the step
+        MAX_STEPS_IN_FLIGHT back has finished on the GPU (see MAX_STEPS_IN_FLIGHT).  No device-wide synchronisation."""
+        if MAX_STEPS_IN_FLIGHT <= 0 or not torch.cuda.is_available():
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._inflight.append(ev)
+        while len(self._inflight) > MAX_STEPS_IN_FLIGHT:
+            self._inflight.popleft().synchronize()
 
     @property
     def arena(self):
@@ -101,6 +124,7 @@ class FusedAdamW(torch.optim.Optimizer):
             A.flush_fresh()
             self._launch(A, 0, A.total, grad_sumsq)
         A.version += 1   # the bf16 shadows changed: the fp8-forward mode re-quantises its weight copies on next use
+        self.pace()
         return loss
 
     def covers(self, parameters):

@@ -9,6 +9,7 @@ averaged (the reference forces 4 host syncs per micro-step, main_pretrain.py:143
 """
 import builtins
 import datetime
+import math
 import os
 import time
 from collections import deque
@@ -265,18 +266,83 @@ _FUSED_GRAD_NORM = os.environ.get("ECAMP_FUSED_GRAD_NORM", "1") != "0"   # 0: se
 
 
 class NativeScalerWithGradNormCount:
-    """Call signature and return value of misc.py:251-277.  bf16 / f32 training needs no loss scaling, so the scale is
-    identically 1 (`state_dict` keeps the GradScaler keys so reference checkpoints round-trip)."""
+    """Call signature and return value of misc.py:251-277.
+
+    Two modes.  Default (`dynamic=False`): bf16 / f32 training needs no loss scaling, the scale is identically 1 (the state dict keeps
+    GradScaler's keys so a reference checkpoint round-trips).  `dynamic=True` (`main_pretrain.py --loss_scale dynamic`,
+    env ECAMP_LOSS_SCALE=dynamic) is the reference's `torch.cuda.amp.GradScaler()` restated (torch 1.13.1 grad_scaler.py; defaults
+    init_scale 65536, growth 2, backoff 0.5, growth_interval 2000): the loss is multiplied by the scale before backward; at an update step
+    the gradients are checked for inf / nan and un-scaled, the returned norm is that of the un-scaled gradients (inf / nan when the step
+    overflowed, as the reference's get_grad_norm_ after unscale_), the optimizer step is SKIPPED on overflow, then the scale backs off
+    (x 0.5, growth tracker to 0) or, after `growth_interval` clean steps in a row, grows (x 2).  A reference checkpoint's scaler state is
+    loaded and continued.  On the arena path the check is one sum-of-squares pass over the flat gradient buffer (a non-finite sum <=> a
+    non-finite element, up to |g| > 1.8e19), the un-scaling is folded into AdamW's read of the gradient (`grad_scale`) and into the norm:
+    p.grad keeps the SCALED values until zero_grad().  One host read of the check per optimizer step -- GradScaler.step does the same
+    (`found_inf.item()`).  Activations stay bf16: fp16 autocast (main_pretrain.py:139) is not built."""
     state_dict_key = "amp_scaler"
 
-    def __init__(self):
-        self._state = {"scale": 1.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
+    def __init__(self, dynamic=None, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        if dynamic is None:
+            dynamic = os.environ.get("ECAMP_LOSS_SCALE", "none") == "dynamic"
+        self.dynamic = bool(dynamic)
+        self._state = {"scale": float(init_scale) if self.dynamic else 1.0, "growth_factor": float(growth_factor), "backoff_factor": float(backoff_factor),
+                       "growth_interval": int(growth_interval), "_growth_tracker": 0}
+        self.skipped_steps = 0      # optimizer steps skipped because a gradient overflowed (dynamic mode)
+        self.last_found_inf = False
+
+    def get_scale(self):
+        return self._state["scale"]
+
+    def _update(self, found_inf):
+        """GradScaler.update() (grad_scaler.py: _amp_update_scale_)."""
+        st = self._state
+        if found_inf:
+            st["scale"] *= st["backoff_factor"]
+            st["_growth_tracker"] = 0
+        else:
+            st["_growth_tracker"] += 1
+            if st["_growth_tracker"] == st["growth_interval"]:
+                st["scale"] *= st["growth_factor"]
+                st["_growth_tracker"] = 0
+
+    def _dynamic_step(self, optimizer, clip_grad, parameters):
+        """unscale_ + grad norm + scaler.step + scaler.update of misc.py:262-269 for the scaled gradients sitting in p.grad."""
+        scale = self._state["scale"]
+        inv = 1.0 / scale
+        ps = list(parameters) if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]]
+        arena = getattr(ps[0], "_ecamp_arena", None) if ps else None
+        fused = (clip_grad is None and arena is not None and hasattr(optimizer, "covers") and optimizer.covers(ps)
+                 and all(getattr(p, "_ecamp_arena", None) is arena for p in ps))
+        if fused:
+            from .. import hip_ops as ops
+            s = ops.zeros((1,), arena.device)
+            ops.sumsq(arena.flat_g, s)                       # over the SCALED gradients: one pass, no per-tensor launches
+            found_inf = not math.isfinite(float(s))          # the one host read of the step (GradScaler.step: found_inf.item())
+            norm = (s.sqrt() * inv).reshape(())              # inf / nan on overflow, like the reference's norm of the unscaled gradients
+            if not found_inf:
+                optimizer.grad_scale = inv                   # AdamW reads g * inv: the un-scaling without a pass of its own
+                try:
+                    optimizer.step()
+                finally:
+                    optimizer.grad_scale = 1.0
+        else:   # any optimizer / CPU tensors / clip_grad: GradScaler's own order of operations in plain torch
+            grads = [p.grad for p in ps if p.grad is not None]
+            for g in grads:
+                g.mul_(inv)
+            found_inf = any(not bool(torch.isfinite(g).all()) for g in grads)
+            norm = torch.nn.utils.clip_grad_norm_(ps, clip_grad) if clip_grad is not None else get_grad_norm_(ps)
+            if not found_inf:
+                optimizer.step()
+        self.last_found_inf = found_inf
+        self.skipped_steps += int(found_inf)
+        self._update(found_inf)
+        return norm
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
         arena = getattr(optimizer, "arena", None) if loss.is_cuda else None
         reducer = getattr(arena, "reducer", None) if arena is not None else None
         lazy = False
-        if (reducer is not None and update_grad and clip_grad is None and not create_graph and _FUSED_GRAD_NORM and _BUCKETWISE_ADAMW
+        if (reducer is not None and update_grad and clip_grad is None and not create_graph and _FUSED_GRAD_NORM and _BUCKETWISE_ADAMW and not self.dynamic
                 and hasattr(optimizer, "step_with_grad_norm") and getattr(reducer, "side", None) is not None
                 and (reducer.world > 1 or reducer.force_comm) and not reducer.host_staged):
             ps = list(parameters) if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]]
@@ -284,11 +350,13 @@ class NativeScalerWithGradNormCount:
         if lazy:
             reducer.lazy = True    # the end-of-backward callback leaves the buckets' events to the optimizer (GradReducer.lazy)
         try:
-            loss.backward(create_graph=create_graph)
+            (loss * self._state["scale"] if self.dynamic else loss).backward(create_graph=create_graph)   # scaler.scale(loss).backward()
         finally:
             if lazy:
                 reducer.lazy = False
         if not update_grad:
+            if hasattr(optimizer, "pace"):
+                optimizer.pace()   # accumulation micro-steps count against the host's lead too (optim.MAX_STEPS_IN_FLIGHT)
             return None
         if lazy:
             reducer.finalize()     # a no-op when the autograd callback has run (then the bucket events are waiting)
@@ -299,6 +367,8 @@ class NativeScalerWithGradNormCount:
             optimizer.flush_grads()  # weights no GEMM wrote this window read as zero (lazy zero_grad)
         if reducer is not None:
             reducer.finalize()  # normally a no-op (the autograd callback has run); the safety net when no callback could be queued
+        if self.dynamic:
+            return self._dynamic_step(optimizer, clip_grad, parameters)
         if clip_grad is not None:
             assert parameters is not None
             norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
@@ -314,7 +384,13 @@ class NativeScalerWithGradNormCount:
         return dict(self._state)
 
     def load_state_dict(self, state_dict):
-        self._state.update({k: v for k, v in state_dict.items() if k in self._state})
+        """GradScaler.load_state_dict's keys.  In dynamic mode the reference's scale and growth tracker are continued; in the default
+        mode the scale stays 1 (a reference checkpoint's 65536 must not scale a loss nobody un-scales)."""
+        keep = {k: v for k, v in state_dict.items() if k in self._state}
+        if not self.dynamic:
+            keep.pop("scale", None)
+            keep.pop("_growth_tracker", None)
+        self._state.update(keep)
 
 
 # --------------------------------------------------------------------------------------------- checkpoints

@@ -1,6 +1,7 @@
 """not gpu: host-side logic of the drop-in surface -- state-dict keys, parameter groups, LR schedule, sin-cos table,
 meters, the synthetic dataset schema, the run.sh command line, and the refusal to run without the HIP device."""
 import argparse
+import math
 import os
 import types
 
@@ -248,3 +249,55 @@ def test_roofline_traffic_is_quoted_only_for_the_sources_it_was_measured_on():
     assert "gemm_source_sha256" in open(os.path.join(root, "tools", "pmc_traffic.py")).read()
     for f in glob.glob(os.path.join(root, "profiles", "r0[1-4]_pmc_traffic.json")):   # the unstamped files of rounds 1-4 can never match
         assert "gemm_source_sha256" not in json.load(open(f))
+
+
+
+def test_dynamic_loss_scaler_follows_torch_grad_scaler():
+    """`NativeScalerWithGradNormCount(dynamic=True)` -- the reference's `torch.cuda.amp.GradScaler()` (util/misc.py:251-271) -- against torch's
+    own GradScaler on the CPU, same model, same batches, an overflow injected on steps 2 and 3 and accumulation over two micro-steps: scale
+    and growth tracker after every update, which steps were skipped, the returned gradient norm (nan / inf on overflow) and the parameters
+    after every step are equal; the state dict round-trips and a non-dynamic scaler ignores a checkpoint's scale."""
+    import copy
+    from ecamp_amd.util.misc import NativeScalerWithGradNormCount
+    torch.manual_seed(0)
+    m_ref = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.GELU(), torch.nn.Linear(8, 3))
+    m_our = copy.deepcopy(m_ref)
+    o_ref = torch.optim.AdamW(m_ref.parameters(), lr=0.05, betas=(0.9, 0.95))
+    o_our = torch.optim.AdamW(m_our.parameters(), lr=0.05, betas=(0.9, 0.95))
+    ref = torch.amp.GradScaler("cpu", init_scale=65536.0, growth_interval=3)
+    our = NativeScalerWithGradNormCount(dynamic=True, growth_interval=3)
+    assert our.state_dict() == ref.state_dict()
+    g = torch.Generator().manual_seed(1)
+    skipped = []
+    for step in range(9):
+        for micro in range(2):
+            x = torch.randn(5, 6, generator=g)
+            boom = float("inf") if (step in (2, 3) and micro == 1) else 1.0
+            upd = micro == 1
+            l_ref = m_ref(x).pow(2).mean() * boom / 2
+            ref.scale(l_ref).backward()
+            if upd:
+                ref.unscale_(o_ref)
+                n_ref = torch.norm(torch.stack([torch.norm(p.grad.detach(), 2.0) for p in m_ref.parameters()]), 2.0)
+                ref.step(o_ref)
+                ref.update()
+                o_ref.zero_grad()
+            l_our = m_our(x).pow(2).mean() * boom / 2
+            n_our = our(l_our, o_our, parameters=m_our.parameters(), update_grad=upd)
+            if upd:
+                o_our.zero_grad()
+                assert our.state_dict() == ref.state_dict(), (step, our.state_dict(), ref.state_dict())
+                assert (math.isnan(float(n_our)) and math.isnan(float(n_ref))) or float(n_our) == float(n_ref), (step, float(n_our), float(n_ref))
+                skipped.append(our.last_found_inf)
+                for a, b in zip(m_our.parameters(), m_ref.parameters()):
+                    assert torch.equal(a, b), step
+            else:
+                assert n_our is None
+    assert skipped == [False, False, True, True, False, False, False, False, False] and our.skipped_steps == 2
+    assert our.get_scale() == ref.get_scale() != 65536.0
+    again = NativeScalerWithGradNormCount(dynamic=True)
+    again.load_state_dict(ref.state_dict())
+    assert again.state_dict() == ref.state_dict()
+    plain = NativeScalerWithGradNormCount()
+    plain.load_state_dict(ref.state_dict())
+    assert plain.get_scale() == 1.0 and set(plain.state_dict()) == set(ref.state_dict())

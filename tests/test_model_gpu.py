@@ -5,6 +5,9 @@ Tolerances: compute_dtype=float32 ("parity mode", exact-f32 MFMA) must match the
 (BASELINE.json north_star); we assert 2e-4 on losses / activations and 1e-3 on gradients.  bf16 mode is checked
 against the same vectors with 3e-2 on losses and 8e-2 on gradient norms (8-bit mantissa activations).
 """
+import math
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -190,6 +193,74 @@ def test_engine_step_matches_reference(dev):
     for n, p in params.items():
         if "pooler" in n:
             assert torch.equal(p.detach().cpu(), old[n]), "unused pooler parameters must not move (torch skips grad=None)"
+
+
+def test_dynamic_loss_scale_matches_torch_grad_scaler_on_the_oracle(dev):
+    """VERDICT r5 item 7 (util/misc.py:251-271, main_pretrain.py:139-149): `--loss_scale dynamic` on the HIP path -- loss x scale into the
+    backward kernels, ONE sum-of-squares pass as the inf / nan check, the un-scaling folded into AdamW's gradient read, skip + backoff on
+    overflow, growth after `growth_interval` clean steps -- against the oracle model driven by torch's own GradScaler on the host
+    (tiny config, f32 parity mode, eval).  An overflow is injected on step 1 through a report weight of 3e38 (the scaled loss is inf on
+    both sides).  Per optimizer step: the same scale / growth tracker / skip decision, the gradient norm to 1e-3 (nan or inf on the
+    overflow), and after five steps the parameters equal the oracle's to the engine test's bound."""
+    from ecamp_amd import optim
+    from ecamp_amd.util.misc import NativeScalerWithGradNormCount
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    name = "tiny_b4_s128"
+    g = _load(name)
+    B, S = 2, 64
+    model, cfg = _build(name, torch.float32, dev)
+    model.eval()
+    model.prepare()
+    opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
+    ours = NativeScalerWithGradNormCount(dynamic=True, growth_interval=2)
+    opt.zero_grad()
+    # the checker: oracle parameters + torch.optim.AdamW + torch.amp.GradScaler on the host
+    state = recipe.recipe_state(cfg, seed=0)
+    P = orc.set_requires_grad(orc.load_state(orc.new_params(cfg), state), cfg)
+    names = [k for k in orc.trainable_names(cfg)]
+    nd = set(orc.weight_decay_groups(cfg)[0])
+    o_ref = torch.optim.AdamW([{"params": [P[k] for k in names if k in nd], "weight_decay": 0.0},
+                               {"params": [P[k] for k in names if k not in nd], "weight_decay": 0.05}], lr=1.5e-4, betas=(0.9, 0.95))
+    ref = torch.amp.GradScaler("cpu", init_scale=65536.0, growth_interval=2)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    for step in range(5):
+        batch = recipe.recipe_batch(cfg, B, S, seed=40 + step)
+        noise = recipe.recipe_noise(B, cfg.num_patches, seed=40 + step)
+        if step == 1:
+            batch["weights"] = batch["weights"].clone()
+            batch["weights"][0, 3] = 3e38                      # mlm loss ~ 1e37: finite, x 65536+ overflows
+        lr = orc.forward(P, cfg, batch, 0.75, noise)
+        ref.scale(sum(lr)).backward()
+        ref.unscale_(o_ref)
+        gl = [P[k].grad for k in names if P[k].grad is not None]
+        n_ref = torch.norm(torch.stack([torch.norm(t.detach(), 2.0) for t in gl]), 2.0)
+        ref.step(o_ref)
+        ref.update()
+        o_ref.zero_grad()
+        lo = model(batch, noise=noise)
+        n_our = ours(sum(lo), opt, parameters=model.parameters(), update_grad=True)
+        opt.zero_grad()
+        print("  step %d: scale %.0f / %.0f, tracker %d / %d, skipped %s, norm %.6g / %.6g" % (step, ours.get_scale(), ref.get_scale(),
+              ours.state_dict()["_growth_tracker"], ref.state_dict()["_growth_tracker"], ours.last_found_inf, float(n_our), float(n_ref)))
+        assert ours.state_dict() == ref.state_dict(), (step, ours.state_dict(), ref.state_dict())
+        assert ours.last_found_inf == (step == 1)
+        if step == 1:
+            assert not math.isfinite(float(n_our)) and not math.isfinite(float(n_ref))
+        else:
+            assert rel(float(n_our), float(n_ref)) < 1e-3, (step, float(n_our), float(n_ref))
+    assert ours.skipped_steps == 1 and ours.get_scale() == ref.get_scale()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for k in names:
+        if P[k].grad is None and "pooler" in k:
+            continue
+        a, b, o = params[k].detach().float().cpu(), P[k].detach(), state[k]
+        upd_ref = (b - o).abs().max().item()
+        if upd_ref > 0:
+            worst = max(worst, (a - b).abs().max().item() / upd_ref)
+    print("  worst parameter difference relative to the largest update of its tensor after 4 applied steps: %.2e" % worst)
+    assert worst < 5e-2, worst
 
 
 def test_train_mode_dropout_and_determinism(dev):
