@@ -142,20 +142,34 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const T* __restrict
         }
         s1 = wave_sum(s1) / (float)cols;
         s2 = wave_sum(s2) / (float)cols;
+        // A row of an ordinary token goes to its embedding row by atomics.  Issued from the 16-B-per-lane register layout an atomic instruction
+        // touches 4 B in each of 64 chunks 16 B apart (eight 128-B lines a quarter full: 165 us per call at B = 256, the atomic units' line rate);
+        // passed through this wave's LDS row first, lane l adds element 64 k + l: two full lines per instruction (round 6).
+        const bool scatter = id != hot0 && id != hot1 && id != pad_id;   // wave-uniform (one row per wave)
+        float* wrow = sh + wave * cols;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             int c = lane + 64 * i;
             if (c < nv) {
+                float dz4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float dz = rs * (g[i][r] - s1 - xh[i][r] * s2);
+                    dz4[r] = dz;
                     acc[2][i][r] += dz;
                     if (ty == 0) acc[3][i][r] += dz; else acc[4][i][r] += dz;
                     if (id == hot0) acc[5][i][r] += dz;
                     else if (id == hot1) acc[6][i][r] += dz;
-                    else if (id != pad_id) atomicAdd(gword + id * cols + c * 4 + r, dz);
                 }
+                if (scatter) *reinterpret_cast<float4*>(wrow + c * 4) = make_float4(dz4[0], dz4[1], dz4[2], dz4[3]);
             }
+        }
+        if (scatter) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed (the row is private to the wave)
+            __builtin_amdgcn_wave_barrier();
+            float* dst = gword + id * cols;
+            for (int c = lane; c < cols; c += 64) atomicAdd(dst + c, wrow[c]);
+            __builtin_amdgcn_wave_barrier();       // the next row's writes stay behind these reads
         }
     }
     for (int k = 0; k < 7; ++k) {
