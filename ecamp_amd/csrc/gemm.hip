@@ -780,21 +780,6 @@ static double q16_cost(int64_t M, int64_t N, int tn, int ncu) {
     const long tiles = (long)ceil_div(M, 256) * ceil_div(N, tn);
     return (double)((tiles + ncu - 1) / ncu) * (tn == 192 ? 0.79 : 1.0);
 }
-// Slack stagger (gemm_q8.h): ticks of the 100 MHz wall clock the workgroups with one tile fewer start late = pct % of a tile's estimated time
-// (per 256-wide tile: ~8 us of epilogue alone, ~18 us with a second tensor, ~1.5 us per K tile of 64; profiles/r05_epilogue_scale.txt).
-// "stagger" option / ECAMP_GEMM_STAGGER: percent of a tile time (0 = off).
-static int g_stagger_pct = -1;
-static int stagger_pct() {
-    static const int v = getenv("ECAMP_GEMM_STAGGER") ? atoi(getenv("ECAMP_GEMM_STAGGER")) : 0;
-    return g_stagger_pct >= 0 ? g_stagger_pct : v;
-}
-static int stagger_ticks(long total, long grid, int64_t K, int epi, double tile_frac) {
-    const int pct = stagger_pct();
-    if (pct <= 0 || total <= grid || total % grid == 0) return 0;
-    const double a_us = (epi == 1 || epi == 2 || epi == 3) ? 18.0 : 8.0, b_us = 1.5;
-    const double tile_us = tile_frac * (a_us + b_us * (double)((K + 63) / 64));
-    return (int)(tile_us * pct);   // us * 100 ticks/us * pct/100
-}
 typedef void (*q16_fn)(GemmArgs);
 static q16_fn q16_pick(int b_kc, int epi, int nw) {
     if (b_kc) {
@@ -813,7 +798,6 @@ extern "C" int ecamp_set_option(const char* name, int32_t value) {
     if (strcmp(name, "p8_wgrad_reserve_cus") == 0) { g_p8_wgrad_reserve = value < 0 ? 0 : value; return 0; }
     if (strcmp(name, "q8_bwd_grid") == 0) { g_q8_bwd_grid = value < 0 ? 0 : value; return 0; }
     if (strcmp(name, "q8_sch") == 0) { g_q8_sch = value; return 0; }
-    if (strcmp(name, "stagger") == 0) { g_stagger_pct = (value >= 0 && value <= 100) ? value : -1; return 0; }
     if (strcmp(name, "attn_head") == 0) { attn_set_head_mode(value); return 0; }   // attention_bf16.hip: 1 head kernels (default), 0 streaming kernels
     return ecamp_set_error(-1, "set_option: unknown option '%s'", name);
 }
@@ -981,7 +965,6 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
                             const int bg16 = g_q8_bwd_grid > 0 ? g_q8_bwd_grid : env_bwd16;
                             if (!b_kc && bg16 > 0) grid16 = bg16;
                         }
-                        g.dbg = stagger_ticks(total16, grid16, K, epi, nw == 6 ? 0.79 : 1.0);
                         hipLaunchKernelGGL(f16, dim3((unsigned)(total16 < grid16 ? total16 : grid16)), dim3(256), shm16, stream, g);
                         ++g_q16_launches;
                         if (prof16) ecamp_prof_end(stream);
@@ -1016,7 +999,6 @@ extern "C" int ecamp_gemm(const void* A, const void* B, void* C, int64_t M, int6
                 const int bg = g_q8_bwd_grid > 0 ? g_q8_bwd_grid : env_bwd;
                 if (a_kc && !b_kc && bg > 0) ncu = bg;
             }
-            if (a_kc && split_k == 1) g.dbg = stagger_ticks(total8, ncu, K, epi, 1.0);   // forward and data-gradient forms
             hipLaunchKernelGGL(fn, dim3((unsigned)(total8 < ncu ? total8 : ncu)), dim3(512), shm, stream, g);
             ++g_q8_launches;
             if (split_k > 1) {

@@ -353,13 +353,6 @@ __device__ __forceinline__ void q16_body(const GemmArgs& g) {
         rA = Q16_RS(rA, 2); rB = Q16_RS(rB, 2);                                                                          \
     } while (0)
 
-    if (g.dbg > 0) {   // slack stagger: see gemm_q8.h (workgroups that own one tile fewer start g.dbg ticks of the 100 MHz clock late)
-        const int rem = total % G;
-        if (rem != 0 && total > G && (int)blockIdx.x >= rem) {
-            const long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < (long long)g.dbg) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     // prologue: K tiles 0 and 1 issued, K tile 0 landed and published, its first k-step's fragments read
     q_cv(false);
     if (qv < total) Q16_ITEM();

@@ -856,19 +856,6 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         rB = rB + 2 >= NSLOT ? rB + 2 - NSLOT : rB + 2;                                                                  \
     } while (0)
 
-    if (!ITEMS && g.dbg > 0) {
-        // Slack stagger (round 6).  A launch of `total` tiles on G workgroups is floor(total / G) + 1 tiles for the first total % G workgroups
-        // and one tile FEWER for the rest: those start late by g.dbg ticks of the 100 MHz wall clock (half a tile's time, the host's
-        // estimate) -- inside the slack they have anyway, so the launch is not longer -- and from then on run half a period out of phase
-        // with the others: the epilogues of a round no longer hit the memory system from all 256 CUs at once (round 5: a tile's
-        // epilogue costs 8 us alone and 18-19 us with a second tensor when every CU is in it together; a stagger of ALL workgroups
-        // -- DBG 512 below -- cost what it saved).
-        const int rem = total % G;
-        if (rem != 0 && total > G && (int)blockIdx.x >= rem) {
-            const long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < (long long)g.dbg) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     if (DBG & 512) {   // probe: workgroups start in four phases ~9 us apart (are the lock-step epilogue bursts of a round the cost?)
         const long long t0 = wall_clock64();   // 100 MHz
         const long long d = (long long)(blockIdx.x & 3) * 900;
