@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's committed evidence in one GPU call: serialized + production kernel tables, PMC traffic passes, default bench line.
-#   gpurun -- 'bash tools/round_profiles.sh <tag>'   ->  gpurun_out/{kernel_stats_<tag>_serialized.txt, kernel_stats_<tag>_production.txt, r05_pmc_*, bench_<tag>.json}
+#   gpurun -- 'bash tools/round_profiles.sh <tag>'   ->  gpurun_out/{kernel_stats_<tag>_serialized.txt, kernel_stats_<tag>_production.txt, <round>_pmc_*, bench_<tag>.json}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-rXX}
 bash $R/tools/step_kernels.sh ${TAG}_ser 16
