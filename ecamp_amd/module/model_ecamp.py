@@ -333,7 +333,7 @@ class ECAMP(nn.Module):
             if getattr(self, "_augmenter", None) is None or self._augmenter.device != dev or self._augmenter.size != 2 * self.img_size:
                 from .pretrain_datasets import DeviceAugmenter
                 self._augmenter = DeviceAugmenter(dev, size=2 * self.img_size)
-            img = self._augmenter(batch["image_crops"], batch["image_table"])
+            img = self._augmenter(batch["image_crops"], batch["image_table"], meta=batch.get("image_meta"))
         else:
             img = batch["image"]
         if img.dtype == torch.uint8:

@@ -290,6 +290,12 @@ def device_crop_item(image):
     return np.ascontiguousarray(image[i:i + h, j:j + w]), flip
 
 
+def crops_meta(table):
+    """(largest side, sum of h, largest h) of a crop table: what sizes the device call's tap tables and workspace.  Plain Python ints, taken
+    on the host where the table is made, so that the training step never reads the table back from the device."""
+    return int(max(table[:, 1].max(), table[:, 2].max())), int(table[:, 1].sum()), int(table[:, 1].max())
+
+
 def pack_crops(items, pin=False):
     """Batch of `device_crop_item` results -> (flat uint8 tensor of all crops back to back, int64 table [B, 6] for
     ecamp_resample_crops_u8: byte offset, h, w, flip, first intermediate row, 0)."""
@@ -323,13 +329,15 @@ class DeviceAugmenter:
         import math
         return 2 * int(math.ceil(2.0 * max(1.0, max_side / float(size)))) + 1
 
-    def __call__(self, flat, table, check=False):
+    def __call__(self, flat, table, meta=None, check=False):
+        """meta = `crops_meta(table)` made on the host (the collate function's `image_meta`); without it a table that already lives on the
+        device is read back (a host synchronisation: tests only)."""
         from .. import hip_ops as ops
-        tab_host = table if table.device.type == "cpu" else table.cpu()
-        B = tab_host.shape[0]
-        hs, ws_ = tab_host[:, 1], tab_host[:, 2]
-        kmax = self.taps(int(max(hs.max(), ws_.max())), self.size)
-        rows, max_h = int(hs.sum()), int(hs.max())
+        if meta is None:
+            meta = crops_meta(table if table.device.type == "cpu" else table.cpu())
+        B = table.shape[0]
+        max_side, rows, max_h = (int(v) for v in meta)
+        kmax = self.taps(max_side, self.size)
         need = ops.resample_crops_workspace_bytes(B, self.size, kmax, rows)
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
@@ -399,6 +407,7 @@ class ContextBertDataset(Dataset):
         out = {"labels": st(1), "attention_mask": st(2), "type_ids": st(3), "ids": st(4), "weights": st(5), "column": st(6), "row": st(7)}
         if getattr(self, "shard", None) is not None:
             out["image_crops"], out["image_table"] = pack_crops(cols[0])
+            out["image_meta"] = crops_meta(out["image_table"])   # Python ints: stay on the host through the prefetcher
         else:
             out["image"] = torch.stack(cols[0])
         return out

@@ -170,3 +170,40 @@ def test_device_augmenter_at_batch_size(dev):
     print("  device: %d crops (%.0f MB of crop bytes) -> [%d, 448, 448] in %.2f ms; host PIL: %.2f ms per item on one core" %
           (B, flat.numel() / 1e6, B, dev_ms, host_ms))
     assert not bad, bad[:8]
+
+
+@pytest.mark.gpu
+def test_model_forward_on_crops_equals_forward_on_the_host_items(dev):
+    """`ECAMP.forward` on a batch that carries crops (`image_crops` / `image_table` / `image_meta`, the `--image_shard` collate) gives the
+    losses of the same batch with the host-made uint8 items (`image`), through the prefetcher as well (the table and the crop bytes cross PCIe
+    on the copy stream; the Python-int meta stays on the host: no read-back in the step)."""
+    from PIL import Image
+    from ecamp_amd.data import DevicePrefetcher
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.module import pretrain_datasets as pd
+    from oracle import ecamp_oracle as orc
+    from oracle import recipe
+    cfg = orc.cfg_tiny()
+    B, S = 4, 64
+    model = me.ecamp_tiny(compute_dtype=torch.bfloat16)
+    model.load_state_dict(recipe.recipe_state(cfg, seed=0))
+    model.to(dev).eval()
+    batch = recipe.recipe_batch(cfg, B, S, seed=3)
+    noise = recipe.recipe_noise(B, cfg.num_patches, seed=3)
+    imgs = [_radiograph(500 + 60 * k, 420 + 90 * k, 30 + k) for k in range(B)]
+    tf = pd.default_image_transform(448, image_u8=True)
+    host_items, crops = [], []
+    for k, im in enumerate(imgs):
+        torch.manual_seed(700 + k)
+        host_items.append(tf(Image.fromarray(im, "L").convert("RGB")))
+        torch.manual_seed(700 + k)
+        crops.append(pd.device_crop_item(im))
+    rest = {k: v for k, v in batch.items() if k != "image"}
+    a = model(dict(rest, image=torch.stack(host_items)), noise=noise)
+    flat, table = pd.pack_crops(crops, pin=True)
+    crop_batch = dict(rest, image_crops=flat, image_table=table, image_meta=pd.crops_meta(table))
+    b = model(crop_batch, noise=noise)
+    c = [model(x, noise=noise) for x in DevicePrefetcher([crop_batch, crop_batch], dev)][-1]
+    torch.cuda.synchronize()
+    for x, y, z in zip(a, b, c):      # same pixels in, same kernels: equal up to the summation order of the loss sums' f32 atomics
+        assert abs(x.item() - y.item()) <= 1e-5 * abs(x.item()) and abs(x.item() - z.item()) <= 1e-5 * abs(x.item()), (x.item(), y.item(), z.item())
