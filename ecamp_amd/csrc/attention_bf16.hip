@@ -14,6 +14,15 @@
 #include "attention.h"
 #include <type_traits>
 
+// tools/probes/attn_phase_probe.hip compiles this file with -DATTN_TS: wave 0 of every workgroup stamps the 100 MHz wall clock at the phase
+// boundaries of the head-resident kernels (nothing of it exists in the library build)
+#ifdef ATTN_TS
+__device__ long long attn_ts_buf[8 * 8192];
+#define ATTN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) attn_ts_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(4))) short v4s16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
@@ -931,6 +940,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
     const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const HeadOff<HD> off(li, g);
 
+    ATTN_STAMP(0);
     // ---- phase 1: dQ (+ lse, delta -> LDS) -------------------------------------------------------------------------------------
     // the fragments a wave owns come from global memory; the first block's are requested before the staging loads
     bf16x8 qf[HD / 32], gf[HD / 32], of[HD / 32];
@@ -948,6 +958,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
     head_key_bias(KB, a, b, prow, tid, nthr);
     for (int i = ((a.Tq + 15) & ~15) + tid; i < prow; i += nthr) { LS[i] = 1e30f; DL[i] = 0.f; }
     __syncthreads();
+    ATTN_STAMP(1);
     for (int q0 = wave * 16; q0 < a.Tq; q0 += nw * 16) {
         float dl = 0.f;
 #pragma unroll
@@ -1017,6 +1028,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
         }
         if (q0 + nw * 16 < a.Tq) load_q(q0 + nw * 16, qf, gf, of, lse_c);
     }
+    ATTN_STAMP(2);
     // ---- phase 2: dK, dV ---------------------------------------------------------------------------------------------------------
     bf16x8 kf[HD / 32], vf[HD / 32];
     if (wave * 16 < a.Tk) {
@@ -1024,6 +1036,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
         load_row_frags<HD>(vf, vb, a.v_st, wave * 16, a.Tk, lane);
     }
     __syncthreads();
+    ATTN_STAMP(3);
     head_stage_pair<HD, (HD == 128 ? 8 : 4)>(XI, qb, a.q_st, YI, gb, a.do_st, a.Tq, prow, tid, nthr);
     if (use_bits) {   // the head's mask bytes, transposed so that the four query rows of a lane are four consecutive bytes
         for (int i = tid; i < a.Tq * 4; i += nthr) {
@@ -1034,6 +1047,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
         }
     }
     __syncthreads();
+    ATTN_STAMP(4);
     for (int j0 = wave * 16; j0 < a.Tk; j0 += nw * 16) {
         const int kj = j0 + li;
         const bool jok = KB[kj] == 0.f;
@@ -1102,6 +1116,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
             load_row_frags<HD>(vf, vb, a.v_st, j0 + nw * 16, a.Tk, lane);
         }
     }
+    ATTN_STAMP(5);
 }
 
 template <typename K>

@@ -590,6 +590,61 @@ def branch_stream(device):
     return st
 
 
+# ---- tensors a second stream reads ------------------------------------------------------------------------------------------------
+# `t.record_stream(side)` hands the question "when may this block be reused?" to the caching allocator: it answers with an event and keeps
+# the block out of circulation until a LATER allocation call finds the event complete.  Which call that is depends on how far the host
+# runs ahead of the GPU at that moment, so the allocator's steady state never quite arrives: round 6's bench record showed hipMalloc calls
+# inside the timed steps in every run (7-107 even with the host's lead bounded), and one burst of them on a fresh box cost the host 87 ms
+# and the GPU a step of 2x the median.  Instead the tensors are HELD here (a Python reference) until events recorded behind the step on
+# every stream have completed, then dropped: the block goes back to the allocator the ordinary way, reusable at once by its own stream, and
+# the step's allocation pattern is the same every step.  `seal()` is called where a step ends (FusedAdamW.pace) and by `hold` itself every
+# 512 tensors (loops that never reach an optimizer); `reap()` drops what the GPU has finished.  ECAMP_HOLD_TENSORS=0: record_stream as before.
+HOLD_TENSORS = __import__("os").environ.get("ECAMP_HOLD_TENSORS", "1") != "0"
+_held_cur = []
+_held_done = __import__("collections").deque()   # ([events], [tensors]) in seal order
+
+
+def hold(st, *tensors):
+    """`st` (a side stream) reads `tensors`, which live in another stream's pool: keep them alive until that has happened."""
+    if not HOLD_TENSORS:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(st)
+        return
+    _held_cur.extend(t for t in tensors if t is not None)
+    if len(_held_cur) >= 512:
+        seal()
+
+
+def seal():
+    """Close the current set of held tensors behind an event on every stream that may read them (main, weight-gradient, branch); drop the
+    sets whose events have all completed."""
+    global _held_cur
+    if _held_cur:
+        dev = _held_cur[0].device
+        evs = []
+        for st in [torch.cuda.current_stream(dev)] + side_streams(dev):
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        _held_done.append((evs, _held_cur))
+        _held_cur = []
+    reap()
+
+
+def reap(block_first=False):
+    """Drop held sets the GPU is done with (oldest first).  block_first: wait for the oldest one (tests)."""
+    while _held_done:
+        evs, _ = _held_done[0]
+        if block_first:
+            for e in evs:
+                e.synchronize()
+            block_first = False
+        if not all(e.query() for e in evs):
+            break
+        _held_done.popleft()
+
+
 def wgrad_group_async(items, workgroups=0):
     """wgrad_group on the weight-gradient side stream (see linear_wgrad_async)."""
     if not OVERLAP_WGRAD:
@@ -600,8 +655,7 @@ def wgrad_group_async(items, workgroups=0):
     with torch.cuda.stream(st):
         wgrad_group(items, workgroups=workgroups)
     for dy, x, _, _, _ in items:
-        dy.record_stream(st)
-        x.record_stream(st)
+        hold(st, dy, x)
     if not _side.get("cb"):
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join_side)
@@ -617,10 +671,7 @@ def linear_wgrad_async(dy, x, gw, alpha=1.0, alpha_dev=None, gb=None, accumulate
     st.wait_stream(torch.cuda.current_stream())  # dy, x (and earlier accumulations into gw) are ready
     with torch.cuda.stream(st):
         linear_wgrad(dy, x, gw, alpha, alpha_dev, gb, accumulate)
-    dy.record_stream(st)  # the caching allocator must not recycle these while the side stream reads them
-    x.record_stream(st)
-    if alpha_dev is not None:
-        alpha_dev.record_stream(st)
+    hold(st, dy, x, alpha_dev)  # the caching allocator must not recycle these while the side stream reads them
     if not _side.get("cb"):
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join_side)

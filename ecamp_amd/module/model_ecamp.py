@@ -378,12 +378,10 @@ class ECAMP(nn.Module):
             bs.wait_stream(main)
             with torch.cuda.stream(bs):
                 img_losses = image_decoder()
-            for t in (latent, imgs, big, mask, ids_restore, ids_keep, column, row):
-                t.record_stream(bs)
+            ops.hold(bs, latent, imgs, big, mask, ids_restore, ids_keep, column, row)
             mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
             main.wait_stream(bs)
-            for t in img_losses:
-                t.record_stream(main)
+            ops.hold(main, *img_losses)   # (allocated on the branch stream, read by the caller on the main one)
         else:
             img_losses = image_decoder()
             mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)

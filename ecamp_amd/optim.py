@@ -53,13 +53,17 @@ class FusedAdamW(torch.optim.Optimizer):
     def pace(self):
         """Called where a (micro-)step ends: records an event on the compute stream and blocks the host until the step
         MAX_STEPS_IN_FLIGHT back has finished on the GPU (see MAX_STEPS_IN_FLIGHT).  No device-wide synchronisation."""
-        if MAX_STEPS_IN_FLIGHT <= 0 or not torch.cuda.is_available():
+        if not torch.cuda.is_available():
+            return
+        ops.seal()   # tensors the side streams read during this step: held until the GPU is past here (hip_ops.hold)
+        if MAX_STEPS_IN_FLIGHT <= 0:
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._inflight.append(ev)
         while len(self._inflight) > MAX_STEPS_IN_FLIGHT:
             self._inflight.popleft().synchronize()
+        ops.reap()   # the step that wait was for is complete: its held tensors go back to the allocator now
 
     @property
     def arena(self):

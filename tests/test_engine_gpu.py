@@ -181,6 +181,7 @@ def test_bench_driver_protocol_value_is_explained_by_its_own_record(dev):
     616 MB batch hides under a step only while the box's host -> HBM path delivers more than bytes / step time)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.empty_cache()   # the child needs ~60 GB of the card this process may hold in its allocator's cache
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-prof"],
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]

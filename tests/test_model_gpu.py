@@ -251,17 +251,19 @@ def test_dynamic_loss_scale_matches_torch_grad_scaler_on_the_oracle(dev):
             # element whatever the gradient's size) have moved apart by the engine test's few percent of an update: measured 1.0e-3 at step 4
             assert rel(float(n_our), float(n_ref)) < (1e-3 if step == 0 else 5e-3), (step, float(n_our), float(n_ref))
     assert ours.skipped_steps == 1 and ours.get_scale() == ref.get_scale()
+    # parameters: the engine test's sample of tensors (a tensor whose true gradient is zero -- a key bias -- moves by +-lr per element on the
+    # sign of its rounding noise, on both sides independently: only tensors with a real gradient can be compared)
+    from oracle.make_golden import GRAD_SAMPLE_KEYS
     params = dict(model.named_parameters())
     worst = 0.0
-    for k in names:
-        if P[k].grad is None and "pooler" in k:
-            continue
-        a, b, o = params[k].detach().float().cpu(), P[k].detach(), state[k]
-        upd_ref = (b - o).abs().max().item()
-        if upd_ref > 0:
-            worst = max(worst, (a - b).abs().max().item() / upd_ref)
-    print("  worst parameter difference relative to the largest update of its tensor after 4 applied steps: %.2e" % worst)
-    assert worst < 5e-2, worst
+    for k in GRAD_SAMPLE_KEYS:   # the four applied updates as a whole, in the L2 sense (single elements whose gradient is rounding noise flip sign)
+        a, b, o = params[k].detach().float().cpu().double(), P[k].detach().double(), state[k].double()
+        upd = (b - o).norm().item()
+        assert upd > 0, k
+        e = (a - b).norm().item() / upd
+        print("    %-70s |update| %.3e  relative difference %.2e" % (k, upd, e))
+        worst = max(worst, e)
+    assert worst < 1e-1, worst
 
 
 def test_train_mode_dropout_and_determinism(dev):
@@ -867,7 +869,7 @@ def test_production_kernel_selection_matches_oracle_bf16(dev, B):
           % (B, nq, n16, nw, time.time() - t0))
     print("  losses hip", got, "oracle", want, "rel", np.abs(got - want) / want)
     assert nq > 150 and nw >= 20, (nq, nw)     # the persistent kernel and the grouped launches (one per transformer block) are what ran
-    assert n16 >= 60, n16                      # the four-wave kernel -- the default of every 768-wide output -- is part of what was compared
+    assert n16 >= (60 if B >= 256 else 40), n16   # the four-wave kernel -- the default of the 768-wide outputs (114 launches at B = 256, 50 at 128) -- is part of what was compared
     assert (np.abs(got - want) / want).max() < 3e-2
     names = [n for n in names if P[n].grad is not None]     # the two pooler tensors have no gradient in the reference
     ref_n = np.array([P[n].grad.double().norm().item() for n in names])
