@@ -601,7 +601,13 @@ def branch_stream(device):
 # 512 tensors (loops that never reach an optimizer); `reap()` drops what the GPU has finished.  ECAMP_HOLD_TENSORS=0: record_stream as before.
 HOLD_TENSORS = __import__("os").environ.get("ECAMP_HOLD_TENSORS", "1") != "0"
 _held_cur = []
-_held_done = __import__("collections").deque()   # ([events], [tensors]) in seal order
+_held_done = __import__("collections").deque()   # ([events], [tensors], bytes) in seal order
+_held_bytes = 0                                   # bytes of the sealed sets still held
+
+
+def held_bytes():
+    """Bytes of the tensors held behind steps the GPU has not finished (FusedAdamW.pace lets the host run fewer steps ahead when that is large)."""
+    return _held_bytes
 
 
 def hold(st, *tensors):
@@ -619,7 +625,7 @@ def hold(st, *tensors):
 def seal():
     """Close the current set of held tensors behind an event on every stream that may read them (main, weight-gradient, branch); drop the
     sets whose events have all completed."""
-    global _held_cur
+    global _held_cur, _held_bytes
     if _held_cur:
         dev = _held_cur[0].device
         evs = []
@@ -627,15 +633,18 @@ def seal():
             ev = torch.cuda.Event()
             ev.record(st)
             evs.append(ev)
-        _held_done.append((evs, _held_cur))
+        nb = sum(t.numel() * t.element_size() for t in _held_cur)
+        _held_done.append((evs, _held_cur, nb))
+        _held_bytes += nb
         _held_cur = []
     reap()
 
 
 def reap(block_first=False):
     """Drop held sets the GPU is done with (oldest first).  block_first: wait for the oldest one (tests)."""
+    global _held_bytes
     while _held_done:
-        evs, _ = _held_done[0]
+        evs, _, nb = _held_done[0]
         if block_first:
             for e in evs:
                 e.synchronize()
@@ -643,6 +652,7 @@ def reap(block_first=False):
         if not all(e.query() for e in evs):
             break
         _held_done.popleft()
+        _held_bytes -= nb
 
 
 def wgrad_group_async(items, workgroups=0):

@@ -176,21 +176,36 @@ def test_bench_prints_one_contract_line(dev):
 
 def test_bench_driver_protocol_value_is_explained_by_its_own_record(dev):
     """VERDICT r5 item 1.  The driver's command (`--steps 20 --warmup 5`, the B = 256 workload): `value` (inputs resident in HBM when the
-    timed region starts) must be a steady number -- no step of the timed region more than 10 % over the median -- and the
+    timed region starts) must be a steady number -- no step of the timed region more than 10 % over the median, mean = median -- and the
     PCIe-inclusive leg must either sit within 3 % of it or carry the measured copy bandwidth that explains the gap (the copy of a
-    616 MB batch hides under a step only while the box's host -> HBM path delivers more than bytes / step time)."""
+    616 MB batch hides under a step only while the box's host -> HBM path delivers more than bytes / step time).  A slow step must be
+    EXPLAINED by the record (the host took long to queue it, or the allocator / garbage collector ran) and must not repeat: a run with one
+    is repeated once -- the first GPU processes of a fresh box have shown single steps of 2x-10x the median (profiles/r06_host_lead_and_stalls.txt)
+    -- and the second run has to be clean."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     torch.cuda.empty_cache()   # the child needs ~60 GB of the card this process may hold in its allocator's cache
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-prof"],
-                       capture_output=True, text=True, timeout=900, cwd=root)
-    assert p.returncode == 0, p.stderr[-2000:]
-    r = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
-    st, hs = r["step_ms"], r["host_inclusive_step_ms"]
-    print("  value %.0f pairs/s (%.2f ms/step; steps min %.2f median %.2f p90 %.2f max %.2f) | host-inclusive %.0f pairs/s (%.2f ms/step; "
-          "steps min %.2f median %.2f max %.2f) | h2d %.1f ms per batch = %.1f GB/s, needed %.1f GB/s"
-          % (r["value"], r["ms_per_step"], st["min"], st["median"], st["p90"], st["max"], r["host_inclusive_pairs_per_s"],
-             r["host_inclusive_ms_per_step"], hs["min"], hs["median"], hs["max"], r["h2d_ms_per_step"], r["h2d_gbps"], r["h2d_gbps_needed"]))
+
+    def run():
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-prof"],
+                           capture_output=True, text=True, timeout=900, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        r = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+        st, hs = r["step_ms"], r["host_inclusive_step_ms"]
+        print("  value %.0f pairs/s (%.2f ms/step; steps min %.2f median %.2f p90 %.2f max %.2f) | host-inclusive %.0f pairs/s (%.2f ms/step; "
+              "steps min %.2f median %.2f max %.2f) | h2d %.1f ms per batch = %.1f GB/s, needed %.1f GB/s"
+              % (r["value"], r["ms_per_step"], st["min"], st["median"], st["p90"], st["max"], r["host_inclusive_pairs_per_s"],
+                 r["host_inclusive_ms_per_step"], hs["min"], hs["median"], hs["max"], r["h2d_ms_per_step"], r["h2d_gbps"], r["h2d_gbps_needed"]))
+        print("  value leg: host ms to queue a step %s, runtime counters %s, steps %s" % (st.get("host_queue_ms"), st.get("runtime"), st.get("sequence")))
+        return r, st, hs
+
+    r, st, hs = run()
+    if st["max"] > 1.10 * st["median"]:
+        hq, rt = st["host_queue_ms"], st["runtime"]
+        explained = hq["of_slowest_step"] > 1.5 * hq["median"] or hq["max"] > 2.0 * hq["median"] or rt["device_allocs"] > 16 or rt["gc_gen2"] > 0 or rt["alloc_retries"] > 0
+        print("  a step of %.1f ms against a median of %.2f: %s by the record; running once more" % (st["max"], st["median"], "explained" if explained else "NOT explained"))
+        assert explained, st
+        r, st, hs = run()
     assert st["max"] <= 1.10 * st["median"], st                      # no stall inside the timed region of `value`
     assert abs(r["ms_per_step"] - st["median"]) <= 0.03 * st["median"], (r["ms_per_step"], st)   # mean = median: nothing hides in the mean
     gap = r["host_inclusive_ms_per_step"] / r["ms_per_step"] - 1.0
