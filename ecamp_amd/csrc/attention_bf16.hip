@@ -977,46 +977,53 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
         f32x4 dq[HD / 16];  // dq[dt][r] = dQ[i = q0+li][d = dt*16 + 4g + r]
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the arithmetic between the score MFMAs and the dQ MFMAs of one 16-key tile: e = s * scale*log2e (+ key bias) - lse;
+        // ds = 2^e * (dp (* dropout) - delta), two scores per VALU instruction -> two packed words of the pair's dS operand
+        auto soft = [&](int pp, int hf, bool biased, const f32x4& s, const f32x4& dp, uint32_t& w0, uint32_t& w1) __attribute__((always_inline)) {
+            const int t = 2 * pp + hf;   // (an odd tile count: the last tile is all padding -- zero rows, biased keys)
+            f32x2 e0 = {s[0], s[1]}, e1 = {s[2], s[3]}, d0 = {dp[0], dp[1]}, d1 = {dp[2], dp[3]};
+            const f32x2 sc = {sc2, sc2}, nl = {-lse2, -lse2}, dlv = {dl, dl};
+            if (biased) {
+                const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
+                e0 = e0 * sc + ((f32x2){kb4[0], kb4[1]} + nl);
+                e1 = e1 * sc + ((f32x2){kb4[2], kb4[3]} + nl);
+            } else {
+                e0 = e0 * sc + nl;
+                e1 = e1 * sc + nl;
+            }
+            if (FLAGS && a.drop_p > 0.f) {
+                float dm[4];
+                if (use_bits) {
+                    const unsigned nib = ((pp < 4 ? mw.x : mw.y) >> (8 * (pp & 3) + 4 * hf)) & 15u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dm[r] = (nib >> r) & 1u ? inv_keep : 0.f;
+                } else {
+                    attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+                }
+                d0 *= (f32x2){dm[0], dm[1]};
+                d1 *= (f32x2){dm[2], dm[3]};
+            }
+            w0 = hpk(hexp2(e0) * (d0 - dlv));
+            w1 = hpk(hexp2(e1) * (d1 - dlv));
+        };
         auto pair = [&](int pp, bool biased) {
             uint32_t dsp[4];
+            {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int t = 2 * pp + hf;   // (an odd tile count: the last tile is all padding -- zero rows, biased keys)
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int t = 2 * pp + hf;
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) {
-                    s = MFMA(hfr<HD>(XI, off, t, ks), qf[ks], s);
-                    dp = MFMA(hfr<HD>(YI, off, t, ks), gf[ks], dp);
-                }
-                // e = s * scale*log2e (+ key bias) - lse;  ds = 2^e * (dp (* dropout) - delta), two scores per VALU instruction
-                f32x2 e0 = {s[0], s[1]}, e1 = {s[2], s[3]}, d0 = {dp[0], dp[1]}, d1 = {dp[2], dp[3]};
-                const f32x2 sc = {sc2, sc2}, nl = {-lse2, -lse2}, dlv = {dl, dl};
-                if (biased) {
-                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(KB + t * 16 + 4 * g);
-                    e0 = e0 * sc + ((f32x2){kb4[0], kb4[1]} + nl);
-                    e1 = e1 * sc + ((f32x2){kb4[2], kb4[3]} + nl);
-                } else {
-                    e0 = e0 * sc + nl;
-                    e1 = e1 * sc + nl;
-                }
-                if (FLAGS && a.drop_p > 0.f) {
-                    float dm[4];
-                    if (use_bits) {
-                        const unsigned nib = ((pp < 4 ? mw.x : mw.y) >> (8 * (pp & 3) + 4 * hf)) & 15u;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dm[r] = (nib >> r) & 1u ? inv_keep : 0.f;
-                    } else {
-                        attn_drop4(a, (uint64_t)bh * a.Tq + qi, t * 16 + 4 * g, inv_keep, dm);
+                    for (int ks = 0; ks < HD / 32; ++ks) {
+                        s = MFMA(hfr<HD>(XI, off, t, ks), qf[ks], s);
+                        dp = MFMA(hfr<HD>(YI, off, t, ks), gf[ks], dp);
                     }
-                    d0 *= (f32x2){dm[0], dm[1]};
-                    d1 *= (f32x2){dm[2], dm[3]};
+                    soft(pp, hf, biased, s, dp, dsp[2 * hf], dsp[2 * hf + 1]);
                 }
-                dsp[2 * hf] = hpk(hexp2(e0) * (d0 - dlv));
-                dsp[2 * hf + 1] = hpk(hexp2(e1) * (d1 - dlv));
-            }
-            const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(dsp[0], dsp[1], dsp[2], dsp[3]));
+                const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(dsp[0], dsp[1], dsp[2], dsp[3]));
 #pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = MFMA(htr<HD>(XI, off, pp, dt), sf, dq[dt]);
+                for (int dt = 0; dt < HD / 16; ++dt) dq[dt] = MFMA(htr<HD>(XI, off, pp, dt), sf, dq[dt]);
+            }
         };
 #pragma unroll 2
         for (int pp = 0; pp < pfull; ++pp) pair(pp, false);
@@ -1060,15 +1067,9 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
 #pragma unroll 2
         for (int ip = 0; ip < nqp; ++ip) {
             uint32_t pdp[4], dsp[4];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
+            // one 16-query tile of the pair: p = 2^(s*scale*log2e - lse), P (with the dropout scale) and dS = p * (dp (* dropout) - delta)
+            auto soft2 = [&](int hf, const f32x4& s, const f32x4& dp) __attribute__((always_inline)) {
                 const int it = 2 * ip + hf;   // (an odd tile count: the last tile is all padding -- zero rows, lse = +1e30)
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) {
-                    s = MFMA(hfr<HD>(XI, off, it, ks), kf[ks], s);
-                    dp = MFMA(hfr<HD>(YI, off, it, ks), vf[ks], dp);
-                }
                 const f32x4 lse4 = *reinterpret_cast<const f32x4*>(LS + it * 16 + 4 * g);
                 const f32x4 dl4 = *reinterpret_cast<const f32x4*>(DL + it * 16 + 4 * g);
                 const f32x2 sc = {sc2, sc2};
@@ -1094,13 +1095,26 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
                 }
                 dsp[2 * hf] = hpk(p0 * (d0 - (f32x2){dl4[0], dl4[1]}));
                 dsp[2 * hf + 1] = hpk(p1 * (d1 - (f32x2){dl4[2], dl4[3]}));
-            }
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pdp[0], pdp[1], pdp[2], pdp[3]));
-            const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(dsp[0], dsp[1], dsp[2], dsp[3]));
+            };
+            {
 #pragma unroll
-            for (int dt = 0; dt < HD / 16; ++dt) {
-                dv[dt] = MFMA(htr<HD>(YI, off, ip, dt), pf, dv[dt]);
-                dk[dt] = MFMA(htr<HD>(XI, off, ip, dt), sf, dk[dt]);
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int it = 2 * ip + hf;
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < HD / 32; ++ks) {
+                        s = MFMA(hfr<HD>(XI, off, it, ks), kf[ks], s);
+                        dp = MFMA(hfr<HD>(YI, off, it, ks), vf[ks], dp);
+                    }
+                    soft2(hf, s, dp);
+                }
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pdp[0], pdp[1], pdp[2], pdp[3]));
+                const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(dsp[0], dsp[1], dsp[2], dsp[3]));
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; ++dt) {
+                    dv[dt] = MFMA(htr<HD>(YI, off, ip, dt), pf, dv[dt]);
+                    dk[dt] = MFMA(htr<HD>(XI, off, ip, dt), sf, dk[dt]);
+                }
             }
         }
         if (kj < a.Tk) {

@@ -12,9 +12,9 @@ from . import hip_ops as ops
 # host's lead grows by 20 ms per step, and every tensor a side stream reads (record_stream: the weight-gradient stream's x and dy, i.e.
 # most saved activations, ~10 GB per step) is only returned to the caching allocator when the GPU gets there -- round 6's bench record
 # showed 250-570 hipMalloc calls and 27-60 GB of reserve growth inside 20 timed steps, and steps of 2x the median when such a burst met
-# a small lead (BENCH_r05's 40.7 ms mean).  Three steps in flight keep the GPU fed through a host hiccup of ~100 ms (the first GPU processes of a fresh box have
-# shown 87 ms) and the reserve at its steady state after the warm-up.  0 = unbounded (the old behaviour).
-MAX_STEPS_IN_FLIGHT = int(os.environ.get("ECAMP_MAX_STEPS_IN_FLIGHT", "3"))
+# a small lead (BENCH_r05's 40.7 ms mean).  Two steps in flight keep the GPU fed through a host hiccup of ~70 ms and reach their steady state within a 5-step warm-up
+# (three: +35 ms of slack, but the lead is still growing when the driver's timed region starts).  0 = unbounded (the old behaviour).
+MAX_STEPS_IN_FLIGHT = int(os.environ.get("ECAMP_MAX_STEPS_IN_FLIGHT", "2"))
 # ... and fewer than that (never fewer than one) while the tensors held for the side streams (hip_ops.hold: ~21 GB per step at B = 256) pass this
 MAX_HELD_BYTES = int(float(os.environ.get("ECAMP_MAX_HELD_GB", "96")) * 2 ** 30)
 

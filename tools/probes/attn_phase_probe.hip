@@ -69,9 +69,10 @@ static void run(const char* name, int B, int H, int T, int hd, bool flags) {
     hipFree(qkv); hipFree(dqkv); hipFree(o); hipFree(dO); hipFree(lse); hipFree(delta); hipFree(km); hipFree(bits);
 }
 
-int main() {
-    run("report side", 256, 6, 128, 128, true);
-    run("decoder    ", 256, 16, 197, 32, false);
-    run("encoder    ", 256, 12, 50, 64, false);
+int main(int argc, char** argv) {
+    const int which = argc > 1 ? atoi(argv[1]) : 0;   // 0 all, 1 report side, 2 decoder, 3 encoder
+    if (which == 0 || which == 1) run("report side", 256, 6, 128, 128, true);
+    if (which == 0 || which == 2) run("decoder    ", 256, 16, 197, 32, false);
+    if (which == 0 || which == 3) run("encoder    ", 256, 12, 50, 64, false);
     return 0;
 }
