@@ -598,11 +598,13 @@ def branch_stream(device):
 # and the GPU a step of 2x the median.  Instead the tensors are HELD here (a Python reference) until events recorded behind the step on
 # every stream have completed, then dropped: the block goes back to the allocator the ordinary way, reusable at once by its own stream, and
 # the step's allocation pattern is the same every step.  `seal()` is called where a step ends (FusedAdamW.pace) and by `hold` itself every
-# 512 tensors (loops that never reach an optimizer); `reap()` drops what the GPU has finished.  ECAMP_HOLD_TENSORS=0: record_stream as before.
+# 512 tensors or 8 GB (loops that never reach an optimizer); `reap()` drops what the GPU has finished.  ECAMP_HOLD_TENSORS=0: record_stream as before.
 HOLD_TENSORS = __import__("os").environ.get("ECAMP_HOLD_TENSORS", "1") != "0"
 _held_cur = []
 _held_done = __import__("collections").deque()   # ([events], [tensors], bytes) in seal order
 _held_bytes = 0                                   # bytes of the sealed sets still held
+_cur_bytes = 0                                    # bytes of the open set
+_cur_readers = []                                 # the streams named as readers of the open set (hold's first argument)
 
 
 def held_bytes():
@@ -617,26 +619,38 @@ def hold(st, *tensors):
             if t is not None:
                 t.record_stream(st)
         return
-    _held_cur.extend(t for t in tensors if t is not None)
-    if len(_held_cur) >= 512:
+    global _cur_bytes
+    if all(st is not r for r in _cur_readers):
+        _cur_readers.append(st)
+    for t in tensors:
+        if t is not None:
+            _held_cur.append(t)
+            _cur_bytes += t.numel() * t.element_size()
+    if len(_held_cur) >= 512 or _cur_bytes > (8 << 30):   # loops that never reach an optimizer step (evaluation, tests): bounded all the same
         seal()
+    elif _held_done and (len(_held_cur) & 31) == 0:
+        reap()
 
 
 def seal():
     """Close the current set of held tensors behind an event on every stream that may read them (main, weight-gradient, branch); drop the
     sets whose events have all completed."""
-    global _held_cur, _held_bytes
+    global _held_cur, _held_bytes, _cur_bytes
     if _held_cur:
         dev = _held_cur[0].device
         evs = []
-        for st in [torch.cuda.current_stream(dev)] + side_streams(dev):
+        streams = [torch.cuda.current_stream(dev)]
+        for st in list(_cur_readers) + side_streams(dev):   # every stream named as a reader, and the side streams whatever was named
+            if all(st is not q and st != q for q in streams):
+                streams.append(st)
+        for st in streams:
             ev = torch.cuda.Event()
             ev.record(st)
             evs.append(ev)
-        nb = sum(t.numel() * t.element_size() for t in _held_cur)
-        _held_done.append((evs, _held_cur, nb))
-        _held_bytes += nb
-        _held_cur = []
+        del _cur_readers[:]
+        _held_done.append((evs, _held_cur, _cur_bytes))
+        _held_bytes += _cur_bytes
+        _held_cur, _cur_bytes = [], 0
     reap()
 
 

@@ -381,7 +381,8 @@ class ECAMP(nn.Module):
             ops.hold(bs, latent, imgs, big, mask, ids_restore, ids_keep, column, row)
             mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
             main.wait_stream(bs)
-            ops.hold(main, *img_losses)   # (allocated on the branch stream, read by the caller on the main one)
+            for t in img_losses:   # three scalars allocated on the branch stream and read by the CALLER on the main one, later than any point this
+                t.record_stream(main)   # function could fence: the allocator's own bookkeeping (no effect on its steady state at this size)
         else:
             img_losses = image_decoder()
             mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
