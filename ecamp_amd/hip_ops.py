@@ -613,7 +613,9 @@ def held_bytes():
 
 
 def hold(st, *tensors):
-    """`st` (a side stream) reads `tensors`, which live in another stream's pool: keep them alive until that has happened."""
+    """`st` (a side stream) reads `tensors`, which live in another stream's pool: keep them alive until that has happened.  Contract: every
+    read of them by `st` has ALREADY been queued when this is called (the weight-gradient launches) -- a tensor that a side stream reads again
+    later (the branch stream's backward nodes) must use record_stream, whose event is taken when the tensor is freed."""
     if not HOLD_TENSORS:
         for t in tensors:
             if t is not None:

@@ -378,7 +378,8 @@ class ECAMP(nn.Module):
             bs.wait_stream(main)
             with torch.cuda.stream(bs):
                 img_losses = image_decoder()
-            ops.hold(bs, latent, imgs, big, mask, ids_restore, ids_keep, column, row)
+            for t in (latent, imgs, big, mask, ids_restore, ids_keep, column, row):
+                t.record_stream(bs)   # (not hip_ops.hold: the branch's BACKWARD nodes read these again on `bs`, later than any fence taken here)
             mlm_loss = self.forward_report_decoder(latent, ids_keep, ids, labels, attention_mask, type_ids, weights, B, T)
             main.wait_stream(bs)
             for t in img_losses:   # three scalars allocated on the branch stream and read by the CALLER on the main one, later than any point this
