@@ -60,7 +60,7 @@ template <> struct Q16FragN<false> {
 
 // EPI: 0 bf16 C = alpha*acc (+bias)   2 ... + residual.   NW: MFMA tiles per wave along N (8: 256-column tile, 6: 192-column tile).
 // B_KC: the N-side operand is contraction-contiguous (forward form) or strided (data-gradient form).
-template <int EPI, int NW, bool B_KC, int DBG = 0>   // DBG (lab only): 1 no MFMA, 2 no DMA, 4 no fragment reads
+template <int EPI, int NW, bool B_KC, int DBG = 0>   // DBG (lab only): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 conflict-free (wrong) transpose reads
 __device__ __forceinline__ void q16_body(const GemmArgs& g) {
     constexpr int NSLOT = 5;
     constexpr int TN = 32 * NW;                       // tile columns
@@ -96,7 +96,9 @@ __device__ __forceinline__ void q16_body(const GemmArgs& g) {
     } else {         // per tile pair T = t >> 1 (the XOR touches the pair bits); tile parity at + 8 B, k-step at + 8192, second read at + 1024
         const int r = l15 >> 2, q = l15 & 3;
 #pragma unroll
-        for (int T = 0; T < 4; ++T) offN[T] = (unsigned)((8 * lq + r) * 256 + ((((4 * T + q) ^ (r << 2)) & 15) << 4));
+        for (int T = 0; T < 4; ++T) offN[T] = (unsigned)((8 * lq + r) * 256 + ((((4 * T + q) ^ (r << 2)) & 15) << 4)) + ((DBG & 8) ? (unsigned)(lq & 1) * 8u : 0u);
+        // (DBG & 8, lab only, WRONG results: the odd k-groups of a 32-lane half read the other 8-byte half of their chunks -- the pattern
+        // without the 2-way bank meeting of the two k-groups; prices what that meeting costs: profiles/r06_q16_dgrad_conflicts.txt)
     }
     q16_f32x4 acc[8][NW];
 

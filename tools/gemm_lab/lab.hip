@@ -45,6 +45,10 @@ static q8_fn pick(int a_kc, int b_kc, int epi, int nslot, int dbg) {
 #define W(A, B, E, S) ((q8_fn)gemm_bf16_q8_kernel<A, B, E, 0, false, S>)
     if (g_sch == 16 || g_sch == 12) {   // four waves on the 16 x 16 x 32 MFMA (csrc/gemm_q16.h): 256- (16) or 192-column (12) tiles; forward and data-gradient forms, plain / bias / residual
         if (!a_kc) return nullptr;
+        if (dbg == 8) {   // data-gradient form with conflict-free (wrong) transpose-read addresses: the price of the 2-way bank meeting
+            if (epi != 0 || b_kc) return nullptr;
+            return g_sch == 16 ? (q8_fn)gemm_bf16_q16_kernel<0, 8, false, 8> : (q8_fn)gemm_bf16_q16_kernel<0, 6, false, 8>;
+        }
         if (dbg != 0) {
             if (g_sch != 16 || epi != 0 || !b_kc) return nullptr;
             if (dbg == 1) return (q8_fn)gemm_bf16_q16_kernel<0, 8, true, 1>;
@@ -309,13 +313,15 @@ int main(int argc, char** argv) {
             float t_ref = quick ? 0.f : time_us([&] { launch_ref(r, 0, s); });
             launch_ref(r, 0, s);
             printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f\n", sh.name, "dgrad", M, K, N, "128^2 (r1)", t_ref, fl / t_ref / 1e6);
-            for (int ns : nslots) {
+            for (int ns : nslots)
+            for (int dbg : dbgs) {   // (dbg 8: the four-wave kernels with conflict-free, WRONG transpose-read addresses -- a timing probe)
+                if (dbg != 0 && !(dbg == 8 && (ns == 16 || ns == 12))) continue;
                 CK(hipMemsetAsync(dx1, 0xff, (size_t)M * K * 2, s));
-                launch_q8(q, ns, 0, grid_override, s);
+                launch_q8(q, ns, dbg, grid_override, s);
                 CK(hipStreamSynchronize(s));
                 double rn; double d = compare(dx1, dx0, (size_t)M * K, false, &rn);
-                float t = time_us([&] { launch_q8(q, ns, 0, grid_override, s); });
-                char v[64]; snprintf(v, sizeof v, "Q8 sch=%d", ns);
+                float t = time_us([&] { launch_q8(q, ns, dbg, grid_override, s); });
+                char v[64]; snprintf(v, sizeof v, "Q8 sch=%d dbg=%d", ns, dbg);
                 printf("%-11s %-5s %6d %6d %5d | %-22s %8.1f %7.0f  maxdiff %.3g (max %.3g)\n", sh.name, "dgrad", M, K, N, v, t, fl / t / 1e6, d, rn);
             }
         }
