@@ -111,6 +111,18 @@ def test_shards_and_crop_items_round_trip(tmp_path):
     assert max(pd.U8ShardReader(os.path.join(tmp_path, "small.u8"))[0].shape) == 128
 
 
+def test_tap_count_formula_matches_pillow_coefficients():
+    """`DeviceAugmenter.taps` (the size of the device's tap tables) equals the ksize of Pillow's precompute_coeffs for every input size, and
+    the restated coefficients sum to 2^22 +- rounding per output pixel (22-bit fixed point, normalised)."""
+    from ecamp_amd.module import pretrain_datasets as pd
+    from oracle import tv_transforms as tv
+    for n in (1, 2, 5, 37, 200, 447, 448, 449, 897, 1024, 2544, 3056, 9000):
+        kk, bounds = tv.pillow_coeffs(n, 448)
+        assert pd.DeviceAugmenter.taps(n, 448) == kk.shape[1], n
+        assert (bounds[:, 1] >= 1).all() and (bounds[:, 0] >= 0).all() and (bounds[:, 0] + bounds[:, 1] <= n).all()
+        assert np.abs(kk.sum(1) - (1 << 22)).max() <= kk.shape[1], n
+
+
 @pytest.mark.gpu
 def test_device_augmenter_equals_the_host_pil_item(dev):
     """The device path against the host path on the same stored pixels and the same torch seed: ecamp_resample_crops_u8 returns the bytes
