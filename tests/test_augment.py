@@ -219,3 +219,55 @@ def test_model_forward_on_crops_equals_forward_on_the_host_items(dev):
     torch.cuda.synchronize()
     for x, y, z in zip(a, b, c):      # same pixels in, same kernels: equal up to the summation order of the loss sums' f32 atomics
         assert abs(x.item() - y.item()) <= 1e-5 * abs(x.item()) and abs(x.item() - z.item()) <= 1e-5 * abs(x.item()), (x.item(), y.item(), z.item())
+
+
+REF_TOK = "/root/reference/ECAMP/Pre-training/dataset/mimic_wordpiece.json"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TOK), reason="the reference tokenizer file is only present in the authoring container")
+def test_dataset_with_image_shard_hands_over_crops_of_the_same_items(tmp_path):
+    """`ContextBertDataset(data_root, image_shard=...)` end to end on a four-row data root written here (the reference's CSV columns, JPEG files,
+    its tokenizer): every item of the shard-backed dataset carries the crop whose Pillow resample (+ flip) IS the `image_u8` item of the
+    file-backed dataset under the same seeds; the text half is identical; `collate_fn` packs crops, table and host-side meta."""
+    import random
+    import shutil
+    import pandas as pd
+    from PIL import Image
+    from ecamp_amd.module import pretrain_datasets as pdm
+    from oracle import tv_transforms as tv
+    root = str(tmp_path)
+    shutil.copy(REF_TOK, os.path.join(root, "mimic_wordpiece.json"))
+    paths, raws = [], []
+    for k in range(4):
+        a = _radiograph(420 + 50 * k, 380 + 40 * k, 60 + k)
+        p = os.path.join(root, "img%d.png" % k)      # PNG: lossless, so that the shard and the file hold the same pixels
+        Image.fromarray(a, "L").save(p)
+        paths.append(p)
+        raws.append(a)
+    pd.DataFrame({"img_path": paths, "report": ["there is no evidence of pneumothorax. small left pleural effusion."] * 4,
+                  "llm_output": ["effusion small."] * 4}).to_csv(os.path.join(root, "mimic-cxr-2.0.0-entity-llm.csv"), index=False)
+    pd.DataFrame({"label_i": [0, 1, 2, 1], "label_j": [2, 1, 0, 0]}).to_csv(os.path.join(root, "mimic-cxr-2.0.0-attn-label.csv"), index=False)
+    shard = os.path.join(root, "images.u8")
+    with pdm.U8ShardWriter(shard) as w:
+        for a in raws:
+            w.add(a)
+    ds_file = pdm.ContextBertDataset(root, max_caption_length=64, image_u8=True)
+    ds_shard = pdm.ContextBertDataset(root, max_caption_length=64, image_shard=shard)
+    items = []
+    for k in range(4):
+        random.seed(100 + k); torch.manual_seed(200 + k)
+        a = ds_file[k]
+        random.seed(100 + k); torch.manual_seed(200 + k)
+        b = ds_shard[k]
+        crop, flip = b[0]
+        want = tv.pillow_resize_u8(crop, 448)
+        if flip:
+            want = want[:, ::-1]
+        assert np.array_equal(a[0].numpy(), want), k
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y)
+        items.append(b)
+    batch = ds_shard.collate_fn(items)
+    assert "image" not in batch and batch["image_table"].shape == (4, 6) and batch["image_crops"].dtype == torch.uint8
+    assert batch["image_meta"] == pdm.crops_meta(batch["image_table"]) and batch["ids"].shape == (4, 64)
+    assert int(batch["image_table"][:, 1].mul(batch["image_table"][:, 2]).sum()) == batch["image_crops"].numel()
