@@ -248,9 +248,12 @@ def test_dataset_with_image_shard_hands_over_crops_of_the_same_items(tmp_path):
                   "llm_output": ["effusion small."] * 4}).to_csv(os.path.join(root, "mimic-cxr-2.0.0-entity-llm.csv"), index=False)
     pd.DataFrame({"label_i": [0, 1, 2, 1], "label_j": [2, 1, 0, 0]}).to_csv(os.path.join(root, "mimic-cxr-2.0.0-attn-label.csv"), index=False)
     shard = os.path.join(root, "images.u8")
-    with pdm.U8ShardWriter(shard) as w:
-        for a in raws:
-            w.add(a)
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_image_shard.py"), "--data_path", root, "--out", shard, "--workers", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rd = pdm.U8ShardReader(shard)
+    assert len(rd) == 4 and all(np.array_equal(rd[k], raws[k]) for k in range(4))   # the tool decodes the CSV's files in row order, pixel for pixel
     ds_file = pdm.ContextBertDataset(root, max_caption_length=64, image_u8=True)
     ds_shard = pdm.ContextBertDataset(root, max_caption_length=64, image_shard=shard)
     items = []
