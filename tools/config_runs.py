@@ -25,11 +25,14 @@ def run(name, ctor, B, big, **kw):
         opt.zero_grad()
         return mim, res, mlm
     for _ in range(6): out = step()   # allocator and weight-quantisation caches settle within a few steps
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(args.steps): out = step()
+    torch.cuda.synchronize(); n0 = torch.cuda.memory_stats().get("num_device_alloc", 0); t0 = time.perf_counter()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]; marks[0].record()
+    for i in range(args.steps): out = step(); marks[i + 1].record()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    per_step = [round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(args.steps)]
     r = {"config": name, "pairs_per_gpu": B, "ms_per_step": round(1e3 * dt, 2), "pairs_per_s": round(B / dt, 1),
-         "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses": [round(float(t), 4) for t in out]}
+         "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses": [round(float(t), 4) for t in out],
+         "step_ms": per_step, "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - n0}
     print(json.dumps(r), flush=True)
     del model, opt, batch
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
