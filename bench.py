@@ -228,7 +228,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU (configs[1] = 256)")
     ap.add_argument("--seq", type=int, default=128)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="bf16: the headline mode.  fp16: IEEE-half activations (the reference's "
+                    "autocast format) with its dynamic loss scaling inside the timed step (libecamp_hip_f16.so).  fp32: parity mode")
     ap.add_argument("--image-u8", action="store_true", help="compact image schema: uint8 [B,448,448] grayscale crops (51 MB per 256 pairs over PCIe instead "
                     "of 616 MB of f32 [B,3,448,448]); the default stays the reference's f32 schema")
     ap.add_argument("--grad-dtype", default=os.environ.get("ECAMP_DDP_GRAD_DTYPE", "f32"), choices=["f32", "bf16"],
@@ -269,12 +270,13 @@ def main():
     from ecamp_amd.util.misc import NativeScalerWithGradNormCount
 
     torch.manual_seed(42 + rank)  # main_pretrain.py:189
-    cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cd = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    half16 = args.dtype in ("bf16", "fp16")
     model = model_ecamp.ecamp(compute_dtype=cd).to(dev)
     model.prepare()
     net = DistributedDataParallel(model, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None) if world > 1 else model
     opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
-    scaler = NativeScalerWithGradNormCount()
+    scaler = NativeScalerWithGradNormCount(dynamic=(args.dtype == "fp16"))   # fp16: GradScaler's check + skip + update run in every timed step
     from ecamp_amd.data import DevicePrefetcher
     host_batch = {k: v.pin_memory() for k, v in synthetic_batch(args.batch, args.seq, 448, seed=rank, device="cpu", image_u8=args.image_u8).items()}   # what a
     # pin_memory DataLoader yields (main_pretrain.py:232-240); it crosses PCIe inside the timed region, one step ahead of its use
@@ -479,6 +481,8 @@ def main():
                           "image": "448^2 -> 224^2 encoder input" + (", uint8 grayscale crops normalised on the device" if args.image_u8 else ""),
                           "seq_len": args.seq, "mask_ratio": 0.75, "accum_iter": 1, "parallelism": "dp%d" % world,
                           "last_losses_mim_res_mlm": [round(x, 5) for x in losses]},
+               **({"loss_scale": {"mode": "dynamic (GradScaler: init 65536, x2 after 2000 clean steps, x0.5 and a skipped step on inf / nan)",
+                                  "scale": scaler.get_scale(), "skipped_steps": scaler.skipped_steps}} if scaler.dynamic else {}),
                "input": "resident in HBM when the timed region starts (`value`, `ms_per_step`, `step_ms`); the PCIe-inclusive rate of the same "
                         "step is `host_inclusive_*` (pinned host batch -> HBM inside that timed region: every timed step issues the copy of the batch "
                         "two steps ahead on a copy stream; steady-state pipeline primed by 3 untimed steps)",
@@ -498,7 +502,7 @@ def main():
         # the north-star's ">= 40 % MFMA roofline on the ViT-B/16 forward+backward at bs=256/GPU" in its own scope: the image side alone
         # (model_ecamp.py:218-264,276-300), 7.154 GMAC forward per image x 2 FLOP x 3 (fwd + dgrad + wgrad) = 42.92 GFLOP per image
         # (SURVEY.md 8(d)); production stream layout (weight gradients on the side stream), inputs resident
-        if args.seq in (128, 256) and args.dtype == "bf16":
+        if args.seq in (128, 256) and half16:
             vit_tf = 42.92e9 * args.batch / dt_vit / 1e12
             res.update({"vit_fwd_bwd_ms": round(1e3 * dt_vit, 3), "vit_tflops": round(vit_tf, 2), "vit_frac": round(vit_tf / PEAK_BF16_TFLOPS, 4),
                         "vit_note": "image side only (stem, 12 encoder blocks, decoder, SR head, image losses), forward + backward, per GPU: "
@@ -507,12 +511,12 @@ def main():
             res["rccl"] = rccl
         if not args.no_prof:
             ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-            cat = 0 if args.dtype == "bf16" else 1
+            cat = 0 if half16 else 1
             lib.ecamp_prof_collect(cat, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
             ams, afl, an = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
             lib.ecamp_prof_collect(2, ctypes.byref(ams), ctypes.byref(afl), ctypes.byref(an))
             ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            peak = PEAK_BF16_TFLOPS if half16 else 157.3   # the dense f16 peak equals the bf16 one
             # HBM-side traffic per GEMM launch: not measurable from inside this process -- taken from the newest committed PMC passes of
             # this very command (profiles/rNN_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), and only when that
             # file is stamped with the hash of the GEMM sources this library was built from; otherwise null (never last round's number)
@@ -535,7 +539,7 @@ def main():
                         traffic = None
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "gemm_bf16_q8_kernel + gemm_bf16_q16_kernel + gemm_bf16_kernel (bf16 GEMM family)" if args.dtype == "bf16" else "gemm_f32_kernel",
+                               "kernel": "gemm_bf16_q8_kernel + gemm_bf16_q16_kernel + gemm_bf16_kernel (bf16 GEMM family)" if args.dtype == "bf16" else "the same three kernels built for IEEE half (libecamp_hip_f16.so)" if half16 else "gemm_f32_kernel",
                                "launches_per_step": n.value // max(prof_steps, 1),
                                "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2),
                                "algorithmic_gflop_per_launch": round(fl.value / max(n.value, 1) / 1e9, 3),

@@ -1,5 +1,9 @@
-"""ctypes binding of libecamp_hip.so.  The prototypes are parsed from include/ecamp_hip.h so the binding can
-never drift from the declared C ABI.  There is NO fallback: if the library is missing or a call fails, we raise."""
+"""ctypes binding of libecamp_hip.so (bfloat16 activations, the default) and libecamp_hip_f16.so (IEEE-half activations: the same sources
+built with -DECAMP_HALF_F16, for `--amp fp16`).  The prototypes are parsed from include/ecamp_hip.h so the binding can never drift from
+the declared C ABI.  There is NO fallback: if the library is missing or a call fails, we raise.
+
+One process computes in ONE 16-bit format at a time: `set_half("f16")` makes every later call go to the f16 build (its option state,
+plan caches and counters are its own); hip_ops.code() refuses a tensor whose dtype is not the active format."""
 import ctypes
 import os
 import re
@@ -7,6 +11,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ECAMP_LIB (development A/B of two builds on one box, tools/ab_lib.sh): another build of the SAME library; the default is the in-tree one
 LIB_PATH = os.environ.get("ECAMP_LIB") or os.path.join(HERE, "libecamp_hip.so")
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.environ.get("ECAMP_LIB_F16") or os.path.join(HERE, "libecamp_hip_f16.so")}
 HEADER = os.path.join(os.path.dirname(HERE), "include", "ecamp_hip.h")
 
 F32, BF16 = 0, 1
@@ -49,20 +54,39 @@ def abi_version_of_header(path=HEADER):
     return int(m.group(1))
 
 
-_lib = None
+_libs = {}
+_half = "bf16"
 _protos = None
 
 
-def load():
-    global _lib, _protos
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise EcampHipError("libecamp_hip.so not found at %s -- run `python -m ecamp_amd.build` (there is no CPU fallback)" % LIB_PATH)
+def half():
+    """The active 16-bit activation format: "bf16" or "f16"."""
+    return _half
+
+
+def set_half(fmt):
+    """Route every later call to the build whose 16-bit format is `fmt` ("bf16" / "f16", or torch.bfloat16 / torch.float16 /
+    torch.float32 -- f32 leaves the choice alone); returns the previous format."""
+    global _half
+    name = {"torch.bfloat16": "bf16", "torch.float16": "f16", "torch.float32": _half}.get(str(fmt), fmt)
+    if name not in LIB_PATHS:
+        raise EcampHipError("unknown 16-bit format %r (bf16 or f16)" % (fmt,))
+    prev, _half = _half, name
+    return prev
+
+
+def load(fmt=None):
+    global _protos
+    fmt = fmt or _half
+    if fmt in _libs:
+        return _libs[fmt]
+    path = LIB_PATHS[fmt]
+    if not os.path.exists(path):
+        raise EcampHipError("%s not found at %s -- run `python -m ecamp_amd.build` (there is no CPU fallback)" % (os.path.basename(path), path))
     # torch first: it brings its own HIP runtime, and a process that loads /opt/rocm's runtime (through this library) before
     # torch's ends up with two runtimes of which the second sees no device ("no ROCm-capable device is detected")
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     _protos = parse_header()
     for name, (ret, args) in _protos.items():
         fn = getattr(lib, name)  # raises AttributeError if the symbol is not exported
@@ -73,8 +97,11 @@ def load():
     if got != want:
         raise EcampHipError("ABI version mismatch: %s was built for version %d, include/ecamp_hip.h declares %d -- rebuild "
                             "(`python -m ecamp_amd.build`); an older build must not be called with this header's argument lists"
-                            % (LIB_PATH, got, want))
-    _lib = lib
+                            % (path, got, want))
+    if lib.ecamp_half_format() != (1 if fmt == "f16" else 0):
+        raise EcampHipError("%s stores %s, not %s: the two builds were swapped (ECAMP_LIB / ECAMP_LIB_F16?)"
+                            % (path, "IEEE half" if lib.ecamp_half_format() else "bfloat16", fmt))
+    _libs[fmt] = lib
     return lib
 
 

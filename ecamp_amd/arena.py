@@ -63,7 +63,7 @@ class ParamArena:
         self.total = off
         self.flat_p = ops.zeros((off,), dev)
         self.flat_g = ops.zeros((off,), dev)
-        self.flat_p16 = torch.empty((off,), device=dev, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
+        self.flat_p16 = torch.empty((off,), device=dev, dtype=compute_dtype) if compute_dtype in (torch.bfloat16, torch.float16) else None
         self.index = {}
         for i, (p, o, n) in enumerate(zip(self.params, self.offsets, self.sizes)):
             self.flat_p[o:o + n].view(p.shape).copy_(p.data)

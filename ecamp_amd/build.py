@@ -15,7 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(os.path.dirname(HERE), "build")
 LIB = os.path.join(HERE, "libecamp_hip.so")
+LIB_F16 = os.path.join(HERE, "libecamp_hip_f16.so")   # the same sources with IEEE half as the 16-bit format (csrc/common.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-result"]
+
+
+def _variant(half):
+    if half == "f16":
+        return os.path.join(OBJ, "f16"), LIB_F16, FLAGS + ["-DECAMP_HALF_F16=1"]
+    return OBJ, LIB, FLAGS
 
 
 def gemm_source_hash():
@@ -36,7 +43,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, half="bf16"):
+    """`half`: "bf16" -> libecamp_hip.so, "f16" -> libecamp_hip_f16.so (objects under build/f16), "both"."""
+    if half == "both":
+        build(force, verbose, "bf16")
+        build(force, verbose, "f16")
+        return LIB
+    OBJ, LIB, FLAGS = _variant(half)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
@@ -72,11 +85,11 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n" + r.stderr)
         if verbose:
             print("[ecamp_amd.build] linked %s" % LIB, flush=True)
-        check_isa(verbose)
+        check_isa(verbose, LIB)
     return LIB
 
 
-def check_isa(verbose=True):
+def check_isa(verbose=True, LIB=LIB):
     """The inline-asm invariants of the persistent GEMMs that hipcc does not promise (tools/check_isa.py), checked on every freshly
     linked library: a violation is a wrong-bias race, so it fails the build.  Without the ROCm binutils the check cannot run: said
     loudly, not silently (tests/test_isa.py then skips as well)."""
@@ -101,4 +114,4 @@ def check_isa(verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, half="f16" if "--f16" in sys.argv else "bf16" if "--bf16" in sys.argv else "both")

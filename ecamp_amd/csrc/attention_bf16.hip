@@ -24,9 +24,9 @@ __device__ long long attn_ts_buf[8 * 8192];
 #endif
 
 typedef __attribute__((ext_vector_type(4))) short v4s16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef hw_h16x8 bf16x8_t;
 
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0)
+#define MFMA(a, b, c) ECAMP_MFMA_16x16x32(a, b, c)
 
 // softmax in base 2: scores are scaled by scale*log2(e) once, exp(x) becomes the native v_exp_f32 (2^x) with no extra multiply, and
 // a masked score (-1e30) needs no select: 2^(-1e30 - max(m, -1e29)) is 0.  lse is still stored in natural-log units.

@@ -8,7 +8,19 @@
 #define ECAMP_F32 0
 #define ECAMP_BF16 1
 
-typedef unsigned short bf16_t;  // raw bfloat16 bits
+// The 16-bit storage format is a property of the BUILD: libecamp_hip.so keeps bfloat16 (the benchmarked mode), libecamp_hip_f16.so -- the same
+// sources with -DECAMP_HALF_F16 -- keeps IEEE half, the format the reference's torch.cuda.amp.autocast() computes in (main_pretrain.py:139,
+// engine_pretrain.py:44).  Everything that touches the bits goes through the helpers below (h16 <-> f32, the packed pair forms, the MFMA
+// macros, H16_ONE / H16_NEG_INF); `bf16_t` is the historical name of "one raw 16-bit element" in either build, and dtype code ECAMP_BF16
+// means "the library's 16-bit format" (ecamp_half_format() says which).
+#ifdef ECAMP_HALF_F16
+#define ECAMP_HALF_IS_F16 1
+typedef _Float16 hw_h16;
+#else
+#define ECAMP_HALF_IS_F16 0
+typedef __bf16 hw_h16;
+#endif
+typedef unsigned short bf16_t;  // raw 16-bit element (bfloat16 bits, or IEEE half bits in the f16 build)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;  // MFMA bf16 operand (8 x bf16 = 4 VGPRs)
 
@@ -27,15 +39,42 @@ int ecamp_set_error(int code, const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// f32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per instruction);
-// the integer emulation it replaces cost ~8 VALU operations per value and dominated the GEMM epilogues
-typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef hw_h16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef hw_h16 hw_h16x4 __attribute__((ext_vector_type(4)));
+typedef hw_h16 hw_h16x8 __attribute__((ext_vector_type(8)));
 typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+#if ECAMP_HALF_IS_F16
+constexpr unsigned short H16_ONE = 0x3C00, H16_NEG_INF = 0xFC00;
+#define ECAMP_DOT2C "v_dot2c_f32_f16"    // f32 += two 16-bit products (inline asm of the bias-gradient row sums, gemm_q8.h)
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// the two elements of a packed pair (low half first): v_cvt_f32_f16 reads either half of the register directly
+__device__ __forceinline__ float h16_lo(uint32_t w) { return (float)__builtin_bit_cast(hw_bf16x2, w)[0]; }
+__device__ __forceinline__ float h16_hi(uint32_t w) { return (float)__builtin_bit_cast(hw_bf16x2, w)[1]; }
+#else
+constexpr unsigned short H16_ONE = 0x3F80, H16_NEG_INF = 0xFF80;
+#define ECAMP_DOT2C "v_dot2c_f32_bf16"
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float h16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
+constexpr uint32_t H16_ONE_X2 = (uint32_t)H16_ONE * 0x10001u, H16_NEG_INF_X2 = (uint32_t)H16_NEG_INF * 0x10001u;
+// f32 -> 16 bit, round-to-nearest-even: gfx950 has both conversions in hardware (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, two values per
+// instruction); the integer emulation the bf16 one replaces cost ~8 VALU operations per value and dominated the GEMM epilogues
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (hw_h16)f); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((hw_f32x2){lo, hi}, hw_bf16x2));
 }
+// The matrix instructions of the 16-bit format (operands: eight / four raw elements per lane, any 16- / 8-byte type)
+#if ECAMP_HALF_IS_F16
+#define ECAMP_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hw_h16x8, a), __builtin_bit_cast(hw_h16x8, b), c, 0, 0, 0)
+#define ECAMP_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hw_h16x8, a), __builtin_bit_cast(hw_h16x8, b), c, 0, 0, 0)
+#define ECAMP_MFMA_4x4x4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(hw_h16x4, a), __builtin_bit_cast(hw_h16x4, b), c, 0, 0, 0)
+#else
+#define ECAMP_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_h16x8, a), __builtin_bit_cast(hw_h16x8, b), c, 0, 0, 0)
+#define ECAMP_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hw_h16x8, a), __builtin_bit_cast(hw_h16x8, b), c, 0, 0, 0)
+typedef short bf16x4_raw __attribute__((ext_vector_type(4)));
+#define ECAMP_MFMA_4x4x4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf16x4_raw, a), __builtin_bit_cast(bf16x4_raw, b), c, 0, 0, 0)
+#endif
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
@@ -54,8 +93,8 @@ template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&o
 }
 template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&o)[4]) {
     uint2 v = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[0] = h16_lo(v.x); o[1] = h16_hi(v.x);
+    o[2] = h16_lo(v.y); o[3] = h16_hi(v.y);
 }
 template <typename T> __device__ __forceinline__ void st4(T* p, const float (&o)[4]);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o)[4]) {

@@ -15,6 +15,8 @@ int ecamp_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* ecamp_last_error(void) { return g_ecamp_err; }
 extern "C" int ecamp_abi_version(void) { return ECAMP_ABI_VERSION; }
+// 0: dtype code ECAMP_BF16 means bfloat16 (libecamp_hip.so); 1: it means IEEE half (libecamp_hip_f16.so, built with -DECAMP_HALF_F16)
+extern "C" int ecamp_half_format(void) { return ECAMP_HALF_IS_F16; }
 
 // Development aid (tools/hog_probe.py): `blocks` workgroups that spin for `cycles` shader clocks -- a stand-in for a communication
 // kernel (RCCL all-reduce) that shares the GPU with the training step on another stream.

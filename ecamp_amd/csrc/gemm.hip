@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     f32x4 accr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8 ones = {(short)H16_ONE, (short)H16_ONE, (short)H16_ONE, (short)H16_ONE, (short)H16_ONE, (short)H16_ONE, (short)H16_ONE, (short)H16_ONE};
 
     uint4 ra_kc[4], rb_kc[4];
     uint4 ra_oc[4], rb_oc[4];
@@ -154,15 +154,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fn[tn]),
-                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = ECAMP_MFMA_16x16x32(fn[tn], fm[tm], acc[tm][tn]);
             if (do_rowsum) {
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
-                    accr[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ones),
-                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fm[tm]), accr[tm], 0, 0, 0);
+                    accr[tm] = ECAMP_MFMA_16x16x32(ones, fm[tm], accr[tm]);
             }
         }
         __syncthreads();

@@ -260,7 +260,7 @@ __device__ __forceinline__ void q16_body(const GemmArgs& g) {
             }
             if (EPI == 2) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[2 * r] += __uint_as_float(qr[I][r] << 16); v[2 * r + 1] += __uint_as_float(qr[I][r] & 0xffff0000u); }
+                for (int r = 0; r < 4; ++r) { v[2 * r] += h16_lo(qr[I][r]); v[2 * r + 1] += h16_hi(qr[I][r]); }
             }
             __builtin_amdgcn_raw_buffer_store_b128(q8_pack8(v), rC, uo[I], 0, 0);
             Q16_SB();
@@ -301,7 +301,7 @@ __device__ __forceinline__ void q16_body(const GemmArgs& g) {
 #define Q16_MFMA(S, J, ZERO)                                                                                             \
     do {                                                                                                                 \
         constexpr int i_ = (J) / NW, t_ = (J) % NW;                                                                      \
-        if (!(DBG & 1)) acc[i_][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[S][t_].get(), fa[S][i_], (ZERO) ? zero4 : acc[i_][t_], 0, 0, 0); \
+        if (!(DBG & 1)) acc[i_][t_] = ECAMP_MFMA_16x16x32(fb[S][t_].get(), fa[S][i_], (ZERO) ? zero4 : acc[i_][t_]); \
     } while (0)
     // one k-step of 32: 8 NW MFMAs with ONE other action behind every second one: the NW + 8 fragment reads of the next k-step (set NS,
     // k-step NKS of the K tile at SM_ / SN_) in the order its MFMAs consume them, then the DMA pieces of part DP0, its bookkeeping (part

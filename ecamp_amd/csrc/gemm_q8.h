@@ -35,7 +35,7 @@
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 hw_bf16x8;
+typedef hw_h16x8 hw_bf16x8;   // MFMA operand: eight elements of the build's 16-bit format (common.h)
 typedef __attribute__((ext_vector_type(4))) short q8_v4s16;
 typedef unsigned int q8_u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -441,7 +441,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                               \
             _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                          \
                 const q8_u32x4_ w_ = __builtin_bit_cast(q8_u32x4_, FM[t_].get());                                        \
-                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(rs[t_]) : "v"(w_[j_]), "v"(rs_ones));                           \
+                asm(ECAMP_DOT2C " %0, %1, %2" : "+v"(rs[t_]) : "v"(w_[j_]), "v"(rs_ones));                           \
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
@@ -465,7 +465,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
             asm volatile("" ::"v"(FN[nh_].get()), "v"(FM[tm_].get()));                                                   \
             if (ZERO) acc[tm_][nh_] = zero16;                                                                            \
         } else {                                                                                                         \
-            acc[tm_][nh_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FN[nh_].get(), FM[tm_].get(), (ZERO) ? zero16 : acc[tm_][nh_], 0, 0, 0); \
+            acc[tm_][nh_] = ECAMP_MFMA_32x32x16(FN[nh_].get(), FM[tm_].get(), (ZERO) ? zero16 : acc[tm_][nh_]); \
         }                                                                                                                \
     } while (0)
 
@@ -660,7 +660,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                 if (EPI == 3) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const f32x2_t lg_ = {__uint_as_float(qg[tm][gq][r] << 16), __uint_as_float(qg[tm][gq][r] & 0xffff0000u)};
+                        const f32x2_t lg_ = {h16_lo(qg[tm][gq][r]), h16_hi(qg[tm][gq][r])};
                         const f32x2_t gp_ = g.act == 2 ? lg_ : gelu_grad_fast_f2(lg_);   // act == 2: the forward pass saved gelu' itself (uniform branch)
                         v[2 * r] *= gp_[0];
                         v[2 * r + 1] *= gp_[1];
@@ -669,8 +669,8 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
                 if (EPI == 2 || (EPI == 3 && g.residual)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[2 * r] += __uint_as_float(qr[tm][gq][r] << 16);
-                        v[2 * r + 1] += __uint_as_float(qr[tm][gq][r] & 0xffff0000u);
+                        v[2 * r] += h16_lo(qr[tm][gq][r]);
+                        v[2 * r + 1] += h16_hi(qr[tm][gq][r]);
                     }
                 }
                 if (EPI == 4) {
@@ -903,7 +903,7 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         if (it_beg < total) Q9_CDECODE(it_beg);
         for (int cv = it_beg; cv < total; cv += G) {
             const int cm0 = nm0, cn0 = nn0, cz = nz, cnt = ncnt;
-            if (ROWSUM) { rs_on = nrs; rs_ones = rs_on ? 0x3f803f80u : 0u; }
+            if (ROWSUM) { rs_on = nrs; rs_ones = rs_on ? H16_ONE_X2 : 0u; }
             if constexpr (F8) {
                 Q9F_KTILE(true); bias_landed();
 #pragma unroll 1
@@ -927,11 +927,11 @@ __device__ __forceinline__ void q8_body(const GemmArgs& g, const Q8Group& GR) {
         if (ITEMS) {
             const Q8ItemRec cr = item_at(cv);
             cm0 = cr.m0; cn0 = cr.prob; cz = cr.slab; cnt = (cr.kend - cr.kbeg + 63) >> 6;
-            if (ROWSUM) { rs_on = (cr.flags & 1) != 0 && wc == 0 && Q8_PROB(cr.prob, rowsum) != nullptr; rs_ones = rs_on ? 0x3f803f80u : 0u; }
+            if (ROWSUM) { rs_on = (cr.flags & 1) != 0 && wc == 0 && Q8_PROB(cr.prob, rowsum) != nullptr; rs_ones = rs_on ? H16_ONE_X2 : 0u; }
         } else {
             const Q8Item cit = q8_decode(g, cv, total);
             cm0 = cit.m0; cn0 = cit.n0; cz = cit.z; cnt = cit.nt;
-            if (ROWSUM) { rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0; rs_ones = rs_on ? 0x3f803f80u : 0u; }
+            if (ROWSUM) { rs_on = g.rowsum != nullptr && wc == 0 && cit.ncol == 0; rs_ones = rs_on ? H16_ONE_X2 : 0u; }
         }
         Q8_KTILE(true); bias_landed();
 #pragma unroll 1

@@ -17,18 +17,18 @@ template <> struct LnVec<float, 4> {
 template <> struct LnVec<bf16_t, 4> {
     typedef uint2 raw_t;
     static __device__ __forceinline__ void cvt(const uint2& v, float (&o)[4]) {
-        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[0] = h16_lo(v.x); o[1] = h16_hi(v.x);
+        o[2] = h16_lo(v.y); o[3] = h16_hi(v.y);
     }
     static __device__ __forceinline__ uint2 pack(const float (&o)[4]) { return make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])); }
 };
 template <> struct LnVec<bf16_t, 8> {
     typedef uint4 raw_t;
     static __device__ __forceinline__ void cvt(const uint4& v, float (&o)[8]) {
-        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+        o[0] = h16_lo(v.x); o[1] = h16_hi(v.x);
+        o[2] = h16_lo(v.y); o[3] = h16_hi(v.y);
+        o[4] = h16_lo(v.z); o[5] = h16_hi(v.z);
+        o[6] = h16_lo(v.w); o[7] = h16_hi(v.w);
     }
     static __device__ __forceinline__ uint4 pack(const float (&o)[8]) {
         return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));

@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_reg_kernel(bf16_t* __restrict_
             float p[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[2 * r] = __uint_as_float(w[r] << 16);
-                p[2 * r + 1] = __uint_as_float(w[r] & 0xffff0000u);
+                p[2 * r] = h16_lo(w[r]);
+                p[2 * r + 1] = h16_hi(w[r]);
             }
             const float m8 = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
             if (m8 > mx) {
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_reg_kernel(bf16_t* __restrict_
             float g[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                g[2 * r] = __uint_as_float(wq[r] << 16);
-                g[2 * r + 1] = __uint_as_float(wq[r] & 0xffff0000u);
+                g[2 * r] = h16_lo(wq[r]);
+                g[2 * r + 1] = h16_hi(wq[r]);
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) g[r] = sc * (__expf(g[r] - gmx) * inv - ((long)(c * 8 + r) == label ? 1.0f : 0.0f));
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NT) void ce_fwd_bwd_row_kernel(bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const int c = threadIdx.x + NT * j;
-        q[j] = c < nv8 ? *reinterpret_cast<const uint4*>(x + c * 8) : make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);
+        q[j] = c < nv8 ? *reinterpret_cast<const uint4*>(x + c * 8) : make_uint4(H16_NEG_INF_X2, H16_NEG_INF_X2, H16_NEG_INF_X2, H16_NEG_INF_X2);
     }
     float e[NG][8];
     float mx = -INFINITY;
@@ -407,8 +407,8 @@ __global__ __launch_bounds__(NT) void ce_fwd_bwd_row_kernel(bf16_t* __restrict__
         const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            e[j][2 * r] = __uint_as_float(w[r] << 16);
-            e[j][2 * r + 1] = __uint_as_float(w[r] & 0xffff0000u);
+            e[j][2 * r] = h16_lo(w[r]);
+            e[j][2 * r + 1] = h16_hi(w[r]);
             mx = fmaxf(mx, fmaxf(e[j][2 * r], e[j][2 * r + 1]));
         }
     }

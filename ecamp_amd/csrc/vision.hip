@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void sr_fused_fwd_kernel(const float* __restri
 // f32 accumulation; u, c1 (and ds, dc1 in backward) are rounded to bf16, the skip connection and the loss stay f32.
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-#define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k((A), (B), (C), 0, 0, 0)
+#define MFMA4(A, B, C) ECAMP_MFMA_4x4x4((A), (B), (C))
 
 __device__ __forceinline__ bf16x4_t sr_pack4(float a, float b, float c) {
     uint2 u = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, 0.f));
@@ -953,9 +953,9 @@ __global__ __launch_bounds__(256, 2) void sr_fused_bwd_kernel(const float* __res
 }
 
 __device__ __forceinline__ void sr_unpack3(uint2 q, float (&v)[3]) {   // the three channels of an interleaved bf16 pixel as f32
-    v[0] = __uint_as_float(q.x << 16);
-    v[1] = __uint_as_float(q.x & 0xffff0000u);
-    v[2] = __uint_as_float(q.y << 16);
+    v[0] = h16_lo(q.x);
+    v[1] = h16_hi(q.x);
+    v[2] = h16_lo(q.y);
 }
 
 // ---- backward on the matrix cores, pixel-PAIR form (the production kernel of compute_dtype = bf16) ---------------------------------
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(256, 2) void sr_pair_bwd_kernel(const float* __rest
     bf16x4_t NAME[9];                                                        \
     _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) NAME[t_] = TAPS[(C)][t_][lane & 3]
     const f32x4_t bias1 = {P.b1[0], P.b1[1], P.b1[2], 0.f}, bias2 = {P.b2[0], P.b2[1], P.b2[2], 0.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
-    const bf16x4_t ones = {(short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80};
+    const bf16x4_t ones = {(short)H16_ONE, (short)H16_ONE, (short)H16_ONE, (short)H16_ONE};
     const int R2 = 2 * R, G = R2 / SRT, PT = SRT / 2;
     const long T = B * G * G;
     f32x4_t G1[9], G2[9], gb1 = zero4, gb2 = zero4;   // [tap][o] of input channel lane & 3, summed over this lane's block's pixels

@@ -630,7 +630,10 @@ class MlmHeadFn(torch.autograd.Function):
         if m.keep_aux:
             m._aux_logits = logits.clone()
         s = ops.zeros((1,), h.device)
-        ops.ce_fwd_bwd_(logits, labels.view(-1), weights.view(-1), s)
+        # IEEE-half mode: the kernel leaves 256 M x the gradient (|w (p - onehot)| x 256 <= 65504 for token weights up to 255; a probability
+        # keeps its 11 bits down to 2.4e-7) and backward divides the upstream gradient -- the loss scale -- by the same power of two
+        ctx.gain = 256.0 * logits.shape[0] if logits.dtype == torch.float16 else 1.0
+        ops.ce_fwd_bwd_(logits, labels.view(-1), weights.view(-1), s, gain=ctx.gain)
         ctx.s = (h, pre, t1, mean, rstd, t, logits, cls, m)
         return s * (1.0 / logits.shape[0])
 
@@ -640,7 +643,7 @@ class MlmHeadFn(torch.autograd.Function):
         A = m.arena
         G = A.grad
         pr = cls.predictions
-        g = g.contiguous()
+        g = g.contiguous() if ctx.gain == 1.0 else g * (1.0 / ctx.gain)
         _wgrad(A, dlog, t, pr.decoder.weight, alpha_dev=g, gb=G(pr.bias))
         dt = ops.linear_dgrad(dlog, A.w(pr.decoder.weight), alpha_dev=g)
         ln = pr.transform.LayerNorm

@@ -14,9 +14,13 @@ _I64x3 = ctypes.c_int64 * 3
 def code(dtype):
     if dtype == torch.float32:
         return F32
-    if dtype == torch.bfloat16:
+    if dtype == torch.bfloat16 or dtype == torch.float16:
+        want = "bf16" if dtype == torch.bfloat16 else "f16"
+        if _lib.half() != want:   # the 16-bit format is a property of the loaded build, not of the call: the wrong one would reinterpret the bits
+            raise TypeError("a %s tensor reached the %s build of libecamp_hip -- call ecamp_amd._lib.set_half(%r) first "
+                            "(ECAMP(compute_dtype=...) does)" % (dtype, _lib.half(), want))
         return BF16
-    raise TypeError("ecamp_amd supports float32 and bfloat16 activations, got %s" % dtype)
+    raise TypeError("ecamp_amd supports float32, bfloat16 and float16 activations, got %s" % dtype)
 
 
 def _chk(*ts):
@@ -180,7 +184,7 @@ def wgrad_group_supported(items):
         return False
     rows = items[0][0].shape[0]
     for dy, x, gw, gb, _ in items:
-        if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.shape[0] != rows or x.shape[0] != rows:
+        if dy.dtype not in (torch.bfloat16, torch.float16) or x.dtype != dy.dtype or dy.shape[0] != rows or x.shape[0] != rows:
             return False
         if not (dy.is_contiguous() and x.is_contiguous() and gw.is_contiguous() and gw.dtype == torch.float32):
             return False
@@ -511,11 +515,13 @@ def bert_embed_bwd(de, z, mean, rstd, gamma, ids, type_ids, gword, gpos, gtype, 
          ptr(gtype), ptr(ggamma), ptr(gbeta), B, S, H, pad_id, hot[0], hot[1], float(drop_p), seed, offset, code(de.dtype), stream())
 
 
-def ce_fwd_bwd_(logits, labels, weights, loss_sum):
-    """In place: logits -> d(mean weighted CE)/d logits (unit upstream gradient); loss_sum += sum_i w_i CE_i."""
+def ce_fwd_bwd_(logits, labels, weights, loss_sum, gain=1.0):
+    """In place: logits -> gain * d(mean weighted CE)/d logits (unit upstream gradient); loss_sum += sum_i w_i CE_i.
+    `gain` (a power of two the caller divides out of the upstream gradient again): the gradient is written in the logits' own format before
+    the loss scale is known, and w (p - onehot) / M is 1e-9 for M = 32768 rows -- zero in IEEE half."""
     _chk(logits, labels, weights)
     M, V = logits.shape
-    call("ecamp_ce_fwd_bwd", ptr(logits), ptr(labels), ptr(weights), ptr(loss_sum), M, V, logits.stride(0), 1.0 / M,
+    call("ecamp_ce_fwd_bwd", ptr(logits), ptr(labels), ptr(weights), ptr(loss_sum), M, V, logits.stride(0), float(gain) / M,
          code(logits.dtype), stream())
     return logits
 
@@ -530,12 +536,20 @@ def adamw(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
          float(wd), int(step), float(grad_scale), stream())
 
 
-def adamw_grouped(p, g, m, v, p16, block_group, lrs, wds, beta1, beta2, eps, step, grad_scale=1.0, grad_sumsq=None):
-    """grad_sumsq: optional zeroed f32[1]; receives sum((g * grad_scale)^2) over the updated elements (global grad-norm, fused)."""
+def adamw_grouped(p, g, m, v, p16, block_group, lrs, wds, beta1, beta2, eps, step, grad_scale=1.0, grad_sumsq=None, ctl=None):
+    """grad_sumsq: optional zeroed f32[1]; receives sum((g * grad_scale)^2) over the updated elements (global grad-norm, fused).
+    ctl: optional device f32[4] from loss_scale_update -- grad scale, skip flag and bias corrections are then read on the device."""
     n = len(lrs)
     arr = ctypes.c_float * n
     call("ecamp_adamw_grouped", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), ptr(block_group), p.numel(), n, arr(*lrs), arr(*wds),
-         float(beta1), float(beta2), float(eps), int(step), float(grad_scale), ptr(grad_sumsq), stream())
+         float(beta1), float(beta2), float(eps), int(step), float(grad_scale), ptr(grad_sumsq), ptr(ctl), stream())
+
+
+def loss_scale_update(sumsq_, state, opt_step, ctl, norm_out, growth, backoff, interval, beta1, beta2):
+    """GradScaler's unscale_ / step / update on the device (no host read): see include/ecamp_hip.h."""
+    _chk(sumsq_, state, opt_step, ctl)
+    call("ecamp_loss_scale_update", ptr(sumsq_), ptr(state), ptr(opt_step), ptr(ctl), ptr(norm_out), float(growth), float(backoff), int(interval),
+         float(beta1), float(beta2), stream())
 
 
 # --------------------------------------------------------------------------------------------- side-stream weight gradients

@@ -3,7 +3,7 @@ unchanged), on the MI355X-native model / optimizer / data-parallel reducer.
 
     python -m torch.distributed.run --nproc_per_node=8 -m ecamp_amd.main_pretrain --batch_size 256 --accum_iter 8 ...
 
-Extra flags (all optional): --compute_dtype {bf16,fp32}, --max_caption_length, --synthetic, --synthetic_len, --print_freq, --profile, --no_prefetch.
+Extra flags (all optional): --compute_dtype {bf16,fp16,fp32} (--amp fp16), --max_caption_length, --synthetic, --synthetic_len, --print_freq, --profile, --no_prefetch.
 When `--data_path` holds the MIMIC-CXR CSVs the `ContextBertDataset` of module/pretrain_datasets.py is used (batched
 entity-aware masker, bit-exact against the reference loop).  A missing CSV is an error (as in the reference) unless `--synthetic`
 asks for the synthetic stand-in with the same batch schema.  `--profile` puts roctx ranges around every step and its phases
@@ -70,7 +70,10 @@ def get_args_parser():
     p.add_argument("--dist_on_itp", action="store_true")
     p.add_argument("--dist_url", default="env://")
     # additions of this implementation
-    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="16-bit storage format of the activations: bf16 "
+                   "(default, the benchmarked mode), fp16 = IEEE half, what the reference's torch.cuda.amp.autocast() computes in "
+                   "(main_pretrain.py:139; libecamp_hip_f16.so; implies --loss_scale dynamic, the reference's GradScaler), fp32 = parity mode")
+    p.add_argument("--amp", default="", choices=["", "bf16", "fp16"], help="alias: --amp fp16 == --compute_dtype fp16 --loss_scale dynamic")
     p.add_argument("--gelu_saved_grad", default=1, type=int, choices=[0, 1], help="bf16 mode: 1 = the fc1 / BertIntermediate epilogue saves gelu'(x) "
                    "for the backward pass (no erf in backward; one more bf16 rounding of the derivative), 0 = save x and recompute gelu' in f32 like "
                    "the reference's GeluBackward")
@@ -144,7 +147,11 @@ def main(args):
     data_loader_train = DataLoader(dataset_train, sampler=sampler_train, batch_size=args.batch_size, num_workers=args.num_workers,
                                    pin_memory=args.pin_mem, drop_last=True, collate_fn=dataset_train.collate_fn)
 
-    dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    if args.amp:
+        args.compute_dtype = args.amp
+    if args.compute_dtype == "fp16":
+        args.loss_scale = "dynamic"   # half's 5-bit exponent needs the reference's GradScaler (util/misc.py:251-271), as its autocast does
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.compute_dtype]
     model = model_ecamp.__dict__[args.model](norm_pix_loss=args.norm_pix_loss, compute_dtype=dtype, gelu_saved_grad=bool(args.gelu_saved_grad))
     model.to(device)
     model_without_ddp = model

@@ -83,8 +83,8 @@ class ECAMP(nn.Module):
         for d, h in ((embed_dim, num_heads), (decoder_embed_dim, decoder_num_heads)):
             if d % h != 0 or d // h not in (32, 64, 128):
                 raise ValueError("head_dim must be 32, 64 or 128 (got %d/%d)" % (d, h))
-        if compute_dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute_dtype must be torch.float32 (parity mode) or torch.bfloat16")
+        if compute_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("compute_dtype must be torch.float32 (parity mode), torch.bfloat16 or torch.float16 (the reference's autocast format)")
         self.img_size, self.patch_size, self.embed_dim = img_size, patch_size, embed_dim
         self.num_heads, self.decoder_embed_dim, self.decoder_num_heads = num_heads, decoder_embed_dim, decoder_num_heads
         self.compute_dtype = compute_dtype
@@ -103,7 +103,7 @@ class ECAMP(nn.Module):
         # the environment's ECAMP_GELU_SAVED_GRAD, default on.
         if gelu_saved_grad is None:
             gelu_saved_grad = os.environ.get("ECAMP_GELU_SAVED_GRAD", "1") != "0"
-        self.gelu_saved_grad = bool(gelu_saved_grad) and compute_dtype == torch.bfloat16
+        self.gelu_saved_grad = bool(gelu_saved_grad) and compute_dtype in (torch.bfloat16, torch.float16)
         self.gelu_act = 2 if self.gelu_saved_grad else 1
         self.bert_config = bert_config if bert_config is not None else BertConfig()
         # image encoder (model_ecamp.py:58-69)
@@ -188,10 +188,13 @@ class ECAMP(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def prepare(self):
-        """Move the parameters into the flat HBM arenas (idempotent).  Called lazily by forward()."""
+        """Move the parameters into the flat HBM arenas (idempotent).  Called lazily by forward() and by every public stage method, so it
+        is also where the process is switched to the build of this model's 16-bit format (bf16: libecamp_hip.so; torch.float16, the
+        reference's autocast format: libecamp_hip_f16.so) -- backward and the optimizer run under the same setting."""
+        from .. import _lib
+        _lib.set_half(self.compute_dtype)
         if self.arena is None:
             from ..arena import ParamArena
-            from .. import _lib
             _lib.load()
             self.arena = ParamArena(self, self.compute_dtype)
             self._rng_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) & 0xFFFFFFFFFFFFFFFF

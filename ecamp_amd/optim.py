@@ -48,6 +48,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("all groups must share betas and eps")
         self._arena = None
         self._step = 0
+        self._step_dev = None       # f32[1] on the device: the count of steps actually taken when a loss scaler decides skips there (`ctl`)
         self.grad_scale = 1.0
         self.bucketwise_steps = 0   # optimizer steps that ran bucket by bucket behind the gradient all-reduces
         self._inflight = collections.deque()
@@ -101,21 +102,39 @@ class FusedAdamW(torch.optim.Optimizer):
         self._arena = arena
         return arena
 
-    def _launch(self, A, lo, hi, grad_sumsq):
+    @property
+    def steps_taken(self):
+        """Optimizer steps applied so far (a step skipped by the dynamic loss scaler does not count; reading it waits for the device)."""
+        if self._step_dev is not None:
+            self._step = int(self._step_dev.item())
+        return self._step
+
+    def step_counter(self):
+        """The device-side step count (created from the host's on first use): ecamp_loss_scale_update advances it only on clean steps."""
+        if self._step_dev is None:
+            self._step_dev = torch.full((1,), float(self._step), device=self._bind().device, dtype=torch.float32)
+        return self._step_dev
+
+    def _launch(self, A, lo, hi, grad_sumsq, ctl=None):
         g0 = self.param_groups[0]
         ops.adamw_grouped(A.flat_p[lo:hi], A.flat_g[lo:hi], self._m[lo:hi], self._v[lo:hi], A.flat_p16[lo:hi] if A.flat_p16 is not None else None,
                           self._table[lo // 64:hi // 64], [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups],
-                          g0["betas"][0], g0["betas"][1], g0["eps"], self._step, self.grad_scale, grad_sumsq)
+                          g0["betas"][0], g0["betas"][1], g0["eps"], max(self._step, 1), self.grad_scale, grad_sumsq, ctl)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_sumsq=None):
+    def step(self, closure=None, grad_sumsq=None, ctl=None):
+        """`ctl` (device f32[4], hip_ops.loss_scale_update): the gradient scale, the bias corrections and whether this step happens at all
+        are read on the device; the step count then lives in `step_counter()`."""
         loss = closure() if closure is not None else None
         A = self._bind()
         events = None
         if A.reducer is not None:
             A.reducer.assert_reduced()   # loud failure instead of a silent step on un-reduced gradients
             events = A.reducer.take_bucket_events()
-        self._step += 1
+        if ctl is None:
+            if self._step_dev is not None:      # back from device-decided steps to host-counted ones
+                self._step, self._step_dev = self.steps_taken, None
+            self._step += 1
         if events and not A._fresh:
             # data parallel, lazy join (GradReducer.lazy): one slice of the fused kernel per gradient bucket, each behind its own
             # all-reduce, in the order the collectives were issued -- the update of the early buckets runs while the last ones
@@ -123,13 +142,13 @@ class FusedAdamW(torch.optim.Optimizer):
             cur = torch.cuda.current_stream()
             for lo, hi, ev in events:
                 cur.wait_event(ev)
-                self._launch(A, lo, hi, grad_sumsq)
+                self._launch(A, lo, hi, grad_sumsq, ctl)
             self.bucketwise_steps += 1
         else:
             for _, _, ev in events or ():    # (a module did not run this window: zero its weights only behind every collective)
                 torch.cuda.current_stream().wait_event(ev)
             A.flush_fresh()
-            self._launch(A, 0, A.total, grad_sumsq)
+            self._launch(A, 0, A.total, grad_sumsq, ctl)
         A.version += 1   # the bf16 shadows changed: the fp8-forward mode re-quantises its weight copies on next use
         self.pace()
         return loss
@@ -165,6 +184,7 @@ class FusedAdamW(torch.optim.Optimizer):
     # -- checkpoint format compatible with torch.optim.AdamW (misc.py:295-338) ---------------------------------
     def state_dict(self):
         A = self._bind()
+        self._step = self.steps_taken
         state, packed_groups, idx = {}, [], 0
         for g in self.param_groups:
             ids = []
@@ -193,5 +213,5 @@ class FusedAdamW(torch.optim.Optimizer):
                     o, n = A.offsets[i], A.sizes[i]
                     self._m[o:o + n].view(p.shape).copy_(st["exp_avg"])
                     self._v[o:o + n].view(p.shape).copy_(st["exp_avg_sq"])
-                    self._step = int(float(st["step"]))
+                    self._step, self._step_dev = int(float(st["step"])), None
                 idx += 1

@@ -277,8 +277,11 @@ class NativeScalerWithGradNormCount:
     (x 0.5, growth tracker to 0) or, after `growth_interval` clean steps in a row, grows (x 2).  A reference checkpoint's scaler state is
     loaded and continued.  On the arena path the check is one sum-of-squares pass over the flat gradient buffer (a non-finite sum <=> a
     non-finite element, up to |g| > 1.8e19), the un-scaling is folded into AdamW's read of the gradient (`grad_scale`) and into the norm:
-    p.grad keeps the SCALED values until zero_grad().  One host read of the check per optimizer step -- GradScaler.step does the same
-    (`found_inf.item()`).  Activations stay bf16: fp16 autocast (main_pretrain.py:139) is not built."""
+    p.grad keeps the SCALED values until zero_grad().  The decision itself (skip / backoff / growth) is taken ON THE DEVICE
+    (ecamp_loss_scale_update -> AdamW's `ctl`): GradScaler.step blocks the host on `found_inf.item()` once per optimizer step, this class
+    never does -- scale, growth tracker, skipped-step count and the optimizer's step count are device values that get_scale(),
+    skipped_steps, last_found_inf, state_dict() read back only when asked.  With `compute_dtype=torch.float16` (`--amp fp16`:
+    IEEE-half activations, libecamp_hip_f16.so) this is the reference's autocast + GradScaler pair (main_pretrain.py:139)."""
     state_dict_key = "amp_scaler"
 
     def __init__(self, dynamic=None, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
@@ -287,10 +290,40 @@ class NativeScalerWithGradNormCount:
         self.dynamic = bool(dynamic)
         self._state = {"scale": float(init_scale) if self.dynamic else 1.0, "growth_factor": float(growth_factor), "backoff_factor": float(backoff_factor),
                        "growth_interval": int(growth_interval), "_growth_tracker": 0}
-        self.skipped_steps = 0      # optimizer steps skipped because a gradient overflowed (dynamic mode)
-        self.last_found_inf = False
+        self._skipped = 0           # optimizer steps skipped because a gradient overflowed (dynamic mode)
+        self._last_found_inf = False
+        # fused path: scale / growth tracker / skipped count live on the device (f32[4]; hip_ops.loss_scale_update keeps them) so that no
+        # step waits for the overflow flag; `_dev_ctl` is what the last update handed to AdamW.  The host copies above are refreshed on demand.
+        self._dev = None
+        self._dev_ctl = None
+        self.last_step_fused = None   # whether the last dynamic update ran as the three device launches (tests assert it on the arena path)
+
+    def _to_device(self, device):
+        if self._dev is None:
+            st = self._state
+            self._dev = torch.tensor([st["scale"], float(st["_growth_tracker"]), float(self._skipped), 0.0], device=device, dtype=torch.float32)
+            self._dev_ctl = torch.zeros((4,), device=device, dtype=torch.float32)
+        return self._dev
+
+    def _from_device(self):
+        """Refresh the host copy of the scaler state (waits for the device).  No-op when the state lives on the host."""
+        if self._dev is not None:
+            scale, tracker, skipped, _ = self._dev.tolist()
+            self._state["scale"], self._state["_growth_tracker"], self._skipped = float(scale), int(tracker), int(skipped)
+            self._last_found_inf = bool(self._dev_ctl[1].item() != 0)
+
+    @property
+    def skipped_steps(self):
+        self._from_device()
+        return self._skipped
+
+    @property
+    def last_found_inf(self):
+        self._from_device()
+        return self._last_found_inf
 
     def get_scale(self):
+        self._from_device()
         return self._state["scale"]
 
     def _update(self, found_inf):
@@ -307,34 +340,41 @@ class NativeScalerWithGradNormCount:
 
     def _dynamic_step(self, optimizer, clip_grad, parameters):
         """unscale_ + grad norm + scaler.step + scaler.update of misc.py:262-269 for the scaled gradients sitting in p.grad."""
-        scale = self._state["scale"]
-        inv = 1.0 / scale
         ps = list(parameters) if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]]
-        arena = getattr(ps[0], "_ecamp_arena", None) if ps else None
+        live = [p for p in ps if p.grad is not None]         # (frozen tensors -- the sin-cos position tables -- carry no gradient and are not in the arena)
+        arena = getattr(live[0], "_ecamp_arena", None) if live else None
         fused = (clip_grad is None and arena is not None and hasattr(optimizer, "covers") and optimizer.covers(ps)
-                 and all(getattr(p, "_ecamp_arena", None) is arena for p in ps))
+                 and all(getattr(p, "_ecamp_arena", None) is arena for p in live))
+        self.last_step_fused = fused
         if fused:
+            # Everything on the device, nothing read back: one pass for sum(g^2) over the SCALED gradients (inf / nan = overflow), one
+            # single-thread kernel for GradScaler's decision + update (and AdamW's bias corrections at the count of steps actually taken),
+            # then AdamW, which un-scales as it reads and leaves the arenas alone when told to skip.  The reference blocks on
+            # found_inf.item() here; a host that waits once per step cannot queue the next one while this one runs (+16 ms per step).
             from .. import hip_ops as ops
+            st = self._state
+            dev = self._to_device(arena.device)
             s = ops.zeros((1,), arena.device)
-            ops.sumsq(arena.flat_g, s)                       # over the SCALED gradients: one pass, no per-tensor launches
-            found_inf = not math.isfinite(float(s))          # the one host read of the step (GradScaler.step: found_inf.item())
-            norm = (s.sqrt() * inv).reshape(())              # inf / nan on overflow, like the reference's norm of the unscaled gradients
-            if not found_inf:
-                optimizer.grad_scale = inv                   # AdamW reads g * inv: the un-scaling without a pass of its own
-                try:
-                    optimizer.step()
-                finally:
-                    optimizer.grad_scale = 1.0
-        else:   # any optimizer / CPU tensors / clip_grad: GradScaler's own order of operations in plain torch
-            grads = [p.grad for p in ps if p.grad is not None]
-            for g in grads:
-                g.mul_(inv)
-            found_inf = any(not bool(torch.isfinite(g).all()) for g in grads)
-            norm = torch.nn.utils.clip_grad_norm_(ps, clip_grad) if clip_grad is not None else get_grad_norm_(ps)
-            if not found_inf:
-                optimizer.step()
-        self.last_found_inf = found_inf
-        self.skipped_steps += int(found_inf)
+            norm = torch.empty((1,), device=arena.device, dtype=torch.float32)
+            ops.sumsq(arena.flat_g, s)
+            b1, b2 = optimizer.param_groups[0]["betas"]
+            ops.loss_scale_update(s, dev, optimizer.step_counter(), self._dev_ctl, norm, st["growth_factor"], st["backoff_factor"],
+                                  st["growth_interval"], b1, b2)
+            optimizer.step(ctl=self._dev_ctl)
+            return norm.reshape(())                          # inf / nan on overflow, like the reference's norm of the unscaled gradients
+        self._from_device()                                  # (a fused step ran before: continue from its state on the host)
+        self._dev = None
+        # any optimizer / CPU tensors / clip_grad: GradScaler's own order of operations in plain torch
+        inv = 1.0 / self._state["scale"]
+        grads = [p.grad for p in ps if p.grad is not None]
+        for g in grads:
+            g.mul_(inv)
+        found_inf = any(not bool(torch.isfinite(g).all()) for g in grads)
+        norm = torch.nn.utils.clip_grad_norm_(ps, clip_grad) if clip_grad is not None else get_grad_norm_(ps)
+        if not found_inf:
+            optimizer.step()
+        self._last_found_inf = found_inf
+        self._skipped += int(found_inf)
         self._update(found_inf)
         return norm
 
@@ -350,7 +390,10 @@ class NativeScalerWithGradNormCount:
         if lazy:
             reducer.lazy = True    # the end-of-backward callback leaves the buckets' events to the optimizer (GradReducer.lazy)
         try:
-            (loss * self._state["scale"] if self.dynamic else loss).backward(create_graph=create_graph)   # scaler.scale(loss).backward()
+            if self.dynamic:   # scaler.scale(loss).backward(); the scale is read from the device when it lives there (no host wait)
+                (loss * (self._dev[0] if self._dev is not None and loss.is_cuda else self._state["scale"])).backward(create_graph=create_graph)
+            else:
+                loss.backward(create_graph=create_graph)
         finally:
             if lazy:
                 reducer.lazy = False
@@ -381,6 +424,7 @@ class NativeScalerWithGradNormCount:
         return norm
 
     def state_dict(self):
+        self._from_device()
         return dict(self._state)
 
     def load_state_dict(self, state_dict):
@@ -390,7 +434,9 @@ class NativeScalerWithGradNormCount:
         if not self.dynamic:
             keep.pop("scale", None)
             keep.pop("_growth_tracker", None)
+        self._from_device()
         self._state.update(keep)
+        self._dev = None   # re-created from the host state at the next fused step
 
 
 # --------------------------------------------------------------------------------------------- checkpoints

@@ -24,13 +24,20 @@ typedef struct ihipStream_t* ecampStream_t; /* == hipStream_t */
 #define ECAMP_BF16 1
 
 /* Bumped whenever an exported signature changes (2: ecamp_wgrad_group gained table_bytes, ecamp_gemm_fp8 its q8_* arguments;
- * 3: round 5 -- ecamp_dropout_mask, ecamp_prof_dump, ecamp_fp8_roll's amax history and margin).  ecamp_abi_version()
+ * 3: round 5 -- ecamp_dropout_mask, ecamp_prof_dump, ecamp_fp8_roll's amax history and margin; 4: round 6 -- ecamp_adamw_grouped's
+ * `ctl`, ecamp_loss_scale_update, ecamp_half_format, the resample entry points).  ecamp_abi_version()
  * returns the value the library was BUILT with; a consumer compares it with the header it was compiled against -- the Python binding
  * (ecamp_amd/_lib.py) refuses a library of another version, which is what protects an A/B of two builds (ECAMP_LIB, tools/ab_lib.sh)
  * from calling an older build with a newer argument list. */
-#define ECAMP_ABI_VERSION 3
+#define ECAMP_ABI_VERSION 4
 int ecamp_abi_version(void);
 const char* ecamp_last_error(void);
+/* The 16-bit activation format of THIS build -- what dtype code ECAMP_BF16 (1) stores.  0: bfloat16 (libecamp_hip.so, the benchmarked
+ * mode).  1: IEEE half (libecamp_hip_f16.so: the same sources compiled with -DECAMP_HALF_F16), the format the reference's
+ * torch.cuda.amp.autocast() computes its linear layers and attention products in (main_pretrain.py:139, engine_pretrain.py:44); it is
+ * run with dynamic loss scaling (util/misc.py:251-271).  Accumulation, LayerNorm / softmax statistics, losses, parameters and their
+ * gradients are f32 in both.  The e4m3 forward (ecamp_gemm_fp8 and its producers) exists in the bfloat16 build only. */
+int ecamp_half_format(void);
 
 /* ---- dense contractions -------------------------------------------------------------------------------------
  * C[M,N] (+)= epi( alpha * (alpha_dev ? *alpha_dev : 1) * sum_k opA[m,k] opB[k,n] ); a_kc/b_kc = operand is contiguous along the contraction.
@@ -260,10 +267,18 @@ int ecamp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int6
 
 int ecamp_adamw_grouped(float* p, const float* g, float* m, float* v, void* p_bf16, const uint8_t* block_group, int64_t n,
                         int32_t ngroups, const float* lr_host, const float* wd_host, float beta1, float beta2, float eps,
-                        int64_t step, float grad_scale, float* grad_sumsq,
+                        int64_t step, float grad_scale, float* grad_sumsq, const float* ctl,
                         ecampStream_t stream); /* whole-arena AdamW with timm's decay/no-decay groups, main_pretrain.py:253-254;
                                                 * grad_sumsq (nullable, caller-zeroed): += sum of (g * grad_scale)^2 over the updated
-                                                * elements -- the global gradient norm of util/misc.py:280-292 without a second pass */
+                                                * elements -- the global gradient norm of util/misc.py:280-292 without a second pass;
+                                                * ctl (nullable, device f32[4] written by ecamp_loss_scale_update): {grad_scale, skip, bias
+                                                * corrections} read on the DEVICE instead of `step` / `grad_scale` -- a skipped step writes nothing */
+/* GradScaler's unscale_ + step + update (util/misc.py:262-269: `self._scaler.unscale_`, `.step(optimizer)`, `.update()`) decided on the
+ * device, so the training loop never waits for the overflow flag: sumsq = sum(g^2) over the scaled gradients (ecamp_sumsq);
+ * state f32[4] = {scale, growth tracker, skipped steps, unused}; opt_step f32[1] = optimizer steps actually taken (bias corrections);
+ * ctl f32[4] = output for ecamp_adamw_grouped; norm_out (nullable) = sqrt(sumsq) / scale. */
+int ecamp_loss_scale_update(const float* sumsq, float* state, float* opt_step, float* ctl, float* norm_out, float growth_factor,
+                            float backoff_factor, int32_t growth_interval, float beta1, float beta2, ecampStream_t stream);
 
 /* ---- optional in-process timing (bench.py roofline): HIP-event pairs around every GEMM / attention launch ---- */
 int ecamp_prof_enable(int on);

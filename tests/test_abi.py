@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def lib():
-    if not os.path.exists(_lib.LIB_PATH):
+    if not all(os.path.exists(p) for p in _lib.LIB_PATHS.values()):
         from ecamp_amd import build
-        build.build(verbose=False)
+        build.build(verbose=False, half="both")
     return _lib.load()
 
 
@@ -37,15 +37,40 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), name
     # the library reports the version of the header it was built against; the binding refuses any other (an older build must never be
     # called with this header's argument lists: ECAMP_LIB / tools/ab_lib.sh)
-    assert lib.ecamp_abi_version() == _lib.abi_version_of_header() >= 3
+    assert lib.ecamp_abi_version() == _lib.abi_version_of_header() >= 4
 
 
 def test_binding_refuses_a_library_of_another_abi_version(lib, monkeypatch):
     v = _lib.abi_version_of_header()
     monkeypatch.setattr(_lib, "abi_version_of_header", lambda path=None: v + 1)   # a header one version ahead of the built library
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     with pytest.raises(_lib.EcampHipError, match="ABI version mismatch"):
         _lib.load()
+
+
+def test_both_builds_export_the_whole_abi_and_say_which_format_they_store(lib, monkeypatch):
+    """libecamp_hip.so (bfloat16) and libecamp_hip_f16.so (IEEE half: the reference's autocast format, main_pretrain.py:139) are the same
+    sources; each exports every declared symbol, reports its format, and the binding refuses a swapped pair."""
+    import torch
+    assert lib.ecamp_half_format() == 0
+    f16 = _lib.load("f16")
+    assert f16.ecamp_half_format() == 1 and f16 is not lib
+    for name in _lib.parse_header():
+        assert hasattr(f16, name), name
+    prev = _lib.set_half(torch.float16)
+    try:
+        assert _lib.half() == "f16" and _lib.load() is f16
+        assert _lib.set_half(torch.float32) == "f16" and _lib.half() == "f16"      # f32 parity mode leaves the choice alone
+        from ecamp_amd import hip_ops
+        assert hip_ops.code(torch.float16) == _lib.BF16
+        with pytest.raises(TypeError, match="set_half"):
+            hip_ops.code(torch.bfloat16)                                          # a bf16 tensor must never reach the f16 build
+    finally:
+        _lib.set_half(prev)
+    monkeypatch.setattr(_lib, "_libs", {})
+    monkeypatch.setattr(_lib, "LIB_PATHS", {"bf16": _lib.LIB_PATHS["f16"], "f16": _lib.LIB_PATHS["bf16"]})
+    with pytest.raises(_lib.EcampHipError, match="swapped"):
+        _lib.load("bf16")
 
 
 def test_signatures_have_no_torch_types():

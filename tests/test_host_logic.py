@@ -108,7 +108,7 @@ def test_bad_configs_are_rejected():
     with pytest.raises(ValueError):
         BertConfig(hidden_act="relu")
     with pytest.raises(ValueError):
-        me.ECAMP(compute_dtype=torch.float16)
+        me.ECAMP(compute_dtype=torch.float64)
 
 
 def test_synthetic_dataset_schema():

@@ -11,10 +11,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import h16
+
 pytestmark = pytest.mark.gpu
 
-DT = [torch.float32, torch.bfloat16]
-TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+DT = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}   # half keeps 11 significant bits where bfloat16 keeps 8
 
 
 def ops():
@@ -57,12 +59,13 @@ def test_gemm_fwd_epilogues(dev, dtype, M, N, K):
     ref_pre = x @ w.T + b
     check("linear pre", pre, ref_pre, tol)
     check("linear gelu", y, F.gelu(rnd(ref_pre, dtype) if dtype != torch.float32 else ref_pre), tol)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         y32 = o.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
         assert y32.dtype == torch.float32
         check("linear f32-out", y32, x @ w.T + b, 2e-3)
 
 
+@pytest.mark.usefixtures("both_halves")
 @pytest.mark.parametrize("M,N,K,q8", [(394, 768, 192, 0), (1000, 520, 200, 2), (512, 3072, 768, 2), (512, 3072, 768, 0)])
 def test_gemm_gelu_saved_derivative(dev, M, N, K, q8):
     """ecamp_gemm act = 2 (bf16): the GELU epilogue leaves gelu'(pre-activation) in `pre_out` instead of the pre-activation, and the
@@ -71,7 +74,7 @@ def test_gemm_gelu_saved_derivative(dev, M, N, K, q8):
     derivative is gelu' of the ROUNDED pre-activation to one bf16 rounding, and the two-step gradient equals the one-step (act = 1)
     gradient to bf16 accuracy."""
     o = ops()
-    dt = torch.bfloat16
+    dt = h16()
     x, w, b = rnd(gen(M, K, seed=1), dt), rnd(gen(N, K, seed=2, scale=K ** -0.5), dt), gen(N, seed=3)
     dy, w2 = rnd(gen(M, 256, seed=5), dt), rnd(gen(256, N, seed=6, scale=256 ** -0.5), dt)   # the next layer: [M,256] = gelu(..)[M,N] @ w2^T
     xd, wd, bd, dyd, w2d = x.to(dev, dt), w.to(dev, dt), b.to(dev), dy.to(dev, dt), w2.to(dev, dt)
@@ -123,11 +126,12 @@ def test_gemm_dgrad_wgrad(dev, dtype, M, N, K):
     check("wgrad + fused bias grad (b)", gb2, gen(N, seed=9) + 0.5 * dy.sum(0), 2e-5 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.usefixtures("both_halves")
 def test_gemm_rejects_bad_alignment(dev):
     o = ops()
     from ecamp_amd._lib import EcampHipError
-    x = torch.zeros(8, 30, device=dev, dtype=torch.bfloat16)
-    w = torch.zeros(16, 30, device=dev, dtype=torch.bfloat16)
+    x = torch.zeros(8, 30, device=dev, dtype=h16())
+    w = torch.zeros(16, 30, device=dev, dtype=h16())
     with pytest.raises(EcampHipError):
         o.linear_fwd(x, w)
 
@@ -184,7 +188,7 @@ def test_layernorm_dropout_consistency(dev, dtype):
     dz, dxd = o.layernorm_bwd(dy, z, mean, rstd, g, gg, gb, drop_p=p, seed=1234, offset=77, want_drop=True)
     dzf, dxf = dz.float().cpu(), dxd.float().cpu()
     assert ((dxf != 0) <= keep).all(), "bwd mask is not a subset of the fwd mask"
-    check("dropout bwd scale", dxf, dzf * keep.float() / 0.9, 2e-2 if dtype == torch.bfloat16 else 1e-6)
+    check("dropout bwd scale", dxf, dzf * keep.float() / 0.9, 2e-2 if dtype != torch.float32 else 1e-6)
     # a different offset must give a different mask
     _, z3, _, _ = o.layernorm_fwd(x, g, b, 1e-6, residual=res, drop_p=p, seed=1234, offset=78)
     assert (z3.float().cpu() != zf).float().mean().item() > 0.05
@@ -284,6 +288,7 @@ def test_attention_dropout_statistics(dev):
                                                    (2, 12, 50, 50, 64, False, 0.2), (1, 4, 250, 256, 64, True, 0.1), (2, 3, 33, 17, 32, True, 0.3),
                                                    # the same kernel instantiation first below, then above the 48 KB LDS opt-in threshold
                                                    (1, 2, 70, 70, 64, False, 0.0), (1, 2, 200, 200, 64, False, 0.0)])
+@pytest.mark.usefixtures("both_halves")
 def test_attention_head_kernels_match_streaming_kernels(dev, B, H, Tq, Tk, hd, masked, p):
     """The head-resident kernels (one workgroup per (batch, head), P kept in registers, one fused backward kernel) and the 64-row
     streaming kernels implement the same function with the same Philox dropout mask: same seed/offset -> same dropped entries, outputs
@@ -291,7 +296,7 @@ def test_attention_head_kernels_match_streaming_kernels(dev, B, H, Tq, Tk, hd, m
     sequences that do not fill the last 32-key pair."""
     o = ops()
     D = H * hd
-    dt = torch.bfloat16
+    dt = h16()
     q = rnd(gen(B, Tq, D, seed=11), dt).to(dev, dt)
     k = rnd(gen(B, Tk, D, seed=12), dt).to(dev, dt)
     v = rnd(gen(B, Tk, D, seed=13), dt).to(dev, dt)
@@ -327,13 +332,14 @@ def test_attention_head_kernels_match_streaming_kernels(dev, B, H, Tq, Tk, hd, m
 
 @pytest.mark.parametrize("B,H,Tq,Tk,hd,masked,p", [(2, 6, 128, 128, 128, True, 0.1), (2, 6, 128, 49, 128, False, 0.1), (1, 4, 250, 256, 64, True, 0.1),
                                                    (2, 3, 33, 17, 32, True, 0.3), (2, 12, 50, 50, 64, False, 0.2)])
+@pytest.mark.usefixtures("both_halves")
 def test_attention_saved_dropout_bits_equal_regenerated_mask(dev, B, H, Tq, Tk, hd, masked, p):
     """The forward pass can leave the dropout keep-mask as bits (ecamp_attn_mask_bytes / drop_mask) so that the backward pass does not
     evaluate Philox again: the gradients must be BIT-IDENTICAL to the backward pass that regenerates the mask from (seed, offset), for
     key masks, an odd key count (per-element Philox path), partial last tile pairs and the longest head-resident sequence."""
     o = ops()
     D = H * hd
-    dt = torch.bfloat16
+    dt = h16()
     q = rnd(gen(B, Tq, D, seed=21), dt).to(dev, dt)
     k = rnd(gen(B, Tk, D, seed=22), dt).to(dev, dt)
     v = rnd(gen(B, Tk, D, seed=23), dt).to(dev, dt)
@@ -440,7 +446,7 @@ def test_layernorm_dropout_residual_matches_pytorch_under_the_same_mask(dev, dty
     dz, dxd = o.layernorm_bwd(dy.to(dev, dtype), z, mean, rstd, g.to(dev), gg, gb, drop_p=p, seed=seed, offset=offset, want_drop=True)
     check("ln dropout d residual", dz, rr.grad, tol * 2)
     check("ln dropout d dense-out", dxd, xr.grad, tol * 2)
-    ptol = 1e-2 if dtype == torch.bfloat16 else 2e-5
+    ptol = 1e-2 if dtype != torch.float32 else 2e-5
     check("ln dropout dgamma", gg, gr.grad, ptol)
     check("ln dropout dbeta", gb, br.grad, ptol)
 
@@ -622,7 +628,7 @@ def test_image_losses_and_sr_head(dev, dtype, R, win):
     dsr = o.sr_bwd(pimg_d, big.to(dev), column.to(dev), row.to(dev), *wd, gw, 2 * p, win)
     gmgs = torch.tensor([g_mim * 2 / n1, g_res * 2 / n2], device=dev)
     dpred = o.img_loss_bwd(pimg_d, imgs.to(dev), mask.to(dev), dsr, gmgs, B, R, p, dtype)
-    check("d pred (mim + SR branch)", dpred.view(B, L + 1, -1), pr.grad, 1e-2 if dtype == torch.bfloat16 else 1e-4)
+    check("d pred (mim + SR branch)", dpred.view(B, L + 1, -1), pr.grad, 1e-2 if dtype != torch.float32 else 1e-4)
     s = g_res * 2 / n2
     gtol = 1e-4  # the fused SR head is f32 in LDS whatever the activation dtype
     check("d conv1.weight", gw[0:81] * s, ws[0].grad.view(-1), gtol)
@@ -710,7 +716,7 @@ def test_weighted_cross_entropy(dev, dtype, M, V):
     s = torch.zeros(1, device=dev)
     o.ce_fwd_bwd_(ld, labels.to(dev), w.to(dev), s)
     check("mlm loss", s / M, loss.view(1), 1e-5)
-    check("d logits", ld, lr.grad, TOL[dtype] if dtype == torch.bfloat16 else 1e-5)
+    check("d logits", ld, lr.grad, TOL[dtype] if dtype != torch.float32 else 1e-5)
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -730,7 +736,7 @@ def test_weighted_cross_entropy_ignore_index(dev, dtype):
     s = torch.zeros(1, device=dev)
     o.ce_fwd_bwd_(ld, labels.to(dev), w.to(dev), s)
     check("mlm loss (ignored labels)", s / M, loss.view(1), 1e-5)
-    check("d logits (ignored labels)", ld, lr.grad, TOL[dtype] if dtype == torch.bfloat16 else 1e-5)
+    check("d logits (ignored labels)", ld, lr.grad, TOL[dtype] if dtype != torch.float32 else 1e-5)
     assert float(ld[::3].float().abs().max()) == 0.0
 
 
@@ -754,19 +760,20 @@ def test_small_ops(dev, dtype):
     check("seq_bcast add", y, ref + g[:, None], tol)
     out = torch.zeros(H, device=dev)
     o.colsum(xd.view(B * S, H), out, 1.0, S, 0, 1)
-    check("colsum cls rows", out, x[:, 0].sum(0), 1e-2 if dtype == torch.bfloat16 else 1e-5)
+    check("colsum cls rows", out, x[:, 0].sum(0), 1e-2 if dtype != torch.float32 else 1e-5)
     out = torch.zeros(H, device=dev)
     o.colsum(xd.view(B * S, H), out, 1.0, S, 1, S)
-    check("colsum non-cls rows", out, x[:, 1:].sum((0, 1)), 1e-2 if dtype == torch.bfloat16 else 1e-5)
+    check("colsum non-cls rows", out, x[:, 1:].sum((0, 1)), 1e-2 if dtype != torch.float32 else 1e-5)
     u = o.uniform((4, 196), dev, 42, 0)
     assert 0.0 <= u.min().item() and u.max().item() < 1.0 and abs(u.mean().item() - 0.5) < 0.05
     assert (u != o.uniform((4, 196), dev, 42, 1)).any() and (u == o.uniform((4, 196), dev, 42, 0)).all()
     f = gen(1000, seed=3).to(dev)
-    h = torch.empty(1000, device=dev, dtype=torch.bfloat16)
+    h = torch.empty(1000, device=dev, dtype=h16())
     o.cast(f, h)
-    assert (h.cpu() == f.cpu().to(torch.bfloat16)).all(), "f32->bf16 must be round-to-nearest-even"
+    assert (h.cpu() == f.cpu().to(h16())).all(), "f32->bf16 must be round-to-nearest-even"
 
 
+@pytest.mark.usefixtures("both_halves")
 def test_adamw_and_gradnorm(dev):
     o = ops()
     n = 4096 * 3
@@ -774,7 +781,7 @@ def test_adamw_and_gradnorm(dev):
     pr = p0.clone().requires_grad_(True)
     opt = torch.optim.AdamW([pr], lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05)
     p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-    p16 = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    p16 = torch.empty(n, device=dev, dtype=h16())
     for step in range(1, 4):
         g = g0 * step
         pr.grad = g.clone()
@@ -782,7 +789,7 @@ def test_adamw_and_gradnorm(dev):
         o.adamw(p, g.to(dev), m, v, p16, 1.5e-4, 0.9, 0.95, 1e-8, 0.05, step)
     check("adamw 3 steps (params)", p, pr.detach(), 1e-6)
     check("adamw 3 steps (update; f32 cancellation-limited)", p - p0.to(dev), pr.detach() - p0, 3e-3)
-    assert (p16.cpu() == p.cpu().to(torch.bfloat16)).all()
+    assert (p16.cpu() == p.cpu().to(h16())).all()
     s = torch.zeros(1, device=dev)
     o.sumsq(g0.to(dev), s)
     check("grad norm", s.sqrt(), g0.norm().view(1), 1e-5)
@@ -811,11 +818,12 @@ def test_attention_long_sequence_f32(dev, B, H, Tq, Tk, hd, masked):
     check("long f32 attn dv", dv, vr.grad, 5e-5)
 
 
+@pytest.mark.usefixtures("both_halves")
 @pytest.mark.parametrize("B,H,Tq,Tk,hd,masked", [(1, 16, 785, 785, 32, False), (2, 4, 300, 300, 64, True), (1, 3, 70, 520, 128, False)])
 def test_attention_long_sequence_bf16(dev, B, H, Tq, Tk, hd, masked):
     """Tk > 256 (ViT-L/16 at 448^2: decoder sequence 785) runs the online-softmax forward and the chunk-streaming backward."""
     o = ops()
-    dtype = torch.bfloat16
+    dtype = h16()
     D = H * hd
     q, k, v = rnd(gen(B, Tq, D, seed=1), dtype), rnd(gen(B, Tk, D, seed=2), dtype), rnd(gen(B, Tk, D, seed=3), dtype)
     do = rnd(gen(B, Tq, D, seed=4), dtype)
@@ -854,21 +862,23 @@ def _q8_count():
     return int(_lib.load().ecamp_gemm_q8_launches())
 
 
+@pytest.mark.usefixtures("both_halves")
 @pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 2304, 768), (512, 128, 3072), (256, 30000, 768), (1000, 1000, 200), (300, 520, 136)])
 def test_gemm_q8_fwd_epilogues_ragged(dev, q8_always, M, N, K):
     """test_gemm_fwd_epilogues on the Q8 kernel: ragged M and N (edge tiles, groups of 8 past N), K with a partial last K tile,
     two to 48 K tiles, one or many output tiles per workgroup (N = 30000: 118 tiles)."""
     n0 = _q8_count()
-    test_gemm_fwd_epilogues(dev, torch.bfloat16, M, N, K)
+    test_gemm_fwd_epilogues(dev, h16(), M, N, K)
     assert _q8_count() >= n0 + 3, "the Q8 kernel did not run"
 
 
+@pytest.mark.usefixtures("both_halves")
 @pytest.mark.parametrize("M,N,K", [(394, 768, 192), (100, 3072, 768), (256, 30000, 768), (1000, 520, 264)])
 def test_gemm_q8_dgrad_wgrad_ragged(dev, q8_always, M, N, K):
     """Data gradient (strided weight operand, transpose reads) with gelu' / residual epilogues, weight gradient (both operands
     strided, split-K slabs) and the bias gradient summed inside it, on ragged shapes."""
     n0 = _q8_count()
-    test_gemm_dgrad_wgrad(dev, torch.bfloat16, M, N, K)
+    test_gemm_dgrad_wgrad(dev, h16(), M, N, K)
     assert _q8_count() >= n0 + 5, "the Q8 kernel did not run"
 
 
@@ -887,6 +897,7 @@ def _q16_count():
     return int(_lib.load().ecamp_gemm_q16_launches())
 
 
+@pytest.mark.usefixtures("both_halves")
 @pytest.mark.parametrize("M,N,K", [(394, 768, 192), (1000, 520, 200), (512, 1536, 136), (300, 2304, 768), (2048, 192, 1088), (777 * 8, 768, 264)])
 def test_gemm_q16_forward_and_data_gradient_ragged(dev, q16_always, M, N, K):
     """The four-wave v_mfma_f32_16x16x32_bf16 kernel (csrc/gemm_q16.h) forced on ragged shapes: forward form y = x w^T + b (+ residual) and
@@ -894,7 +905,7 @@ def test_gemm_q16_forward_and_data_gradient_ragged(dev, q16_always, M, N, K):
     picked by the shapes: N = 768 / 192 / 1536 take 192, N = 520 / 2304 take 256), partial last K tiles, one tile per workgroup and several;
     the launch counter proves the kernel ran."""
     o = ops()
-    dt = torch.bfloat16
+    dt = h16()
     x = rnd(gen(M, K, seed=1), dt)
     w = rnd(gen(N, K, seed=2) * K ** -0.5, dt)
     b = gen(N, seed=3)
@@ -919,12 +930,13 @@ def test_gemm_q16_forward_and_data_gradient_ragged(dev, q16_always, M, N, K):
         assert _q16_count() - n0 == 3
 
 
+@pytest.mark.usefixtures("both_halves")
 def test_gemm_q16_is_deterministic_and_selected_for_the_768_wide_outputs(dev):
     """Default kernel selection ("q16_mode" 1): the model's 768-wide outputs at B = 256 (150 / 384 tiles of 256 x 256: 41 % / 25 % of the last
     round idle) run on the four-wave kernel's 256 x 192 tile, the other shapes stay on the eight-wave kernel; repeated launches are
     bit-identical (no atomics, a race screen of the DMA / barrier protocol)."""
     o = ops()
-    dt = torch.bfloat16
+    dt = h16()
     for M, N, K, want in ((12800, 768, 3072, 1), (32768, 768, 768, 1), (12800, 3072, 768, 0), (32768, 1536, 768, 0)):
         x = rnd(gen(M, K, seed=1), dt).to(dev, dt)
         w = rnd(gen(N, K, seed=2) * K ** -0.5, dt).to(dev, dt)
@@ -940,6 +952,7 @@ def test_gemm_q16_is_deterministic_and_selected_for_the_768_wide_outputs(dev):
         assert (y[0][:64].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+@pytest.mark.usefixtures("both_halves")
 @pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (1000, 520, 264), (50432, 512, 2048)])
 def test_gemm_q8_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q8_always, M, N, K):
     """`q8_bwd_grid` (what the data-parallel wrapper sets): the data-gradient form on one workgroup per output tile, on half as many
@@ -947,10 +960,10 @@ def test_gemm_q8_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q8_a
     the same bits, with the gelu' / residual epilogues as well."""
     o = q8_always
     g = torch.Generator().manual_seed(5)
-    dy = torch.randn(M, K, generator=g).to(dev, torch.bfloat16)          # dX[M, N] = dY[M, K] W[K, N]  (W stored [K, N]: strided operand)
-    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(dev, torch.bfloat16)
-    pre = torch.randn(M, N, generator=g).to(dev, torch.bfloat16)
-    res = torch.randn(M, N, generator=g).to(dev, torch.bfloat16)
+    dy = torch.randn(M, K, generator=g).to(dev, h16())          # dX[M, N] = dY[M, K] W[K, N]  (W stored [K, N]: strided operand)
+    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(dev, h16())
+    pre = torch.randn(M, N, generator=g).to(dev, h16())
+    res = torch.randn(M, N, generator=g).to(dev, h16())
     outs = []
     tiles = -(-M // 256) * -(-N // 256)
     try:
@@ -969,6 +982,7 @@ def test_gemm_q8_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q8_a
             assert torch.equal(x, y)
 
 
+@pytest.mark.usefixtures("both_halves")
 @pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (1000, 520, 264), (32768, 768, 1536)])
 def test_gemm_q16_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q16_always, M, N, K):
     """with the default kernel selection the 768-wide data gradients run on the FOUR-wave kernel, so `q8_bwd_grid` must reach
@@ -976,9 +990,9 @@ def test_gemm_q16_data_gradient_one_tile_per_workgroup_is_bit_identical(dev, q16
     epilogues -- the forms the four-wave kernel has), and the four-wave kernel is what ran."""
     from ecamp_amd import hip_ops as o
     g = torch.Generator().manual_seed(6)
-    dy = torch.randn(M, K, generator=g).to(dev, torch.bfloat16)
-    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(dev, torch.bfloat16)
-    res = torch.randn(M, N, generator=g).to(dev, torch.bfloat16)
+    dy = torch.randn(M, K, generator=g).to(dev, h16())
+    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(dev, h16())
+    res = torch.randn(M, N, generator=g).to(dev, h16())
     outs = []
     tiles = -(-M // 256) * -(-N // 192)
     try:
@@ -1004,10 +1018,10 @@ def test_gemm_full_size_kernels_agree(dev):
     same inputs (both accumulate in f32; only the summation order differs), and both against a float64 sample of rows."""
     o = ops()
     M, N, K = 12800, 3072, 768
-    x = (torch.randn(M, K, generator=torch.Generator().manual_seed(1))).to(dev, torch.bfloat16)
-    w = (torch.randn(N, K, generator=torch.Generator().manual_seed(2)) * K ** -0.5).to(dev, torch.bfloat16)
+    x = (torch.randn(M, K, generator=torch.Generator().manual_seed(1))).to(dev, h16())
+    w = (torch.randn(N, K, generator=torch.Generator().manual_seed(2)) * K ** -0.5).to(dev, h16())
     b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
-    dy = torch.randn(M, N, generator=torch.Generator().manual_seed(4)).to(dev, torch.bfloat16)
+    dy = torch.randn(M, N, generator=torch.Generator().manual_seed(4)).to(dev, h16())
     res = {}
     for mode in (0, 8):   # 128^2 kernel, persistent 256^2 kernel (Q8)
         o.set_option("q8_mode", 2 if mode == 8 else 0)
@@ -1065,7 +1079,7 @@ def test_gemm_fp8_forward_epilogues(dev, M, N, K):
     """fp8 forward GEMM == f32 matmul of the DEQUANTISED operands (the only rounding left is the bf16 output / f32 summation
     order), for every forward epilogue; and within the e4m3 quantisation noise of the unquantised product."""
     o = ops()
-    dtype = torch.bfloat16
+    dtype = h16()
     x, w, b, r = rnd(gen(M, K, seed=1), dtype), rnd(gen(N, K, seed=2, scale=K ** -0.5), dtype), gen(N, seed=3), rnd(gen(M, N, seed=4), dtype)
     xd, wd, bd, rd = x.to(dev, dtype), w.to(dev, dtype), b.to(dev), r.to(dev, dtype)
     w8, ws = o.quantize_fp8(wd)
@@ -1097,7 +1111,7 @@ def test_gemm_fp8_persistent_kernel_forced_on_ragged_shapes(dev, M, N, K):
     o = ops()
     from ecamp_amd import _lib
     lib = _lib.load()
-    dtype = torch.bfloat16
+    dtype = h16()
     x, w, b, r = rnd(gen(M, K, seed=1), dtype), rnd(gen(N, K, seed=2, scale=K ** -0.5), dtype), gen(N, seed=3), rnd(gen(M, N, seed=4), dtype)
     xd, wd, bd, rd = x.to(dev, dtype), w.to(dev, dtype), b.to(dev), r.to(dev, dtype)
     w8, ws = o.quantize_fp8(wd)
@@ -1137,7 +1151,7 @@ def test_fp8_delayed_scaling_kernels(dev):
     scale); ecamp_layernorm_fwd_q8's e4m3 copy is bit-identical to quantising its bf16 output afterwards, with and without the fused
     residual + dropout, for 768- and 512-column rows (16-B lane accesses) and a 100-column row (the 4-wide form)."""
     o = ops()
-    x = (gen(300, 512, seed=11, scale=3.0)).to(dev, torch.bfloat16)
+    x = (gen(300, 512, seed=11, scale=3.0)).to(dev, h16())
     scale = torch.tensor([0.0123], device=dev)
     slots = torch.zeros(2 * 512, device=dev)
     q = o.quantize_fp8_site(x, scale, slots[:512], True)
@@ -1154,8 +1168,8 @@ def test_fp8_delayed_scaling_kernels(dev):
     q3, s3 = o.quantize_fp8(x)
     assert torch.equal(q2, q3) and sc2.item() == s3.item() and sl2[0].item() == x.float().abs().max().item()
     for rows, cols in ((260, 768), (130, 512), (50, 100)):
-        xx = gen(rows, cols, seed=3).to(dev, torch.bfloat16)
-        rr = gen(rows, cols, seed=4).to(dev, torch.bfloat16)
+        xx = gen(rows, cols, seed=3).to(dev, h16())
+        rr = gen(rows, cols, seed=4).to(dev, h16())
         g, b = (1.0 + 0.1 * gen(cols, seed=5)).to(dev), (0.1 * gen(cols, seed=6)).to(dev)
         for kw in ({}, dict(residual=rr, drop_p=0.1, seed=7, offset=9)):
             sc, sl = torch.tensor([0.011], device=dev), torch.zeros(512, device=dev)
@@ -1167,30 +1181,32 @@ def test_fp8_delayed_scaling_kernels(dev):
             assert sl.view(16, 32)[:, 0].max().item() == y0.float().abs().max().item()
 
 
+@pytest.mark.usefixtures("both_halves")
 def test_gemm_rows_past_2gb_are_split(dev):
     """An output of more than 2 GB (the vocabulary projection at B = 512) runs as two row halves on the persistent kernel; the rows on
     both sides of the seam match the same rows computed as a small GEMM."""
     o = ops()
     M, N, K = 65536, 16400, 128           # 65536 x 16400 bf16 = 2.15 GB
-    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(dev, torch.bfloat16)
-    w = (torch.randn(N, K, generator=torch.Generator().manual_seed(2)) * K ** -0.5).to(dev, torch.bfloat16)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(dev, h16())
+    w = (torch.randn(N, K, generator=torch.Generator().manual_seed(2)) * K ** -0.5).to(dev, h16())
     b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
     n0 = _q8_count()
     y = o.linear_fwd(x, w, b)
     assert _q8_count() >= n0 + 2, "the two halves did not run on the Q8 kernel"
     for r0 in (0, 32768 - 8, 32768, 65536 - 16):
-        ref = (x[r0:r0 + 16].float() @ w.float().t() + b).to(torch.bfloat16).float()
+        ref = (x[r0:r0 + 16].float() @ w.float().t() + b).to(h16()).float()
         assert (y[r0:r0 + 16].float() - ref).abs().max() < 3e-2 * ref.abs().max()
     del y
 
 
+@pytest.mark.usefixtures("both_halves")
 def test_gemm_wgrad_contraction_past_2gb_is_split(dev):
     """A weight gradient whose dy operand passes 2 GB (the vocabulary head at B = 512) runs as two calls over halves of the rows, the second
     accumulating: weight and bias gradient against torch on a column sample."""
     o = ops()
     M, N, K = 65536, 16400, 128           # dy [M, N] bf16 = 2.15 GB
-    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(dev, torch.bfloat16)
-    dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(dev, h16())
+    dy = torch.randn(M, N, device=dev, dtype=h16())
     gw = torch.zeros(N, K, device=dev)
     gb = torch.zeros(N, device=dev)
     n0 = _q8_count()
@@ -1208,6 +1224,7 @@ def test_gemm_wgrad_contraction_past_2gb_is_split(dev):
                                          (1000, [(1000, 520), (264, 264), (520, 1000)]),      # rows: no multiple of 64 (partial last K tile)
                                          (12608, [(3072, 1024), (1024, 1024)]),               # ViT-L/448: 197 K tiles (odd)
                                          (12800, [(2304, 768), (768, 768), (3072, 768), (768, 3072)])])
+@pytest.mark.usefixtures("both_halves")
 def test_wgrad_group_matches_per_layer_weight_gradients(dev, rows, shapes):
     """ecamp_wgrad_group (the weight and bias gradients of a block's linear layers as ONE item-table launch of the Q8 kernel + one
     grouped reduce) against the per-layer GEMMs: K ranges cut across tile boundaries, ragged output shapes, overwrite and accumulate,
@@ -1216,8 +1233,8 @@ def test_wgrad_group_matches_per_layer_weight_gradients(dev, rows, shapes):
     gen_ = torch.Generator().manual_seed(rows)
     items, refs = [], []
     for i, (n_out, k_in) in enumerate(shapes):
-        dy = (torch.randn(rows, n_out, generator=gen_) * 0.5).to(dev, torch.bfloat16)
-        x = torch.randn(rows, k_in, generator=gen_).to(dev, torch.bfloat16)
+        dy = (torch.randn(rows, n_out, generator=gen_) * 0.5).to(dev, h16())
+        x = torch.randn(rows, k_in, generator=gen_).to(dev, h16())
         acc = i % 2 == 1
         base = torch.randn(n_out, k_in, generator=gen_).to(dev) if acc else torch.zeros(n_out, k_in, device=dev)
         gw, gw_ref = base.clone(), base.clone()
@@ -1241,6 +1258,7 @@ def test_wgrad_group_matches_per_layer_weight_gradients(dev, rows, shapes):
         assert (gw - gw_ref).abs().max() < 1e-4 * gw_ref.abs().max() + 1e-3
 
 
+@pytest.mark.usefixtures("both_halves")
 def test_wgrad_group_refuses_a_table_built_for_another_plan(dev):
     """the grouped launch reads counts and offsets from the host-side plan and the items from the caller's device table; a
     process-wide switch flipped through the RAW C ecamp_set_option (which does not clear the Python table cache) changes the plan.
@@ -1249,7 +1267,7 @@ def test_wgrad_group_refuses_a_table_built_for_another_plan(dev):
     o = ops()
     lib = _lib.load()
     rows, shapes = 12800, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
-    items = [((torch.randn(rows, a) * 0.5).to(dev, torch.bfloat16), torch.randn(rows, b).to(dev, torch.bfloat16), torch.zeros(a, b, device=dev),
+    items = [((torch.randn(rows, a) * 0.5).to(dev, h16()), torch.randn(rows, b).to(dev, h16()), torch.zeros(a, b, device=dev),
               torch.zeros(a, device=dev), False) for a, b in shapes]
     o.wgrad_group(items)
     try:
@@ -1262,6 +1280,7 @@ def test_wgrad_group_refuses_a_table_built_for_another_plan(dev):
     torch.cuda.synchronize()
 
 
+@pytest.mark.usefixtures("both_halves")
 def test_profiling_events_are_bounded(dev):
     """csrc/profile.hip: `main_pretrain.py --profile` brackets every GEMM / attention launch of a whole epoch with HIP events; the pool
     holds at most 4096 pairs however many launches are recorded (finished records are folded into running totals), and the totals
@@ -1270,8 +1289,8 @@ def test_profiling_events_are_bounded(dev):
     from ecamp_amd import _lib
     lib = _lib.load()
     o = ops()
-    x = torch.randn(256, 128, device=dev).bfloat16()
-    w = torch.randn(64, 128, device=dev).bfloat16()
+    x = torch.randn(256, 128, device=dev).to(h16())
+    w = torch.randn(64, 128, device=dev).to(h16())
     lib.ecamp_prof_collect(-1, None, None, None)
     lib.ecamp_prof_enable(1)
     try:

@@ -245,6 +245,7 @@ def test_dynamic_loss_scale_matches_torch_grad_scaler_on_the_oracle(dev):
               ours.state_dict()["_growth_tracker"], ref.state_dict()["_growth_tracker"], ours.last_found_inf, float(n_our), float(n_ref)))
         assert ours.state_dict() == ref.state_dict(), (step, ours.state_dict(), ref.state_dict())
         assert ours.last_found_inf == (step == 1)
+        assert ours.last_step_fused, "the arena path must take GradScaler's decision on the device (sumsq -> loss_scale_update -> AdamW ctl)"
         if step == 1:
             assert not math.isfinite(float(n_our)) and not math.isfinite(float(n_ref))
         else:   # 1e-3 on the first step (same parameters on both sides); later steps see parameters that Adam's first updates (+-lr per
