@@ -719,6 +719,34 @@ def test_weighted_cross_entropy(dev, dtype, M, V):
     check("d logits", ld, lr.grad, TOL[dtype] if dtype != torch.float32 else 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_cross_entropy_gradient_gain_at_the_benchmark_row_count(dev, dtype):
+    """The MLM head's rows at configs[1] (M = 256 x 128 = 32768): d(mean CE)/d logit = w (p - onehot) / M is ~1e-9 off the label column --
+    below IEEE half's smallest subnormal (6e-8): written as it is, the softmax part of the gradient is ZERO in the f16 build (the run
+    learns from the one-hot column alone; `tools/dtype_trajectory.py` saw the MLM loss fall 40 % slower).  MlmHeadFn therefore asks for
+    gain = 256 M and divides it out of the upstream gradient; bfloat16's eight exponent bits need none (gain 1 == the round-5 call)."""
+    o = ops()
+    M, V = 32768, 512
+    logits = rnd(gen(M, V, seed=1) * 3, dtype)
+    labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(2))
+    w = torch.rand(M, generator=torch.Generator().manual_seed(3)) * 2
+    lr = logits.clone().requires_grad_(True)
+    (F.cross_entropy(lr, labels, reduction="none") * w).mean().backward()
+    gain = 256.0 * M if dtype == torch.float16 else 1.0
+    ld, s = logits.to(dev, dtype), torch.zeros(1, device=dev)
+    o.ce_fwd_bwd_(ld, labels.to(dev), w.to(dev), s, gain=gain)
+    check("d logits x gain", ld.float() / gain, lr.grad, TOL[dtype])
+    off = torch.ones(M, V, dtype=torch.bool)
+    off[torch.arange(M), labels] = False
+    check("d logits off the label column", (ld.float().cpu() / gain)[off], lr.grad[off], TOL[dtype])
+    if dtype == torch.float16:
+        l1, s1 = logits.to(dev, dtype), torch.zeros(1, device=dev)
+        o.ce_fwd_bwd_(l1, labels.to(dev), w.to(dev), s1)
+        lost = float((l1.float().cpu()[off] == 0).float().mean())
+        print("  without the gain %.1f %% of the off-label gradient entries are zero in IEEE half" % (100 * lost))
+        assert lost > 0.5
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_weighted_cross_entropy_ignore_index(dev, dtype):
     """CrossEntropyLoss's ignore_index (-100, honoured by the reference's loss at bert_modeling.py:212): zero loss and a zero
