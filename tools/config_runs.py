@@ -9,15 +9,18 @@ from ecamp_amd.data import synthetic_batch
 from ecamp_amd.module import model_ecamp
 from ecamp_amd.util.misc import NativeScalerWithGradNormCount
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=8)
-ap.add_argument("--only", default="", help="substring of the config name, e.g. 'configs[3]' or 'fp8'"); args = ap.parse_args()
+ap.add_argument("--only", default="", help="substring of the config name, e.g. 'configs[3]' or 'fp8'")
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="fp16: IEEE-half activations + dynamic loss scaling (--amp fp16); the fp8 line is skipped")
+args = ap.parse_args()
+CD = torch.float16 if args.dtype == "fp16" else torch.bfloat16
 dev = torch.device("cuda:0")
 def run(name, ctor, B, big, **kw):
-    if args.only and args.only not in name:
+    if (args.only and args.only not in name) or (args.dtype == "fp16" and kw.get("fp8_forward")):
         return
     torch.manual_seed(0)
-    model = ctor(compute_dtype=torch.bfloat16, **kw).to(dev); model.prepare(); model.train()
+    model = ctor(compute_dtype=CD, **kw).to(dev); model.prepare(); model.train()
     opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1.5e-4, betas=(0.9, 0.95))
-    scaler = NativeScalerWithGradNormCount()
+    scaler = NativeScalerWithGradNormCount(dynamic=(args.dtype == "fp16"))
     batch = synthetic_batch(B, 128, big, seed=0, device=dev)
     def step():
         mim, res, mlm = model(batch)
@@ -30,9 +33,10 @@ def run(name, ctor, B, big, **kw):
     for i in range(args.steps): out = step(); marks[i + 1].record()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
     per_step = [round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(args.steps)]
-    r = {"config": name, "pairs_per_gpu": B, "ms_per_step": round(1e3 * dt, 2), "pairs_per_s": round(B / dt, 1),
+    r = {"config": name, "dtype": args.dtype, "pairs_per_gpu": B, "ms_per_step": round(1e3 * dt, 2), "pairs_per_s": round(B / dt, 1),
          "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses": [round(float(t), 4) for t in out],
-         "step_ms": per_step, "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - n0}
+         "step_ms": per_step, "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - n0,
+         **({"loss_scale": scaler.get_scale(), "skipped_steps": scaler.skipped_steps} if scaler.dynamic else {})}
     print(json.dumps(r), flush=True)
     del model, opt, batch
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
