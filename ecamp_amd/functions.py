@@ -64,6 +64,7 @@ def _issue(items, workgroups=0):
             ops.linear_wgrad_async(dy, x, gw, gb=gb, accumulate=acc)
 
 
+_MLM_CHUNK_ROWS = int(__import__("os").environ.get("ECAMP_MLM_CHUNK_ROWS", "0"))   # > 0: MlmHeadFn._chunked (the decoder + CE + its backward, `rows` at a time)
 _FIRST_GROUP = int(__import__("os").environ.get("ECAMP_WGRAD_GROUP_SIZE", "4"))   # layers in a block's first launch, issued as soon as they
 # are collected (1: the first layer alone, 2: the MLP pair, 4: nothing early -- the whole block as ONE launch when its backward has been queued;
 # with the segment-major item table of round 3 that measured 38.3 against 38.65 ms per step for the pair launches, same box)
@@ -626,6 +627,8 @@ class MlmHeadFn(torch.autograd.Function):
             t1, pre = ops.linear_fwd(h, A.w(pr.transform.dense.weight), pr.transform.dense.bias.data, act=1, save_pre=True)
             ln = pr.transform.LayerNorm
             t, _, mean, rstd = ops.layernorm_fwd(t1, ln.weight.data, ln.bias.data, ln.eps)
+            if _MLM_CHUNK_ROWS > 0 and t.shape[0] > _MLM_CHUNK_ROWS and ctx.needs_input_grad[0] and not m.keep_aux:
+                return MlmHeadFn._chunked(ctx, h, labels, weights, cls, m, t1, pre, mean, rstd, t, _MLM_CHUNK_ROWS)
             logits = ops.linear_fwd(t, A.w(pr.decoder.weight), pr.bias.data)
         if m.keep_aux:
             m._aux_logits = logits.clone()
@@ -638,14 +641,53 @@ class MlmHeadFn(torch.autograd.Function):
         return s * (1.0 / logits.shape[0])
 
     @staticmethod
+    def _chunked(ctx, h, labels, weights, cls, m, t1, pre, mean, rstd, t, chunk):
+        """SURVEY K20, the form that fits this machine ("never materialise the logits" without recomputing them): the 30000-way decoder,
+        the cross-entropy and the decoder's OWN backward run chunk by chunk over the rows inside forward -- logits of `chunk` rows are
+        written, turned into their gradient in place and consumed by the data- and weight-gradient GEMMs while they are still in the
+        last-level cache; what survives the forward pass is d loss / d t [M, 768] and the decoder's weight / bias gradient for a UNIT upstream
+        gradient (f32, 92 MB), which backward scales by the upstream gradient that arrives then.  The [M, 30000] tensor (1.97 GB at
+        configs[1]) never exists."""
+        A, pr = m.arena, cls.predictions
+        M, V = t.shape[0], pr.decoder.weight.shape[0]
+        W = A.w(pr.decoder.weight)
+        lab, wts = labels.view(-1), weights.view(-1)
+        s = ops.zeros((1,), h.device)
+        gain = 256.0 * M if t.dtype == torch.float16 else 1.0
+        gw = torch.empty((V, W.shape[1]), device=h.device, dtype=torch.float32)
+        gb = ops.zeros((V,), h.device)
+        dts = []
+        for r0 in range(0, M, chunk):
+            r1 = min(M, r0 + chunk)
+            lg = ops.linear_fwd(t[r0:r1], W, pr.bias.data)
+            ops.ce_fwd_bwd_(lg, lab[r0:r1], wts[r0:r1], s, gain=gain * (r1 - r0) / M)     # (the kernel divides by its own row count)
+            dts.append(ops.linear_dgrad(lg, W))
+            ops.linear_wgrad(lg, t[r0:r1], gw, gb=gb, accumulate=r0 > 0)
+        ctx.gain = gain
+        ctx.s = (h, pre, t1, mean, rstd, t, None, cls, m)
+        ctx.unit = (torch.cat(dts, 0), gw, gb)
+        return s * (1.0 / M)
+
+    @staticmethod
     def backward(ctx, g):
         h, pre, t1, mean, rstd, t, dlog, cls, m = ctx.s
         A = m.arena
         G = A.grad
         pr = cls.predictions
         g = g.contiguous() if ctx.gain == 1.0 else g * (1.0 / ctx.gain)
-        _wgrad(A, dlog, t, pr.decoder.weight, alpha_dev=g, gb=G(pr.bias))
-        dt = ops.linear_dgrad(dlog, A.w(pr.decoder.weight), alpha_dev=g)
+        if dlog is None:     # chunked head: the decoder's gradients exist for a unit upstream gradient
+            dt_u, gw_u, gb_u = ctx.unit
+            ctx.unit = None
+            gw, acc = A.gradw(pr.decoder.weight)
+            if not acc:
+                ops.zero_(gw)
+            gs = g.reshape(1)
+            ops.scaled_accum(gw_u.view(-1), gw.view(-1), gs, 0)
+            ops.scaled_accum(gb_u, G(pr.bias), gs, 0)
+            dt = (dt_u * g.reshape(1)).to(dt_u.dtype)     # (in f32: the upstream gradient is not a power of two in general)
+        else:
+            _wgrad(A, dlog, t, pr.decoder.weight, alpha_dev=g, gb=G(pr.bias))
+            dt = ops.linear_dgrad(dlog, A.w(pr.decoder.weight), alpha_dev=g)
         ln = pr.transform.LayerNorm
         dt1 = ops.layernorm_bwd(dt, t1, mean, rstd, ln.weight.data, G(ln.weight), G(ln.bias))
         # t1 = gelu(pre): chain through GELU' elementwise via the dgrad-style epilogue of an identity is not available;

@@ -425,6 +425,46 @@ def test_train_mode_matches_oracle_under_the_same_dropout_masks(dev, dtype, ltol
     assert med < med_tol and errs[worst] < max_tol, (med, worst, errs[worst])
 
 
+@pytest.mark.parametrize("dtype,gtol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)])   # measured 1.0e-6 / 8.1e-3 / 9.8e-4
+def test_chunked_mlm_head_never_holds_the_logits_and_equals_the_whole_one(dev, dtype, gtol, monkeypatch):
+    """SURVEY K20 ("never materialise the logits", bert_modeling.py:206-217) as the option `ECAMP_MLM_CHUNK_ROWS`: the 30000-way decoder, the
+    weighted cross-entropy and the decoder's own backward run `rows` rows at a time inside forward (MlmHeadFn._chunked), so the largest tensor
+    of the head is [rows, vocab] instead of [B*S, vocab].  Same loss and same gradients as the materialise-once head (the default, which is
+    faster on this machine: DESIGN 7.5) -- only the weight gradient's summation order differs; an upstream gradient that is not a power of two
+    (loss x 0.3 here) reaches every tensor at full precision."""
+    from ecamp_amd import functions, hip_ops
+    from oracle import recipe
+    res = {}
+    vocab_rows = []
+    real_fwd = hip_ops.linear_fwd
+
+    def spy(x, w, *a, **k):
+        if w.shape[0] == 30000:
+            vocab_rows.append(x.shape[0])
+        return real_fwd(x, w, *a, **k)
+    monkeypatch.setattr(hip_ops, "linear_fwd", spy)
+    for rows in (0, 192):
+        monkeypatch.setattr(functions, "_MLM_CHUNK_ROWS", rows)
+        model, cfg = _build("base_b2_s256", dtype, dev)     # B*S = 512 rows: chunks of 192, 192, 128
+        model.eval()
+        out = model(recipe.recipe_batch(cfg, 2, 256, seed=0), mask_ratio=0.75, noise=recipe.recipe_noise(2, cfg.num_patches, seed=0))
+        lscale = 65536.0 if dtype == torch.float16 else 1.0
+        (sum(out) * 0.3 * lscale).backward()
+        torch.cuda.synchronize()
+        res[rows] = ([t.item() for t in out], {n: p.grad.float().clone() / lscale for n, p in model.named_parameters() if p.grad is not None})
+        del model, out
+    (l0, g0), (l1, g1) = res[0], res[192]
+    print("  losses", l0, l1, "rows of the vocabulary GEMMs", vocab_rows)
+    assert vocab_rows == [512, 192, 192, 128]     # whole head: one [512, 30000] tensor; chunked: never more than [192, 30000]
+    assert rel(l1, l0) < 1e-6
+    gmax = max(v.norm().item() for v in g0.values())
+    # (16-bit modes: the unit-gradient form rounds d loss / d t once more than the whole head; tensors whose true gradient is zero -- the key
+    # biases -- are rounding noise in both and skipped, as in the golden tests)
+    worst = max(((g1[n] - g0[n]).norm().item() / (g0[n].norm().item() + 1e-30), n) for n in g0 if dtype == torch.float32 or g0[n].norm().item() > 1e-3 * gmax)
+    print("  worst gradient difference %.2e (%s)" % worst)
+    assert worst[0] < gtol, worst
+
+
 def test_cls_alias_and_own_masking_noise(dev):
     """Old `cross_attn_layer` checkpoint keys load; without injected noise the model draws its own Philox noise."""
     from oracle import recipe
