@@ -48,6 +48,31 @@ extern "C" int ecamp_cast(const void* src, void* dst, int64_t n, int32_t src_dty
     return 0;
 }
 
+// y = x * alpha * (alpha_dev ? *alpha_dev : 1), computed in f32 (x and y may be the same buffer): the upstream gradient applied to a tensor
+// that was computed for a unit upstream gradient (the chunked MLM head)
+template <typename T>
+__global__ void scale_kernel(const T* __restrict__ x, T* __restrict__ y, long n4, float alpha, const float* __restrict__ alpha_dev) {
+    const float a = alpha_dev ? alpha * alpha_dev[0] : alpha;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float p[4];
+        ld4<T>(x + i * 4, p);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] *= a;
+        st4<T>(y + i * 4, p);
+    }
+}
+extern "C" int ecamp_scale(const void* x, void* y, int64_t n, float alpha, const float* alpha_dev, int32_t dtype, hipStream_t stream) {
+    ECAMP_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "ecamp_scale: bad args (n=%ld)", (long)n);
+    const long n4 = n / 4;
+    int nb = (int)((n4 + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    if (dtype == ECAMP_F32) hipLaunchKernelGGL(scale_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)x, (float*)y, n4, alpha, alpha_dev);
+    else if (dtype == ECAMP_BF16) hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n4, alpha, alpha_dev);
+    else return ecamp_set_error(-1, "ecamp_scale: bad dtype");
+    ECAMP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ecamp_zero(void* p, int64_t bytes, hipStream_t stream) {
     ECAMP_CHECK_ARG(p && bytes >= 0, "ecamp_zero: bad args");
     hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, stream);

@@ -684,7 +684,7 @@ class MlmHeadFn(torch.autograd.Function):
             gs = g.reshape(1)
             ops.scaled_accum(gw_u.view(-1), gw.view(-1), gs, 0)
             ops.scaled_accum(gb_u, G(pr.bias), gs, 0)
-            dt = (dt_u * g.reshape(1)).to(dt_u.dtype)     # (in f32: the upstream gradient is not a power of two in general)
+            dt = ops.scale_(dt_u, alpha_dev=gs)     # (in f32 arithmetic: the upstream gradient is not a power of two in general)
         else:
             _wgrad(A, dlog, t, pr.decoder.weight, alpha_dev=g, gb=G(pr.bias))
             dt = ops.linear_dgrad(dlog, A.w(pr.decoder.weight), alpha_dev=g)

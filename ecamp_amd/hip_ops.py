@@ -331,6 +331,14 @@ def cast(src, dst):
     return dst
 
 
+def scale_(x, alpha=1.0, alpha_dev=None):
+    """x *= alpha * alpha_dev[0] in place (f32 arithmetic, any activation dtype)."""
+    _chk(x, alpha_dev)
+    assert x.is_contiguous() and x.numel() % 4 == 0
+    call("ecamp_scale", ptr(x), ptr(x), x.numel(), float(alpha), ptr(alpha_dev), code(x.dtype), stream())
+    return x
+
+
 def zero_blocks_(g, flags):
     """Zero the 64-element blocks of the f32 arena `g` whose byte in `flags` (uint8, len = g.numel() / 64) is non-zero."""
     _chk(g, flags)

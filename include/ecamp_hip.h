@@ -179,6 +179,9 @@ int ecamp_attn_probs(const void* q, const void* k, const int32_t* key_mask, floa
 int ecamp_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, ecampStream_t stream);
 int ecamp_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, ecampStream_t stream);
 int ecamp_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, ecampStream_t stream);
+/* y = x * alpha * (alpha_dev ? *alpha_dev : 1) in f32 arithmetic; x == y allowed (autograd's scaling of a gradient tensor by an upstream
+ * scalar, bert_modeling.py:213-217 -> loss.backward()) */
+int ecamp_scale(const void* x, void* y, int64_t n, float alpha, const float* alpha_dev, int32_t dtype, ecampStream_t stream);
 int ecamp_zero(void* p, int64_t bytes, ecampStream_t stream);
 /* out[n] += alpha * sum over rows m (optionally only rows with lo <= m % period < hi) of X[m*ld+n]: bias grads,
  * cls-token grad (model_ecamp.py:228-230). */

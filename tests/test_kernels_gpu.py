@@ -779,6 +779,8 @@ def test_small_ops(dev, dtype):
     check("add", o.add(xd, xd), 2 * x, tol)
     check("bcast_add", o.bcast_add(xd, gd), x + g[:, None], tol)
     check("seq_sum (gap mean)", o.seq_sum(xd, 1, S, 1.0 / (S - 1)), x[:, 1:].mean(1), tol)
+    a_dev = torch.tensor([0.3], device=dev)
+    check("scale_ (x *= alpha * alpha_dev, in place)", o.scale_(xd.clone(), alpha=2.0, alpha_dev=a_dev), 0.6 * x, tol)
     y = torch.full((B, S, H), 7.0, device=dev, dtype=dtype)
     o.seq_bcast(gd, y, 1, S, 0.5, 0)
     ref = torch.zeros(B, S, H)
