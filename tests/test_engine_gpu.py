@@ -51,6 +51,27 @@ def test_main_pretrain_with_uint8_images(dev, tmp_path):
     assert stats[-1]["train_mlm_loss"] < stats[0]["train_mlm_loss"]
 
 
+def test_main_pretrain_amp_fp16(dev, tmp_path):
+    """`--amp fp16` through the command line: IEEE-half activations (libecamp_hip_f16.so) + the dynamic loss scaler, accumulation 2,
+    checkpoints whose `scaler` entry is GradScaler's state -- losses finite and falling like the bf16 run's, no step skipped at 65536."""
+    from ecamp_amd import _lib, main_pretrain
+    args = _args(tmp_path, ["--amp", "fp16", "--epochs", "2"])
+    try:
+        main_pretrain.main(args)
+        assert _lib.half() == "f16" and args.compute_dtype == "fp16" and args.loss_scale == "dynamic"
+    finally:
+        _lib.set_half("bf16")
+    lines = open(os.path.join(tmp_path, "log.txt")).read().strip().split("\n")
+    stats = [json.loads(l) for l in lines[1:]]
+    assert [s["epoch"] for s in stats] == [0, 1]
+    assert all(s[k] == s[k] for s in stats for k in ("train_mim_loss", "train_res_loss", "train_mlm_loss"))
+    assert stats[-1]["train_mlm_loss"] < stats[0]["train_mlm_loss"] and stats[-1]["train_mim_loss"] < stats[0]["train_mim_loss"]
+    ck = torch.load(os.path.join(tmp_path, "checkpoint-0.pth"), map_location="cpu", weights_only=False)
+    assert ck["scaler"]["scale"] == 65536.0 and ck["scaler"]["_growth_tracker"] == 2 and ck["scaler"]["growth_interval"] == 2000
+    assert all(v.dtype == torch.float32 for v in ck["model"].values() if v.is_floating_point())     # masters are f32 in every mode
+    assert float(ck["optimizer"]["state"][0]["step"]) == 2.0
+
+
 def test_checkpoint_round_trip_and_torch_adamw_compat(dev, tmp_path):
     from ecamp_amd import optim
     from ecamp_amd.data import synthetic_batch
