@@ -34,7 +34,8 @@ def main():
     model.to(dev).eval()               # dropout off (its streams differ per rank); gradients still flow
     net = DistributedDataParallel(model, grad_dtype=torch.bfloat16 if os.environ.get("ECAMP_DDP_GRAD_DTYPE") == "bf16" else None)
     opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=1e-3, betas=(0.9, 0.95))
-    scaler = NativeScalerWithGradNormCount()
+    dyn = os.environ.get("ECAMP_TEST_LOSS_SCALE") == "dynamic"    # GradScaler semantics, decided on the device, behind the all-reduce
+    scaler = NativeScalerWithGradNormCount(dynamic=dyn)
     per = B // world
     mb = per // accum
     opt.zero_grad()
@@ -46,6 +47,11 @@ def main():
         loss = (mim + res + mlm) / accum
         if a < accum - 1:
             scaler(loss, opt, parameters=model.parameters(), update_grad=False)
+        elif dyn:
+            norm = scaler(loss, opt, parameters=model.parameters(), update_grad=True)
+            assert scaler.last_step_fused and scaler.skipped_steps == 0 and opt.steps_taken == 1
+            torch.cuda.synchronize()
+            flat_g = model.arena.flat_g.detach().cpu().clone() / 65536.0     # p.grad keeps the scaled values until zero_grad()
         else:
             loss.backward()
             arena = model.arena

@@ -294,7 +294,7 @@ def test_lazy_zero_grad_matches_memset_and_flushes_unwritten_weights(dev):
                 assert (g - b[k]).abs().max().item() <= 5e-3 * b[k].abs().max().item() + 1e-9, k
 
 
-@pytest.mark.parametrize("accum,branches,gdt", [(1, 0, "f32"), (2, 0, "f32"), (1, 1, "f32"), (1, 0, "bf16")])
+@pytest.mark.parametrize("accum,branches,gdt", [(1, 0, "f32"), (2, 0, "f32"), (1, 1, "f32"), (1, 0, "bf16"), (2, 0, "f32+dynamic-loss-scale")])
 def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum, branches, gdt):
     """SURVEY.md section 4, "distributed without a cluster" (main_pretrain.py:247-250): two data-parallel ranks of B=4 (accum 1) or
     2 x B=2 with no_sync on the first micro-step (accum 2) must leave, after the bucketed all-reduce, the SAME gradient arena and
@@ -303,7 +303,9 @@ def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum, branches, gdt)
     wrapper's parameter broadcast must overwrite.  fp32 parity mode, tiny config, recipe inputs.  branches=1: the ranks run with
     ECAMP_OVERLAP_BRANCHES=1 (image decoder and report side on two streams, forward and backward): a bucket reported from a
     branch-stream node must still wait for the main stream's share of its gradients.  gdt = "bf16": the optional bf16
-    gradient exchange (round 4: half the bytes on the links) -- the arena then agrees to bf16 rounding (contract 1e-2, measured ~3e-3)."""
+    gradient exchange (round 4: half the bytes on the links) -- the arena then agrees to bf16 rounding (contract 1e-2, measured ~3e-3).
+    "f32+dynamic-loss-scale": the ranks run the reference's GradScaler (loss x 65536 in every micro-step, the overflow check over the
+    ALL-REDUCED arena, skip / un-scale decided on the device) and must land on the same gradients, norm and parameters."""
     import socket
     import subprocess
     import sys
@@ -338,7 +340,9 @@ def test_ddp_two_ranks_equal_single_process(dev, tmp_path, accum, branches, gdt)
     sock.close()
     out = os.path.join(tmp_path, "ddp_rank0.pt")
     worker = os.path.join(root, "tests", "_ddp_worker.py")
-    env = dict(os.environ, ECAMP_OVERLAP_BRANCHES=str(branches), ECAMP_DDP_GRAD_DTYPE=gdt)
+    dyn = gdt.endswith("dynamic-loss-scale")
+    gdt = gdt.split("+")[0]
+    env = dict(os.environ, ECAMP_OVERLAP_BRANCHES=str(branches), ECAMP_DDP_GRAD_DTYPE=gdt, ECAMP_TEST_LOSS_SCALE="dynamic" if dyn else "none")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(accum), out], cwd=root, env=env) for r in range(2)]
     rcs = [p.wait(timeout=600) for p in procs]
     assert rcs == [0, 0], rcs
