@@ -371,7 +371,7 @@ def main():
                 "allreduce_ms_per_step": round(red.comm_ms() / args.steps, 3),
                 "channels": rccl_env_record(rccl_log),
                 "adamw": "%d of %d optimizer steps ran bucket by bucket behind each bucket's all-reduce (ECAMP_BUCKETWISE_ADAMW; the rest: one pass "
-                         "after the last all-reduce)" % (opt.bucketwise_steps, opt._step),
+                         "after the last all-reduce)" % (opt.bucketwise_steps, opt.steps_taken),
                 "note": "all-reduce of the f32 gradient arena in buckets on a side HIP stream, overlapped with backward; ms = sum of the "
                         "buckets' event-bracketed durations on that stream on rank 0 (they overlap compute, so this is not added step time)"}
         red.timing = False
