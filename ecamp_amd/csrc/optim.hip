@@ -138,7 +138,8 @@ extern "C" int ecamp_adamw_grouped(float* p, const float* g, float* m, float* v,
 // torch.cuda.amp.GradScaler's unscale_ / step / update (util/misc.py:262-269; torch 1.13.1 grad_scaler.py, _amp_update_scale_) as ONE
 // single-thread kernel, so that the host never reads the overflow flag: `sumsq` is sum(g^2) over the SCALED gradients (inf / nan when
 // any element overflowed).  state = {scale, growth tracker, skipped steps, -}; opt_step = AdamW's count of steps actually taken;
-// ctl = {1 / scale of THIS step, skip flag, 1 - beta1^step, 1 / sqrt(1 - beta2^step)} is what ecamp_adamw_grouped reads.
+// ctl = {1 / scale of THIS step, skip flag, 1 - beta1^step, 1 / sqrt(1 - beta2^step)} is what ecamp_adamw_grouped reads.  (The counters are
+// f32: exact to 2^24 = 16.7 M steps, fifteen times the reference's 800-epoch schedule.)
 __global__ void loss_scale_update_kernel(const float* __restrict__ sumsq, float* __restrict__ state, float* __restrict__ opt_step,
                                          float* __restrict__ ctl, float* __restrict__ norm_out, float growth, float backoff, float interval,
                                          float b1, float b2) {
