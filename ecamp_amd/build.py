@@ -46,10 +46,13 @@ def _stale(target, deps):
 def build(force=False, verbose=True, half="bf16"):
     """`half`: "bf16" -> libecamp_hip.so, "f16" -> libecamp_hip_f16.so (objects under build/f16), "both"."""
     if half == "both":
-        build(force, verbose, "bf16")
+        lib = build(force, verbose, "bf16")
         build(force, verbose, "f16")
-        return LIB
-    OBJ, LIB, FLAGS = _variant(half)
+        return lib
+    return _build_variant(force, verbose, *_variant(half))
+
+
+def _build_variant(force, verbose, OBJ, LIB, FLAGS):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"

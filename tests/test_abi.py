@@ -169,3 +169,15 @@ def test_wgrad_group_item_table_covers_every_k_tile_once(lib):
             for x in range(8):
                 assert len({int(items[w][3]) for w in range(x, P, 8)}) <= 2
     assert lib.ecamp_set_option(b"p8_wgrad_reserve_cus", 0) == 0
+
+
+def test_graft_entry_build_is_what_the_driver_runs():
+    """`__graft_entry__.build()` -- the driver's "does it build" check -- compiles (incrementally) and loads BOTH libraries and returns;
+    `python -m ecamp_amd.build` is the same call (round 6 shipped, for two hours, a build("both") that built everything and then raised)."""
+    import subprocess
+    import sys
+    import __graft_entry__ as g
+    g.build()
+    assert set(_lib._libs) >= {"bf16", "f16"}
+    r = subprocess.run([sys.executable, "-m", "ecamp_amd.build"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
