@@ -1058,6 +1058,7 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
     for (int j0 = wave * 16; j0 < a.Tk; j0 += nw * 16) {
         const int kj = j0 + li;
         const bool jok = KB[kj] == 0.f;
+        const f32x2 kb2 = {KB[kj], KB[kj]};     // 0 or -1e30
         // this lane's key in the forward pass's byte layout: tile pair, 4-key group, bit position
         const unsigned char* mcol = MB + ((((kj & 15) >> 2) * 8 + (kj >> 5)) * prow);
         const int mbit = 4 * ((kj >> 4) & 1) + (kj & 3);
@@ -1074,8 +1075,13 @@ __global__ __launch_bounds__(256, (FLAGS == 0 && HD == 32) ? 5 : (FLAGS == 0 && 
                 const f32x4 dl4 = *reinterpret_cast<const f32x4*>(DL + it * 16 + 4 * g);
                 const f32x2 sc = {sc2, sc2};
                 f32x2 d0 = {dp[0], dp[1]}, d1 = {dp[2], dp[3]};
-                f32x2 p0 = hexp2((f32x2){s[0], s[1]} * sc - (f32x2){lse4[0], lse4[1]});
-                f32x2 p1 = hexp2((f32x2){s[2], s[3]} * sc - (f32x2){lse4[2], lse4[3]});
+                // (a masked key: its score is NOT part of lse, so 2^(s - lse) can be anything -- 1e6 was seen 230 steps into a run; in IEEE half
+                // that is inf, inf x 0 in the dV accumulation is NaN, and the "x 0" at the store below keeps it NaN: the key's bias goes into the
+                // exponent, as in phase 1, and the probability is exactly 0)
+                f32x2 e0 = (f32x2){s[0], s[1]} * sc - (f32x2){lse4[0], lse4[1]}, e1 = (f32x2){s[2], s[3]} * sc - (f32x2){lse4[2], lse4[3]};
+                if (FLAGS) { e0 += kb2; e1 += kb2; }
+                f32x2 p0 = hexp2(e0);
+                f32x2 p1 = hexp2(e1);
                 if (FLAGS && a.drop_p > 0.f) {
                     float dm[4];
                     if (use_bits) {

@@ -375,6 +375,21 @@ def test_attention_saved_dropout_bits_equal_regenerated_mask(dev, B, H, Tq, Tk, 
                                                          (2, 12, 50, 50, 64, False, False, 0.2),
                                                          (1, 4, 250, 256, 64, True, False, 0.1)])    # the longest head-resident sequence
 def test_attention_dropout_matches_pytorch_under_the_same_mask(dev, dtype, B, H, Tq, Tk, hd, masked, cross, p):
+    _attn_dropout_case(dev, dtype, B, H, Tq, Tk, hd, masked, cross, p)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,Tq,Tk,hd,p", [(2, 6, 128, 128, 128, 0.1), (2, 6, 128, 128, 128, 0.0), (1, 4, 250, 256, 64, 0.1), (2, 3, 33, 17, 32, 0.3)])
+def test_attention_padded_keys_with_large_scores_stay_out_of_the_gradients(dev, dtype, B, H, Tq, Tk, hd, p):
+    """A padded report token is a key like any other to the QK^T product: its raw score is not part of the row's log-sum-exp, so
+    2^(s - lse) can be astronomically large (seen: 233 steps into a run in IEEE half, where it is inf and inf x 0 = NaN turned dV of the
+    padded key, then every gradient upstream of the value projection, into NaN -- the dynamic loss scaler halved itself to zero).  Keys
+    behind the mask carry 40 x the scale of the real ones here: forward and all three gradients must equal the reference, and the padded
+    keys' dK / dV rows must be exactly zero."""
+    _attn_dropout_case(dev, dtype, B, H, Tq, Tk, hd, True, False, p, pad_scale=40.0)
+
+
+def _attn_dropout_case(dev, dtype, B, H, Tq, Tk, hd, masked, cross, p, pad_scale=1.0):
     """HF BertSelfAttention in TRAIN mode (context_fusion.py:28-57 / bert_modeling.py:131: `attention_probs = self.dropout(probs)`):
     out = (softmax(s) * keep / (1 - p)) @ v and its gradients, against plain fp32 PyTorch under the SAME keep-mask -- the Philox mask of
     (seed, offset) materialised by the development ABI `ecamp_dropout_mask` (element index ((b*H + h)*Tq + i)*Tk + j).  Both the
@@ -391,8 +406,11 @@ def test_attention_dropout_matches_pytorch_under_the_same_mask(dev, dtype, B, H,
     if masked:
         lens = torch.randint(max(1, Tk // 3), Tk + 1, (B,), generator=torch.Generator().manual_seed(7))
         km = (torch.arange(Tk)[None, :] < lens[:, None]).int()
-    keep = o.dropout_mask((B, H, Tq, Tk), dev, p, seed, offset).float().cpu()
-    assert abs(keep.mean().item() - (1 - p)) < 0.02
+        if pad_scale != 1.0:
+            assert not cross
+            k = torch.where(km[:, :, None].bool(), k, rnd(k * pad_scale, dtype))
+    keep = o.dropout_mask((B, H, Tq, Tk), dev, p, seed, offset).float().cpu() if p > 0 else torch.ones(B, H, Tq, Tk)
+    assert p == 0 or abs(keep.mean().item() - (1 - p)) < 0.02
     off = 1 if cross else 0
     qr, kr, vr = q.clone().requires_grad_(True), k.clone().requires_grad_(True), v.clone().requires_grad_(True)
     sp = lambda t, n: t.view(B, n, H, hd).permute(0, 2, 1, 3)
@@ -416,6 +434,9 @@ def test_attention_dropout_matches_pytorch_under_the_same_mask(dev, dtype, B, H,
         check("dropout attn dq (%s)" % tag, dq, qr.grad, tol * 2)
         check("dropout attn dk (%s)" % tag, dk, kr.grad, tol * 2)
         check("dropout attn dv (%s)" % tag, dv, vr.grad, tol * 2)
+        if pad_scale != 1.0:
+            pad = (km == 0)
+            assert float(dk.float().cpu()[pad].abs().max()) == 0.0 and float(dv.float().cpu()[pad].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dtype", DT)
