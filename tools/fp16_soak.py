@@ -11,14 +11,14 @@ from ecamp_amd.module import model_ecamp
 from ecamp_amd.util.misc import NativeScalerWithGradNormCount
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=600); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--model", default="ecamp")
-ap.add_argument("--lr", type=float, default=1.5e-4); ap.add_argument("--nbatches", type=int, default=12); ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+ap.add_argument("--lr", type=float, default=1.5e-4); ap.add_argument("--nbatches", type=int, default=12); ap.add_argument("--growth_interval", type=int, default=200); ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 big = 896 if "448" in args.model else 448
 model = getattr(model_ecamp, args.model)(compute_dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16).to(dev); model.prepare(); model.train()
 opt = optim.FusedAdamW(optim.add_weight_decay(model, 0.05), lr=args.lr, betas=(0.9, 0.95))
-scaler = NativeScalerWithGradNormCount(dynamic=True, growth_interval=200)     # (200, not 2000: the scale climbs into real overflows within the run)
+scaler = NativeScalerWithGradNormCount(dynamic=True, growth_interval=args.growth_interval)     # (200, not 2000: the scale climbs within the run; 10: it hunts at half's ceiling)
 batches = [synthetic_batch(args.batch, 128, big, seed=100 + i, device=dev) for i in range(args.nbatches)]
 log = []
 torch.cuda.synchronize(); t0 = time.perf_counter()
