@@ -123,6 +123,68 @@ def test_checkpoint_round_trip_and_torch_adamw_compat(dev, tmp_path):
     assert torch.equal(m3.blocks[0].norm1.weight.cpu(), ck["model"]["blocks.0.norm1.weight"])
 
 
+def test_resume_in_fp16_continues_the_scaler_and_the_step_count(dev, tmp_path):
+    """`--amp fp16` across a checkpoint: three optimizer attempts (the second one overflows: a report weight of 3e38 makes the scaled loss inf),
+    save, load into fresh model / optimizer / scaler objects, three more steps -- against the same six steps without the interruption.
+    What must survive: the loss scale after its backoff, the growth tracker, the skipped-step count's effect on AdamW's bias corrections
+    (`step` = steps actually TAKEN), the f32 masters and moments.  Parameters agree to the atomics' summation order."""
+    import argparse
+    from ecamp_amd import optim
+    from ecamp_amd.data import synthetic_batch
+    from ecamp_amd.module import model_ecamp as me
+    from ecamp_amd.util import misc
+    batches = [synthetic_batch(4, 32, 448, seed=30 + i) for i in range(6)]
+    batches[1]["weights"] = batches[1]["weights"].clone()
+    batches[1]["weights"][0, 0] = 3e38
+    noise = torch.linspace(0, 1, 196).repeat(4, 1)
+
+    def fresh():
+        torch.manual_seed(1)
+        m = me.ecamp_tiny(compute_dtype=torch.float16).to(dev)
+        m.prepare()
+        m.eval()
+        return m, optim.FusedAdamW(optim.add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95)), misc.NativeScalerWithGradNormCount(dynamic=True, growth_interval=2)
+
+    def steps(m, o, sc, lo, hi):
+        for i in range(lo, hi):
+            o.zero_grad()
+            sc(sum(m(batches[i], noise=noise)), o, parameters=m.parameters(), update_grad=True)
+
+    m1, o1, s1 = fresh()
+    steps(m1, o1, s1, 0, 6)
+    m2, o2, s2 = fresh()
+    steps(m2, o2, s2, 0, 3)
+    assert s2.skipped_steps == 1 and o2.steps_taken == 2 and s2.get_scale() == 32768.0 and s2.state_dict()["_growth_tracker"] == 1   # clean, overflow (x 0.5), clean
+    args = argparse.Namespace(output_dir=str(tmp_path), resume="")
+    misc.save_model(args=args, epoch=0, model=m2, model_without_ddp=m2, optimizer=o2, loss_scaler=s2)
+    ck = torch.load(os.path.join(tmp_path, "checkpoint-0.pth"), map_location="cpu", weights_only=False)
+    assert float(ck["optimizer"]["state"][0]["step"]) == 2.0 and ck["scaler"]["scale"] == 32768.0 and ck["scaler"]["_growth_tracker"] == 1
+    m3, o3, s3 = fresh()
+    with torch.no_grad():
+        for p in m3.parameters():
+            p.add_(1.0)     # whatever the fresh objects hold must be overwritten
+    link = "./ECAMP_ckpt_fp16.pth"
+    os.symlink(os.path.join(tmp_path, "checkpoint-0.pth"), link) if not os.path.exists(link) else None
+    try:
+        misc.load_model(args=argparse.Namespace(resume=link, start_epoch=0), model_without_ddp=m3, optimizer=o3, loss_scaler=s3)
+    finally:
+        os.remove(link)
+    m3.eval()
+    steps(m3, o3, s3, 3, 6)
+    assert o3.steps_taken == o1.steps_taken == 5 and s3.state_dict() == s1.state_dict(), (o3.steps_taken, o1.steps_taken, s3.state_dict(), s1.state_dict())
+    # the yardstick is a second uninterrupted run: AdamW moves an element by ~lr x m / sqrt(v), and where a gradient is rounding noise the
+    # summation order of the f32 atomics decides its sign -- two identical runs already differ by a fraction of a learning-rate step there
+    m4, o4, s4 = fresh()
+    steps(m4, o4, s4, 0, 6)
+    for n in ("blocks.3.mlp.fc1.weight", "bert_encoder.model.cls.predictions.decoder.weight", "decoder_pred.bias", "bert_encoder.model.bert.embeddings.LayerNorm.weight"):
+        a, b, c = (dict(m.named_parameters())[n].detach().float().cpu() for m in (m1, m3, m4))
+        d_resume, d_twin = (a - b).norm().item() / a.norm().item(), (a - c).norm().item() / a.norm().item()
+        print("  %-60s resumed vs uninterrupted %.2e, two uninterrupted runs %.2e" % (n, d_resume, d_twin))
+        assert torch.isfinite(b).all() and d_resume <= 3 * d_twin + 1e-6, (n, d_resume, d_twin)
+    from ecamp_amd import _lib
+    _lib.set_half("bf16")
+
+
 def test_ddp_wrapper_runs_rccl_on_the_side_stream(dev):
     """One-rank RCCL group with the collectives forced on: the bucketed all-reduce (AVG over one rank = identity) runs on the side
     HIP stream behind the backward stages, and the gradients equal those of the unwrapped model."""
