@@ -1134,7 +1134,7 @@ def test_vit_large_448_b64_is_the_mean_of_its_sub_batches(dev):
     assert le < 2e-3 and ge < 2e-2, (le, ge)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_uint8_image_schema_is_bit_identical_to_the_f32_schema(dev, dtype):
     """The compact image schema (uint8 [B,448,448] grayscale crops, normalised by the bicubic and SR-loss kernels on the fly) against the
     reference's f32 [B,3,448,448] schema holding the same pixels: identical losses and an identical gradient arena, in both compute
