@@ -99,6 +99,15 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
             tb_pending.append((int((data_iter_step / n_iter + epoch) * 1000), reduced, lr))
             if (data_iter_step + 1) % print_freq == 0 or data_iter_step == n_iter - 1:
                 _flush_tb(log_writer, tb_pending)
+        if getattr(loss_scaler, "dynamic", False) and ((data_iter_step + 1) % print_freq == 0 or data_iter_step == n_iter - 1):
+            # GradScaler's state is on the device; it is read back where the meters are printed anyway.  A scale below 1 means every recent
+            # step overflowed whatever the scale -- in IEEE half that is an activation past 65504 in the FORWARD pass (the residual stream is
+            # stored in half here, f32 under the reference's autocast: INTEGRATION.md), and training is no longer making progress
+            sc = loss_scaler.get_scale()
+            metric_logger.update(loss_scale=sc)
+            if sc < 1.0:
+                print("warning: the dynamic loss scale has fallen to %g after %d skipped steps -- every step overflows; fp16 activations out of range?"
+                      % (sc, loss_scaler.skipped_steps))
     if log_writer is not None:
         _flush_tb(log_writer, tb_pending)
     if prof:
