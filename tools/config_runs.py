@@ -27,7 +27,7 @@ def run(name, ctor, B, big, **kw):
         scaler(mim + res + mlm, opt, parameters=model.parameters(), update_grad=True)
         opt.zero_grad()
         return mim, res, mlm
-    for _ in range(6): out = step()   # allocator and weight-quantisation caches settle within a few steps
+    for _ in range(10): out = step()   # allocator and weight-quantisation caches settle within a few steps (fp16 at B = 512 needs more than six)
     torch.cuda.synchronize(); n0 = torch.cuda.memory_stats().get("num_device_alloc", 0); t0 = time.perf_counter()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]; marks[0].record()
     for i in range(args.steps): out = step(); marks[i + 1].record()
