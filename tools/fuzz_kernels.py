@@ -23,7 +23,7 @@ def chk(tag, case, got, ref, tol):
         fails.append((tag, case, e)); print("FAIL %-28s %s rel err %.3e (tol %.1e)" % (tag, case, e, tol), flush=True)
 def randn(*s, scale=1.0, dt=torch.float32):
     return (torch.randn(*s, device=dev) * scale).to(dt)
-ngemm = natt = nln = nce = nrefused = 0
+ngemm = natt = nln = nce = ngrp = nrefused = 0
 for half, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
     _lib.set_half(half)
     tol = TOL[dt]
@@ -102,6 +102,32 @@ for half, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
             natt += 1
         except Exception as e:
             if "EcampHipError" not in type(e).__name__: fails.append(("exception", case, repr(e)[:200])); print("FAIL exception", case, repr(e)[:300], flush=True)
+        # ---- grouped weight gradients: 1-4 layers sharing a row count, ragged shapes, overwrite / accumulate, with / without bias gradient
+        rows_g = rng.choice([256 * rng.randint(1, 8), 8 * rng.randint(32, 1600), 12800, 6304])
+        nl = rng.randint(1, 4)
+        case = "%s wgrad_group rows=%d layers=%d" % (half, rows_g, nl)
+        try:
+            items, refs = [], []
+            for i in range(nl):
+                n_out, k_in = 8 * rng.randint(2, 200), 8 * rng.randint(2, 200)
+                dy, x = randn(rows_g, n_out, scale=0.5, dt=dt), randn(rows_g, k_in, dt=dt)
+                acc = rng.random() < 0.5
+                base = randn(n_out, k_in) if acc else torch.zeros(n_out, k_in, device=dev)
+                gbias = torch.ones(n_out, device=dev) if rng.random() < 0.6 else None
+                items.append((dy, x, base.clone(), gbias, acc))
+                refs.append((base + dy.float().T @ x.float(), None if gbias is None else 1.0 + dy.float().sum(0)))
+                case += " [%dx%d%s%s]" % (n_out, k_in, "+" if acc else "", "b" if gbias is not None else "")
+            if o.wgrad_group_supported(items):
+                o.wgrad_group(items)
+                for (dy, x, gw, gbias, acc), (rw, rb) in zip(items, refs):
+                    chk("wgrad_group dW", case, gw, rw, 1e-2)
+                    if gbias is not None: chk("wgrad_group db", case, gbias, rb, 1e-2)
+                ngrp += 1
+            else:
+                nrefused += 1
+        except Exception as e:
+            if "EcampHipError" not in type(e).__name__: fails.append(("exception", case, repr(e)[:200])); print("FAIL exception", case, repr(e)[:300], flush=True)
+            else: nrefused += 1
         # ---- LayerNorm (+ residual, + dropout under the library's own mask) forward / backward, and the weighted cross-entropy
         rows = rng.choice([rng.randint(1, 64), rng.randint(64, 3000), 12800]); cols = rng.choice([64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048])
         use_res = rng.random() < 0.5; p = rng.choice([0.0, 0.1])
@@ -147,6 +173,6 @@ for half, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
             if "EcampHipError" not in type(e).__name__: fails.append(("exception", case, repr(e)[:200])); print("FAIL exception", case, repr(e)[:300], flush=True)
             else: nrefused += 1
 _lib.set_half("bf16")
-print("fuzz: %d GEMM cases, %d attention cases, %d LayerNorm cases, %d cross-entropy cases (%d shapes refused by the library with an error), %d failures"
-      % (ngemm, natt, nln, nce, nrefused, len(fails)), flush=True)
+print("fuzz: %d GEMM cases, %d attention cases, %d grouped weight-gradient cases, %d LayerNorm cases, %d cross-entropy cases (%d shapes refused by the library), %d failures"
+      % (ngemm, natt, ngrp, nln, nce, nrefused, len(fails)), flush=True)
 sys.exit(1 if fails else 0)
