@@ -78,8 +78,10 @@ class ECAMP(nn.Module):
                  decoder_depth=4, decoder_num_heads=6, mlp_ratio=4.0, norm_layer=nn.LayerNorm, norm_pix_loss=False,
                  bert_config=None, compute_dtype=torch.bfloat16, sr_window=None, fp8_forward=False, gelu_saved_grad=None):
         super().__init__()
-        if in_chans != 3 or patch_size % 4 != 0:
-            raise ValueError("in_chans must be 3 and patch_size a multiple of 4")
+        if in_chans != 3 or patch_size != 16:
+            # (the SR head's fused kernels are built for 32-px super-patches = patch 16, the only value the reference constructs,
+            # model_ecamp.py:328-333; refused here instead of at the first forward's ecamp_sr_fwd)
+            raise ValueError("in_chans must be 3 and patch_size 16")
         for d, h in ((embed_dim, num_heads), (decoder_embed_dim, decoder_num_heads)):
             if d % h != 0 or d // h not in (32, 64, 128):
                 raise ValueError("head_dim must be 32, 64 or 128 (got %d/%d)" % (d, h))

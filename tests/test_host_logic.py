@@ -109,6 +109,8 @@ def test_bad_configs_are_rejected():
         BertConfig(hidden_act="relu")
     with pytest.raises(ValueError):
         me.ECAMP(compute_dtype=torch.float64)
+    with pytest.raises(ValueError, match="patch_size 16"):
+        me.ECAMP(img_size=128, patch_size=8)     # the SR head's kernels are built for patch 16: said at construction, not at the first forward
 
 
 def test_synthetic_dataset_schema():
