@@ -21,19 +21,23 @@ rng = random.Random(args.seed)
 TOL = {torch.float32: (2e-4, 1e-3, 2e-3), torch.bfloat16: (3e-2, 1.5e-2, 6e-2), torch.float16: (1e-3, 3e-3, 1e-2)}
 fails = refused = 0
 for c in range(args.cases):
-    img, patch = rng.choice([(224, 16), (112, 8), (256, 16), (336, 16), (448, 16), (288, 16), (400, 16)])
+    img, patch = rng.choice([(224, 16), (256, 16), (336, 16), (448, 16), (288, 16), (400, 16)])
     hd, H = rng.choice([32, 64, 128]), rng.randint(1, 6)
     hdd, Hd = rng.choice([32, 64, 128]), rng.randint(1, 6)
     depth, ddepth, mlp, bl = rng.randint(1, 2), rng.randint(1, 2), rng.choice([2.0, 4.0]), rng.randint(1, 2)
     grid = img // patch
+    # the report side: hidden width / heads / intermediate width / vocabulary other than the reference's 768 / 6 / 1536 / 30000 half of the time
+    bh, bH = rng.choice([(768, 6), (768, 6), (384, 6), (512, 4), (256, 8), (640, 5), (1024, 8)])
+    binter, vocab = rng.choice([2, 4]) * bh if rng.random() < 0.5 else 1536, rng.choice([30000, 30000, 1000, 8000, 30528])
     cfg = orc.Cfg(img_size=img, patch_size=patch, embed_dim=hd * H, depth=depth, num_heads=H, decoder_embed_dim=hdd * Hd, decoder_depth=ddepth,
-                  decoder_num_heads=Hd, mlp_ratio=mlp, sr_window=(12 * grid) // 14, bert=orc.BertCfg(num_hidden_layers=bl))
+                  decoder_num_heads=Hd, mlp_ratio=mlp, sr_window=(12 * grid) // 14,
+                  bert=orc.BertCfg(num_hidden_layers=bl, hidden_size=bh, num_attention_heads=bH, intermediate_size=binter, vocab_size=vocab))
     B, S = rng.randint(1, 4), rng.randint(8, 160)
     mr = rng.choice([0.5, 0.75])
     state = recipe.recipe_state(cfg, seed=c)
     batch = recipe.recipe_batch(cfg, B, S, seed=200 + c)
     noise = recipe.recipe_noise(B, cfg.num_patches, seed=200 + c)
-    tag = "img %d patch %d enc %dx%d (hd %d) depth %d dec %dx%d (hd %d) depth %d mlp %.0f bert %d B %d S %d mask %.2f" % (img, patch, H, hd, hd, depth, Hd, hdd, hdd, ddepth, mlp, bl, B, S, mr)
+    tag = "img %d patch %d enc %dx%d (hd %d) depth %d dec %dx%d (hd %d) depth %d mlp %.0f bert %d x %d/%d/%d vocab %d B %d S %d mask %.2f" % (img, patch, H, hd, hd, depth, Hd, hdd, hdd, ddepth, mlp, bl, bh, bH, binter, vocab, B, S, mr)
     P = orc.set_requires_grad(orc.load_state(orc.new_params(cfg), state), cfg)
     ref = orc.forward(P, cfg, batch, mr, noise)
     sum(ref).backward()
@@ -41,7 +45,7 @@ for c in range(args.cases):
     for dtype in (torch.float32, torch.bfloat16, torch.float16):
         try:
             model = me.ECAMP(img_size=img, patch_size=patch, in_chans=3, embed_dim=hd * H, depth=depth, num_heads=H, decoder_embed_dim=hdd * Hd, decoder_depth=ddepth,
-                             decoder_num_heads=Hd, mlp_ratio=mlp, norm_layer=partial(nn.LayerNorm, eps=1e-6), bert_config=BertConfig(num_hidden_layers=bl), compute_dtype=dtype)
+                             decoder_num_heads=Hd, mlp_ratio=mlp, norm_layer=partial(nn.LayerNorm, eps=1e-6), bert_config=BertConfig(num_hidden_layers=bl, hidden_size=bh, num_attention_heads=bH, intermediate_size=binter, vocab_size=vocab), compute_dtype=dtype)
             model.load_state_dict(state, strict=True); model.to(dev).eval()
             out = model(batch, mask_ratio=mr, noise=noise)
             ls = 65536.0 if dtype == torch.float16 else 1.0
